@@ -1,0 +1,66 @@
+"""ctypes binding of libmanet_hip.so -- the C ABI declared in include/manet_hip.h.
+
+There is no fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmanet_hip.so")
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i = ctypes.c_int
+_sz = ctypes.c_size_t
+_szp = ctypes.POINTER(ctypes.c_size_t)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+# name -> (restype, argtypes); must list every symbol of include/manet_hip.h
+SIGNATURES = {
+    "manet_version": (ctypes.c_char_p, []),
+    "manet_last_error_string": (ctypes.c_char_p, []),
+    "manet_global_match_workspace_bytes": (_i, [_i64, _i64, _i, _i, _i, _i, _szp]),
+    "manet_global_match": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _vp,
+                                _vp, _i, _vp, _sz, _vp]),
+    "manet_bank_workspace_bytes": (_i, [_i64, _i, _i, _i, _szp]),
+    "manet_match_workspace_bytes": (_i, [_i64, _i64, _i, _i, _i, _i, _szp]),
+    "manet_bank_prepare": (_i, [_vp, _i64, _i64, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
+    "manet_global_match_prepared": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _i,
+                                         _vp, _sz, _vp]),
+    "manet_normalize_merge_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "manet_local_workspace_bytes": (_i, [_i, _i, _i, _i, _i, _szp]),
+    "manet_local_dist_f32": (_i, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _i, _vp,
+                                  _vp, _sz, _vp]),
+    "manet_local_match_f32": (_i, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i,
+                                   _i, _vp, _vp, _sz, _vp]),
+    "manet_correlation_out_dims": (_i, [_i, _i, _i, _i, _i, _i, _i, _ip, _ip, _ip]),
+    "manet_correlation_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+}
+
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2
+EPI_NORMALIZE = 1
+
+_lib = None
+
+
+def load():
+    """Load libmanet_hip.so (built by csrc/Makefile, see __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "cvpr2020_manet_amd: %s is missing -- build it with "
+                "`make -C cvpr2020_manet_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().manet_last_error_string().decode("utf-8", "replace")
+        raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg))

@@ -1,0 +1,547 @@
+// Global nearest-neighbour matching for MI355X (gfx950).
+//
+// Replaces networks/IntVOS.py:160-210 (nearest_neighbor_features_per_object) and its helpers
+// (:23-40 pairwise distances, :62-97 masked min, :100-109 pixel selection, :113-157 chunk loop)
+// plus, as a fused epilogue, :611-612 (normalise) and :615-622 (min-aggregation with the stored
+// per-frame global map).
+//
+// Design (see DESIGN.md for the numbers):
+//   * The N x M distance matrix is never materialised.  d(n,m) = (|q_n|^2 + |k_m|^2) - 2 q_n.k_m
+//     is produced tile by tile on the matrix cores and reduced to a running minimum in registers.
+//   * The contraction runs on v_mfma_f32_32x32x2_f32 with the operands SWAPPED (A = bank rows,
+//     B = query pixels): an accumulator register then holds one query column and 16 bank rows, so
+//     the reduction over the bank is lane-local (one v_min per element) and only the two 32-lane
+//     halves have to be combined at the end (one cross-lane shuffle per object).
+//   * bank rows are SORTED BY OBJECT ID in a pre-pass (counting sort; rows whose label is not an
+//     object id are dropped, which is what the reference's pixel selection / 1e20 mask amounts
+//     to).  Every 64-row bank tile then belongs to one object: no per-element label compare, and
+//     work shrinks with the number of labelled pixels.
+//   * the pre-pass writes the bank in the exact LDS image the MFMA loop wants ([k-group][k-parity]
+//     [row][4 k] floats, conflict-free ds_read_b128) so a tile is staged by linear, fully
+//     coalesced global_load_lds_dwordx4 (no VGPR round trip), double buffered, one barrier/tile.
+//   * the 64 queries x C operand of a wave lives in registers for the whole kernel.
+//   * grid = (256-query tiles) x (S bank splits), split index tied to blockIdx % 8 so that the
+//     workgroups of one XCD stream the same bank range through that XCD's L2.  Splits combine by
+//     atomicMin on order-preserving integer keys; a last tiny kernel decodes, normalises and
+//     min-merges with the stored map.
+//
+// Numerics of the fp32 path: the MFMA is a k-ascending fmaf chain from 0, d = fmaf(-2, mm, xs+ys);
+// min is exact -- so the result is bit-identical to oracle/manet_oracle.c.
+#include "manet_common.h"
+
+namespace {
+
+constexpr int QT = 256;       // queries per workgroup (4 waves x 2 blocks of 32)
+constexpr int QB = 32;        // queries per packed block (one MFMA N dimension)
+constexpr int BT = 64;        // bank rows per tile (2 MFMA M blocks)
+constexpr int META_INTS = 256;
+constexpr int META_T = 0;          // [0]        number of bank tiles actually used
+constexpr int META_SEG = 1;        // [1..65]    first tile of object o (entry n_ids = T)
+constexpr int META_CUR = 66;       // [66..129]  scatter cursors (row slots)
+constexpr int META_CNT = 130;      // [130..193] rows per object
+
+__host__ __device__ constexpr int ng_of(int C) { return (C + 7) / 8; }
+// bank tile: NG x [2 parities][64 rows][4 k] floats, then 64 |k|^2, padded to whole 1 KiB pieces
+__host__ __device__ constexpr size_t bank_tile_bytes(int NG)
+{
+    return ((size_t)NG * 2 * BT * 4 * 4 + BT * 4 + 1023) / 1024 * 1024;
+}
+// query block: NG x [2][32][4] floats, then 32 |q|^2
+__host__ __device__ constexpr size_t query_block_bytes(int NG) { return (size_t)NG * 2 * QB * 4 * 4 + QB * 4; }
+
+int pick_ng(int C)
+{
+    if (C <= 32) return 4;
+    if (C <= 104) return 13;
+    return 16;
+}
+
+struct BankLayout {
+    int NG;
+    size_t tile_bytes;
+    long T_max;  // upper bound on tiles: every object wastes < 1 tile
+    size_t off_meta, off_src, off_pack, total;
+};
+
+BankLayout bank_layout(int64_t M0, int C, int n_ids)
+{
+    BankLayout L;
+    L.NG = pick_ng(C);
+    L.tile_bytes = bank_tile_bytes(L.NG);
+    L.T_max = (long)((M0 + BT - 1) / BT) + n_ids;
+    L.off_meta = 0;
+    L.off_src = manet_align_up(META_INTS * sizeof(int), 256);
+    L.off_pack = manet_align_up(L.off_src + (size_t)L.T_max * BT * sizeof(int), 1024);
+    L.total = manet_align_up(L.off_pack + (size_t)L.T_max * L.tile_bytes, 1024);
+    return L;
+}
+
+struct MatchLayout {
+    int NG;
+    long N_pad;
+    int nQT;
+    size_t qblk_bytes, off_q, off_keys, total;
+};
+
+MatchLayout match_layout(int64_t N, int C, int n_ids)
+{
+    MatchLayout L;
+    L.NG = pick_ng(C);
+    L.nQT = (int)((N + QT - 1) / QT);
+    L.N_pad = (long)L.nQT * QT;
+    L.qblk_bytes = query_block_bytes(L.NG);
+    L.off_q = 0;
+    L.off_keys = manet_align_up((size_t)(L.N_pad / QB) * L.qblk_bytes, 256);
+    L.total = manet_align_up(L.off_keys + (size_t)n_ids * L.N_pad * sizeof(unsigned), 1024);
+    return L;
+}
+
+// number of bank splits: enough workgroups for >= ~16 rounds of the 512 resident slots
+// (256 CUs x 2 workgroups) so the last partial round costs little, but >= 4 tiles per split.
+int pick_splits(int nQT, long T_max)
+{
+    long want = (16L * 512 + nQT - 1) / nQT;
+    long cap = T_max / 4;
+    long S = want < cap ? want : cap;
+    S = (S + 7) / 8 * 8;
+    if (S < 8) S = 8;
+    if (S > 512) S = 512;
+    return (int)S;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pre-pass 1: rows per object (IntVOS.py:137: a row counts for object o iff label == o)
+__global__ void label_count_kernel(const int *__restrict__ labels, long M0, int n_ids, int *meta)
+{
+    __shared__ int hist[MANET_MAX_IDS];
+    if (threadIdx.x < MANET_MAX_IDS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M0; i += (long)gridDim.x * blockDim.x) {
+        int lab = labels[i];
+        if (lab >= 0 && lab < n_ids) atomicAdd(&hist[lab], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < n_ids && hist[threadIdx.x]) atomicAdd(&meta[META_CNT + threadIdx.x], hist[threadIdx.x]);
+}
+
+// pre-pass 2: tile ranges per object (each object's rows padded up to whole 64-row tiles)
+__global__ void label_scan_kernel(int n_ids, int *meta)
+{
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int o = 0; o < n_ids; ++o) {
+            meta[META_SEG + o] = t;
+            meta[META_CUR + o] = t * BT;
+            t += (meta[META_CNT + o] + BT - 1) / BT;
+        }
+        meta[META_SEG + n_ids] = t;
+        meta[META_T] = t;
+    }
+}
+
+// pre-pass 3: slot -> source row map (slots not hit stay -1 = padding row)
+__global__ void label_scatter_kernel(const int *__restrict__ labels, long M0, int n_ids, int *meta,
+                                     int *__restrict__ src_of)
+{
+    const int lane = threadIdx.x & 63;
+    const long base = ((long)blockIdx.x * blockDim.x + threadIdx.x) - lane;  // wave's first row
+    for (long w0 = base; w0 < M0; w0 += (long)gridDim.x * blockDim.x) {
+        long i = w0 + lane;
+        int lab = (i < M0) ? labels[i] : -1;
+        bool active = (lab >= 0 && lab < n_ids);
+        // one atomic per (wave, object): ranks inside the wave come from a ballot
+        while (true) {
+            unsigned long long pending = __ballot(active);
+            if (!pending) break;
+            int leader = __ffsll((long long)pending) - 1;
+            int L = __shfl(lab, leader);
+            bool mine = active && (lab == L);
+            unsigned long long mm = __ballot(mine);
+            int rank = __popcll(mm & ((1ull << lane) - 1ull));
+            int start = 0;
+            if (lane == leader) start = atomicAdd(&meta[META_CUR + L], __popcll(mm));
+            start = __shfl(start, leader);
+            if (mine) {
+                src_of[start + rank] = (int)i;
+                active = false;
+            }
+        }
+    }
+}
+
+// pre-pass 4 (bank, ROWS = 64) and query pack (ROWS = 32): write rows in the MFMA operand image
+//   out[tile] = [g][h][row][j] floats with k = 8g + 2j + h (zero beyond C), then |row|^2[ROWS]
+// |row|^2 is the k-ascending fmaf chain of the oracle (IntVOS.py:32,35).
+template <int ROWS>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict__ src, long s_row,
+                                                        long s_c, const int *__restrict__ src_of,
+                                                        const int *__restrict__ meta, long n_rows,
+                                                        int C, int NG, char *__restrict__ dst,
+                                                        long tile_bytes, float pad_norm)
+{
+    const long tile = blockIdx.x;
+    if (meta && tile >= meta[META_T]) return;
+    __shared__ int s_src[ROWS];
+    const int tid = threadIdx.x;
+    if (tid < ROWS) {
+        long slot = tile * ROWS + tid;
+        s_src[tid] = src_of ? src_of[slot] : (slot < n_rows ? (int)slot : -1);
+    }
+    __syncthreads();
+    float *out = (float *)(dst + tile * tile_bytes);
+    for (int item = tid; item < NG * 2 * ROWS; item += 256) {
+        int r = item % ROWS, gh = item / ROWS;
+        int g = gh >> 1, h = gh & 1;
+        int s = s_src[r];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (s >= 0) {
+            const float *row = src + (long)s * s_row;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int k = 8 * g + 2 * j + h;
+                if (k < C) v[j] = row[(long)k * s_c];
+            }
+        }
+        *(f32x4 *)(out + ((long)gh * ROWS + r) * 4) = v;
+    }
+    if (tid < ROWS) {
+        int s = s_src[tid];
+        float n = pad_norm;
+        if (s >= 0) {
+            const float *row = src + (long)s * s_row;
+            n = 0.0f;
+            for (int k = 0; k < C; ++k) {
+                float x = row[(long)k * s_c];
+                n = fmaf(x, x, n);
+            }
+        }
+        out[(long)NG * 2 * ROWS * 4 + tid] = n;
+    }
+}
+
+// order-preserving float -> uint key (so atomicMin on keys == min on floats, negatives included:
+// d may be slightly negative from rounding and must not be clamped)
+__device__ __forceinline__ unsigned key_of(float f)
+{
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_of(unsigned k)
+{
+    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// main kernel, fp32: one workgroup = 256 queries x one bank split
+template <int NG>
+__global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__restrict__ qpack,
+                                                                  const char *__restrict__ bpack,
+                                                                  const int *__restrict__ meta,
+                                                                  int n_ids, int nQT, int S,
+                                                                  long N_pad,
+                                                                  unsigned *__restrict__ keys)
+{
+    constexpr size_t TILE_BYTES = bank_tile_bytes(NG);
+    constexpr int PIECES = (int)(TILE_BYTES / 1024);
+    constexpr size_t QBLK_BYTES = query_block_bytes(NG);
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x TILE_BYTES
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    // XCD-aware mapping: block b runs on XCD b % 8 (observed, used for speed only).  All blocks
+    // of one XCD that are resident together share a bank split -> the split streams through L2.
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int idx = b >> 3;
+    const int qt = idx % nQT;
+    const int s = xcd + 8 * (idx / nQT);
+    const int T = meta[META_T];
+    const int t0 = (int)((long)s * T / S);
+    const int t1 = (int)((long)(s + 1) * T / S);
+    if (t0 >= t1) return;
+
+    auto stage = [&](int t, int buf) {
+        const char *g = bpack + (size_t)t * TILE_BYTES + (size_t)lane * 16;
+        char *l = smem + (size_t)buf * TILE_BYTES;
+#pragma unroll
+        for (int p = 0; p < (PIECES + 3) / 4; ++p) {
+            int piece = p * 4 + wave;
+            if (piece < PIECES)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(g + (size_t)piece * 1024),
+                    (__attribute__((address_space(3))) void *)(l + (size_t)piece * 1024), 16, 0, 0);
+        }
+    };
+    stage(t0, 0);
+
+    // this wave's 2 x 32 queries, resident in registers for the whole kernel (B operand:
+    // lane holds q[j = lane&31][k = 8g + 2jj + (lane>>5)])
+    f32x4 q0[NG], q1[NG];
+    float xs0, xs1;
+    {
+        const char *qb0 = qpack + (size_t)(qt * (QT / QB) + wave * 2) * QBLK_BYTES;
+        const char *qb1 = qb0 + QBLK_BYTES;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            q0[g] = *(const f32x4 *)(qb0 + ((size_t)(g * 2 + h) * QB + l31) * 16);
+            q1[g] = *(const f32x4 *)(qb1 + ((size_t)(g * 2 + h) * QB + l31) * 16);
+        }
+        xs0 = *(const float *)(qb0 + (size_t)NG * 2 * QB * 16 + l31 * 4);
+        xs1 = *(const float *)(qb1 + (size_t)NG * 2 * QB * 16 + l31 * 4);
+    }
+    const long qbase = (long)qt * QT + wave * 64 + l31;
+
+    int o = 0;
+    while (meta[META_SEG + o + 1] <= t0) ++o;  // object owning tile t0
+    int seg_end = meta[META_SEG + o + 1];
+    float m0 = MANET_WRONG_LABEL_PADDING_DISTANCE, m1 = MANET_WRONG_LABEL_PADDING_DISTANCE;
+
+    auto flush = [&](int obj) {
+        float a = fminf(m0, __shfl_xor(m0, 32));
+        float c = fminf(m1, __shfl_xor(m1, 32));
+        if (h == 0) {
+            atomicMin(keys + (size_t)obj * N_pad + qbase, key_of(a));
+            atomicMin(keys + (size_t)obj * N_pad + qbase + 32, key_of(c));
+        }
+    };
+
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        __syncthreads();  // tile t landed (vmcnt(0) before the barrier); buffer buf^1 is free
+        if (t + 1 < t1) stage(t + 1, buf ^ 1);
+        if (t >= seg_end) {  // wave-uniform: crossed into the next object's rows
+            flush(o);
+            m0 = m1 = MANET_WRONG_LABEL_PADDING_DISTANCE;
+            do { ++o; seg_end = meta[META_SEG + o + 1]; } while (t >= seg_end);
+        }
+        const char *tb = smem + (size_t)buf * TILE_BYTES;
+        const f32x4 *A = (const f32x4 *)tb;
+        f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            f32x4 a0 = A[(g * 2 + h) * BT + l31];
+            f32x4 a1 = A[(g * 2 + h) * BT + 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], q0[g][j], c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], q1[g][j], c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], q0[g][j], c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], q1[g][j], c11, 0, 0, 0);
+            }
+        }
+        // epilogue: register r of block rb holds bank row rb*32 + (r&3) + 8*(r>>2) + 4*h
+        const float *ysl = (const float *)(tb + (size_t)NG * 2 * BT * 16);
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            f32x4 y0 = *(const f32x4 *)(ysl + 8 * tq + 4 * h);
+            f32x4 y1 = *(const f32x4 *)(ysl + 32 + 8 * tq + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * tq + i;
+                m0 = fminf(m0, fmaf(-2.0f, c00[r], xs0 + y0[i]));  // IntVOS.py:39
+                m1 = fminf(m1, fmaf(-2.0f, c01[r], xs1 + y0[i]));
+                m0 = fminf(m0, fmaf(-2.0f, c10[r], xs0 + y1[i]));
+                m1 = fminf(m1, fmaf(-2.0f, c11[r], xs1 + y1[i]));
+            }
+        }
+    }
+    flush(o);
+}
+
+// decode + (sigmoid-0.5)*2 (IntVOS.py:611-612) + min-merge with the stored map (IntVOS.py:620-622)
+__global__ void global_finish_kernel(const unsigned *__restrict__ keys, long N, long N_pad, int n_ids,
+                                     int flags, float *__restrict__ out, float *__restrict__ mem)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * n_ids) return;
+    long n = i / n_ids;
+    int o = (int)(i - n * n_ids);
+    unsigned k = keys[(size_t)o * N_pad + n];
+    // an object with no bank row keeps the initial key: padding distance (IntVOS.py:81-83)
+    float g = (k == 0xffffffffu) ? MANET_WRONG_LABEL_PADDING_DISTANCE : float_of(k);
+    if (flags & MANET_EPI_NORMALIZE) g = manet_normalize_dist(g);
+    if (mem) {
+        float mv = mem[i];
+        g = (g <= mv) ? g : mv;
+        mem[i] = g;
+    }
+    out[i] = g;
+}
+
+__global__ void normalize_merge_kernel(float *__restrict__ x, float *__restrict__ mem, long n,
+                                       int normalize)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float g = x[i];
+    if (normalize) g = manet_normalize_dist(g);
+    if (mem) {
+        float mv = mem[i];
+        g = (g <= mv) ? g : mv;
+        mem[i] = g;
+    }
+    x[i] = g;
+}
+
+int check_common(int64_t N, int64_t M0, int C, int n_ids, int k_nn, int compute)
+{
+    if (N <= 0 || M0 < 0) return manet_set_error(MANET_E_INVALID, "N=%lld M0=%lld", (long long)N, (long long)M0);
+    if (M0 >= (1LL << 31) - 64 * (MANET_MAX_IDS + 1) || N >= (1LL << 31) - QT)
+        return manet_set_error(MANET_E_INVALID, "N or M0 too large for 32-bit row indices");
+    if (C <= 0 || C > MANET_MAX_C) return manet_set_error(MANET_E_INVALID, "C=%d (supported 1..%d)", C, MANET_MAX_C);
+    if (n_ids <= 0 || n_ids > MANET_MAX_IDS)
+        return manet_set_error(MANET_E_INVALID, "n_ids=%d (supported 1..%d)", n_ids, MANET_MAX_IDS);
+    if (k_nn != 1) return manet_set_error(MANET_E_INVALID, "k_nn=%d not supported yet (only 1)", k_nn);
+    if (compute != MANET_COMPUTE_F32)
+        return manet_set_error(MANET_E_INVALID, "compute=%d not supported yet (only MANET_COMPUTE_F32)", compute);
+    return MANET_OK;
+}
+
+template <int NG>
+void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S,
+                     long N_pad, unsigned *keys, hipStream_t st)
+{
+    size_t lds = 2 * bank_tile_bytes(NG);
+    // per call (cheap, host side): the attribute is per device and the library keeps no state
+    (void)hipFuncSetAttribute((const void *)global_match_f32_kernel<NG>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(global_match_f32_kernel<NG>, dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack,
+                       bpack, meta, n_ids, nQT, S, N_pad, keys);
+}
+
+}  // namespace
+
+extern "C" {
+
+int manet_bank_workspace_bytes(int64_t M0, int C, int n_ids, int compute, size_t *bytes)
+{
+    if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
+    int rc = check_common(1, M0, C, n_ids, 1, compute);
+    if (rc) return rc;
+    *bytes = bank_layout(M0, C, n_ids).total;
+    return MANET_OK;
+}
+
+int manet_match_workspace_bytes(int64_t N, int64_t M0, int C, int n_ids, int k_nn, int compute,
+                                size_t *bytes)
+{
+    if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
+    int rc = check_common(N, M0, C, n_ids, k_nn, compute);
+    if (rc) return rc;
+    *bytes = match_layout(N, C, n_ids).total;
+    return MANET_OK;
+}
+
+int manet_global_match_workspace_bytes(int64_t N, int64_t M0, int C, int n_ids, int k_nn, int compute,
+                                       size_t *bytes)
+{
+    if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
+    int rc = check_common(N, M0, C, n_ids, k_nn, compute);
+    if (rc) return rc;
+    *bytes = bank_layout(M0, C, n_ids).total + match_layout(N, C, n_ids).total;
+    return MANET_OK;
+}
+
+int manet_bank_prepare(const float *bank, int64_t b_stride_m, int64_t b_stride_c, const int32_t *labels,
+                       int64_t M0, int C, int n_ids, int compute, void *bank_ws, size_t bank_ws_bytes,
+                       manet_stream_t stream)
+{
+    int rc = check_common(1, M0, C, n_ids, 1, compute);
+    if (rc) return rc;
+    if ((M0 > 0 && (!bank || !labels)) || !bank_ws) return manet_set_error(MANET_E_INVALID, "null pointer");
+    BankLayout L = bank_layout(M0, C, n_ids);
+    if (bank_ws_bytes < L.total)
+        return manet_set_error(MANET_E_WORKSPACE, "bank workspace %zu < %zu bytes", bank_ws_bytes, L.total);
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)bank_ws;
+    int *meta = (int *)(ws + L.off_meta);
+    int *src_of = (int *)(ws + L.off_src);
+    (void)hipMemsetAsync(meta, 0, META_INTS * sizeof(int), st);
+    (void)hipMemsetAsync(src_of, 0xff, (size_t)L.T_max * BT * sizeof(int), st);
+    if (M0 > 0) {
+        unsigned blocks = (unsigned)((M0 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(label_count_kernel, dim3(blocks), dim3(256), 0, st, labels, (long)M0, n_ids, meta);
+    }
+    hipLaunchKernelGGL(label_scan_kernel, dim3(1), dim3(64), 0, st, n_ids, meta);
+    if (M0 > 0) {
+        unsigned blocks = (unsigned)((M0 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(label_scatter_kernel, dim3(blocks), dim3(256), 0, st, labels, (long)M0, n_ids, meta,
+                           src_of);
+    }
+    hipLaunchKernelGGL(pack_rows_kernel<BT>, dim3((unsigned)L.T_max), dim3(256), 0, st, bank, (long)b_stride_m,
+                       (long)b_stride_c, (const int *)src_of, (const int *)meta, (long)M0, C, L.NG,
+                       ws + L.off_pack, (long)L.tile_bytes, MANET_WRONG_LABEL_PADDING_DISTANCE);
+    return manet_check_launch("manet_bank_prepare");
+}
+
+int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t q_stride_c,
+                                const void *bank_ws, int64_t N, int64_t M0, int C, int n_ids, int k_nn,
+                                int compute, float *out, float *mem_inout, int epilogue_flags,
+                                void *match_ws, size_t match_ws_bytes, manet_stream_t stream)
+{
+    int rc = check_common(N, M0, C, n_ids, k_nn, compute);
+    if (rc) return rc;
+    if (!query || !bank_ws || !out || !match_ws) return manet_set_error(MANET_E_INVALID, "null pointer");
+    BankLayout BL = bank_layout(M0, C, n_ids);
+    MatchLayout ML = match_layout(N, C, n_ids);
+    if (match_ws_bytes < ML.total)
+        return manet_set_error(MANET_E_WORKSPACE, "match workspace %zu < %zu bytes", match_ws_bytes, ML.total);
+    hipStream_t st = (hipStream_t)stream;
+    const char *bws = (const char *)bank_ws;
+    char *mws = (char *)match_ws;
+    const int *meta = (const int *)(bws + BL.off_meta);
+    unsigned *keys = (unsigned *)(mws + ML.off_keys);
+    (void)hipMemsetAsync(keys, 0xff, (size_t)n_ids * ML.N_pad * sizeof(unsigned), st);
+    hipLaunchKernelGGL(pack_rows_kernel<QB>, dim3((unsigned)(ML.N_pad / QB)), dim3(256), 0, st, query,
+                       (long)q_stride_n, (long)q_stride_c, (const int *)nullptr, (const int *)nullptr, (long)N, C,
+                       ML.NG, mws + ML.off_q, (long)ML.qblk_bytes, 0.0f);
+    const int S = pick_splits(ML.nQT, BL.T_max);
+    const char *qpack = mws + ML.off_q;
+    const char *bpack = bws + BL.off_pack;
+    switch (ML.NG) {
+    case 4: launch_main_f32<4>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); break;
+    case 13: launch_main_f32<13>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); break;
+    default: launch_main_f32<16>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); break;
+    }
+    long total = (long)N * n_ids;
+    hipLaunchKernelGGL(global_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const unsigned *)keys, (long)N, ML.N_pad, n_ids, epilogue_flags, out, mem_inout);
+    return manet_check_launch("manet_global_match_prepared");
+}
+
+int manet_global_match(const float *query, int64_t q_stride_n, int64_t q_stride_c, const float *bank,
+                       int64_t b_stride_m, int64_t b_stride_c, const int32_t *labels, int64_t N, int64_t M0,
+                       int C, int n_ids, int k_nn, int compute, float *out, float *mem_inout,
+                       int epilogue_flags, void *workspace, size_t workspace_bytes, manet_stream_t stream)
+{
+    int rc = check_common(N, M0, C, n_ids, k_nn, compute);
+    if (rc) return rc;
+    if (!workspace) return manet_set_error(MANET_E_INVALID, "workspace == NULL");
+    size_t bbytes = bank_layout(M0, C, n_ids).total;
+    size_t mbytes = match_layout(N, C, n_ids).total;
+    if (workspace_bytes < bbytes + mbytes)
+        return manet_set_error(MANET_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, bbytes + mbytes);
+    char *ws = (char *)workspace;
+    rc = manet_bank_prepare(bank, b_stride_m, b_stride_c, labels, M0, C, n_ids, compute, ws, bbytes, stream);
+    if (rc) return rc;
+    return manet_global_match_prepared(query, q_stride_n, q_stride_c, ws, N, M0, C, n_ids, k_nn, compute, out,
+                                       mem_inout, epilogue_flags, ws + bbytes, mbytes, stream);
+}
+
+int manet_normalize_merge_f32(float *x, float *mem_inout, int64_t n, int normalize, manet_stream_t stream)
+{
+    if (n < 0 || (n > 0 && !x)) return manet_set_error(MANET_E_INVALID, "bad arguments");
+    if (n == 0) return MANET_OK;
+    hipLaunchKernelGGL(normalize_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, mem_inout, (long)n, normalize);
+    return manet_check_launch("manet_normalize_merge_f32");
+}
+
+}  // extern "C"

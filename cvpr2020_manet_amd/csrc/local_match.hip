@@ -1,0 +1,280 @@
+// Local (2d+1)^2 window matching against the previous frame, MI355X (gfx950).
+//
+// Replaces networks/IntVOS.py:266-315 (local_pairwise_distances2) and :345-434
+// (local_previous_frame_nearest_neighbor_features_per_object; USE_CORRELATION_COST=False,
+// MODEL_UNFOLD=True -- the live configuration, IntVOS.py:15-16).
+//
+// This stage is HBM/latency bound (arithmetic intensity ~16 flop/B): the point is
+// to read each embedding once, coalesced along x out of the caller's C-major planes, and never
+// to build the reference's [1,C,h',w',(2d+1)^2] unfold tensor (1.6 GB at d=12).
+//   pool2x2_kernel      both frames -> [C][h'][w'] planes (2x2 mean; floor sizes)
+//   local_dist_kernel   thread = (pixel, window row): (2d+1) running sums over C of (x - y)^2,
+//                       direct form as the reference (no |x|^2+|y|^2-2xy cancellation);
+//                       out-of-image neighbours are the reference's 1e20 padding -> inf -> 1.0
+//   local_min_kernel    thread = full-resolution pixel: bilinear (align_corners) sample of the
+//                       pooled, normalised volume + stride-2 label gather + masked min per object
+//   local_upsample_kernel  only for the stand-alone local_pairwise_distances2 API
+#include "manet_common.h"
+
+namespace {
+
+constexpr int MAXP = 2 * MANET_MAX_LOCAL_DISTANCE + 1;
+
+// IntVOS.py:282-284  F.avg_pool2d(x, (2,2), (2,2)): window summed row-major, times 1/4 (exact)
+__global__ void pool2x2_kernel(const float *__restrict__ a, long a_sy, long a_sx, long a_sc,
+                               const float *__restrict__ b, long b_sy, long b_sx, long b_sc, int C, int hp,
+                               int wp, float *__restrict__ ap, float *__restrict__ bp)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long plane = (long)hp * wp;
+    if (i >= plane * C) return;
+    int c = (int)(i / plane);
+    int rem = (int)(i - (long)c * plane);
+    int py = rem / wp, px = rem - py * wp;
+    const float *p = a + (2L * py) * a_sy + (2L * px) * a_sx + (long)c * a_sc;
+    const float *q = b + (2L * py) * b_sy + (2L * px) * b_sx + (long)c * b_sc;
+    ap[i] = (((p[0] + p[a_sx]) + p[a_sy]) + p[a_sy + a_sx]) * 0.25f;
+    bp[i] = (((q[0] + q[b_sx]) + q[b_sy]) + q[b_sy + b_sx]) * 0.25f;
+}
+
+// IntVOS.py:288-294 (pooled grid, normalised) and :300-313 (full grid, raw).
+// x = current/query frame, y = previous frame, both [H][W][C] with element strides.
+// pooled_out != 0: out[l][H][W] = (sigmoid(dist)-0.5)*2 ; else out[H][W][P*P] = dist.
+__global__ __launch_bounds__(256) void local_dist_kernel(const float *__restrict__ x, long x_sy, long x_sx,
+                                                         long x_sc, const float *__restrict__ y, long y_sy,
+                                                         long y_sx, long y_sc, int H, int W, int C, int d,
+                                                         int pooled_out, float *__restrict__ out)
+{
+    const int P = 2 * d + 1;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)H * W * P) return;
+    int px = (int)(i % W);
+    int py = (int)((i / W) % H);
+    int dy = (int)(i / ((long)W * H));
+    int yy = py + dy - d;
+    const bool row_in = (yy >= 0 && yy < H);
+    float acc[MAXP];
+#pragma unroll
+    for (int dx = 0; dx < MAXP; ++dx) acc[dx] = 0.0f;
+    const float *xp = x + (long)py * x_sy + (long)px * x_sx;
+    const float *yr = y + (long)(row_in ? yy : 0) * y_sy;
+    for (int c = 0; c < C; ++c) {
+        float a = xp[(long)c * x_sc];
+        const float *yc = yr + (long)c * y_sc;
+#pragma unroll
+        for (int dx = 0; dx < MAXP; ++dx) {
+            if (dx < P) {
+                int xx = px + dx - d;
+                float bv = (row_in && xx >= 0 && xx < W) ? yc[(long)xx * y_sx] : 1e20f;  // IntVOS.py:287
+                float df = a - bv;
+                acc[dx] = acc[dx] + df * df;
+            }
+        }
+    }
+#pragma unroll
+    for (int dx = 0; dx < MAXP; ++dx) {
+        if (dx < P) {
+            int l = dy * P + dx;
+            if (pooled_out)
+                out[((long)l * H + py) * W + px] = manet_normalize_dist(acc[dx]);
+            else
+                out[((long)py * W + px) * (P * P) + l] = acc[dx];
+        }
+    }
+}
+
+// F.interpolate(..., mode='bilinear', align_corners=True) coefficients (IntVOS.py:295):
+// scale = (in-1)/(out-1), src = scale*dst, i0 = floor, i1 = i0 + (i0 < in-1), l1 = src - i0.
+struct Bilin {
+    int i0, i1;
+    float l0, l1;
+};
+__device__ __forceinline__ Bilin bilin_coeff(int dst, int in_size, int out_size)
+{
+    float scale = (out_size > 1) ? (float)(in_size - 1) / (float)(out_size - 1) : 0.0f;
+    float src = scale * (float)dst;
+    int a = (int)src;
+    if (a > in_size - 1) a = in_size - 1;
+    Bilin b;
+    b.i0 = a;
+    b.i1 = a + ((a < in_size - 1) ? 1 : 0);
+    b.l1 = src - (float)a;
+    b.l0 = 1.0f - b.l1;
+    return b;
+}
+__device__ __forceinline__ float bilin_sample(const float *__restrict__ pl, int wp, const Bilin &by,
+                                              const Bilin &bx)
+{
+    return by.l0 * (bx.l0 * pl[by.i0 * wp + bx.i0] + bx.l1 * pl[by.i0 * wp + bx.i1]) +
+           by.l1 * (bx.l0 * pl[by.i1 * wp + bx.i0] + bx.l1 * pl[by.i1 * wp + bx.i1]);
+}
+
+// IntVOS.py:398-408 (label unfold, stride 2, zero padding) + :428-432 (where / min).
+// pooled != 0: dvol = [P*P][hp][wp] normalised pooled volume, sampled bilinearly at (y, x);
+// pooled == 0: dvol = [h][w][P*P] full-resolution raw distances.
+constexpr int NI = 8;  // object ids per pass
+__global__ __launch_bounds__(256) void local_min_kernel(const float *__restrict__ dvol, int pooled,
+                                                        const int *__restrict__ labels, int h, int w, int hp,
+                                                        int wp, int d, int n_ids, float *__restrict__ out)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)h * w) return;
+    const int y = (int)(i / w), x = (int)(i - (long)y * w);
+    const int P = 2 * d + 1;
+    Bilin cy = {0, 0, 0.f, 0.f}, cx = {0, 0, 0.f, 0.f};
+    if (pooled) {
+        cy = bilin_coeff(y, hp, h);
+        cx = bilin_coeff(x, wp, w);
+    }
+    const long plane = (long)hp * wp;
+    for (int o0 = 0; o0 < n_ids; o0 += NI) {
+        float m[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) m[k] = INFINITY;
+        for (int by = 0; by < P; ++by) {
+            const int yy = y + 2 * (by - d);
+            const bool yin = (yy >= 0 && yy < h);
+            for (int bx = 0; bx < P; ++bx) {
+                const int xx = x + 2 * (bx - d);
+                const int lab = (yin && xx >= 0 && xx < w) ? labels[(long)yy * w + xx] : 0;
+                const int l = by * P + bx;
+                const float v = pooled ? bilin_sample(dvol + (long)l * plane, wp, cy, cx) : dvol[i * (P * P) + l];
+#pragma unroll
+                for (int k = 0; k < NI; ++k) m[k] = fminf(m[k], (lab == o0 + k) ? v : 1.0f);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k)
+            if (o0 + k < n_ids) out[i * n_ids + o0 + k] = m[k];
+    }
+}
+
+// IntVOS.py:295-296: the resized volume itself, [h][w][P*P]
+__global__ void local_upsample_kernel(const float *__restrict__ dvol, int h, int w, int hp, int wp, int PP,
+                                      float *__restrict__ out)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)h * w * PP) return;
+    int l = (int)(i % PP);
+    long pix = i / PP;
+    int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+    Bilin cy = bilin_coeff(y, hp, h), cx = bilin_coeff(x, wp, w);
+    out[i] = bilin_sample(dvol + (long)l * hp * wp, wp, cy, cx);
+}
+
+struct LocalLayout {
+    int hp, wp, PP;
+    size_t off_ap, off_bp, off_vol, total;
+};
+
+LocalLayout local_layout(int h, int w, int C, int d, int downsample)
+{
+    LocalLayout L;
+    L.PP = (2 * d + 1) * (2 * d + 1);
+    L.hp = downsample ? h / 2 : h;
+    L.wp = downsample ? w / 2 : w;
+    size_t plane = (size_t)L.hp * L.wp;
+    L.off_ap = 0;
+    L.off_bp = manet_align_up(downsample ? plane * C * sizeof(float) : 0, 256);
+    L.off_vol = L.off_bp + manet_align_up(downsample ? plane * C * sizeof(float) : 0, 256);
+    L.total = manet_align_up(L.off_vol + plane * L.PP * sizeof(float), 256);
+    return L;
+}
+
+int check_local(int h, int w, int C, int d, int downsample)
+{
+    if (h <= 0 || w <= 0 || C <= 0) return manet_set_error(MANET_E_INVALID, "h=%d w=%d C=%d", h, w, C);
+    if (d < 0 || d > MANET_MAX_LOCAL_DISTANCE)
+        return manet_set_error(MANET_E_INVALID, "max_distance=%d (supported 0..%d)", d, MANET_MAX_LOCAL_DISTANCE);
+    if (downsample && (h < 2 || w < 2)) return manet_set_error(MANET_E_INVALID, "downsample needs h,w >= 2");
+    return MANET_OK;
+}
+
+// enqueue pooling (if any) + the distance volume into the workspace; returns the volume pointer
+float *enqueue_volume(const float *cur, int64_t c_sy, int64_t c_sx, int64_t c_sc, const float *prev,
+                      int64_t p_sy, int64_t p_sx, int64_t p_sc, int h, int w, int C, int d, int downsample,
+                      char *ws, const LocalLayout &L, hipStream_t st)
+{
+    float *vol = (float *)(ws + L.off_vol);
+    const int P = 2 * d + 1;
+    if (downsample) {
+        float *ap = (float *)(ws + L.off_ap), *bp = (float *)(ws + L.off_bp);
+        long n = (long)C * L.hp * L.wp;
+        hipLaunchKernelGGL(pool2x2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cur, (long)c_sy,
+                           (long)c_sx, (long)c_sc, prev, (long)p_sy, (long)p_sx, (long)p_sc, C, L.hp, L.wp, ap, bp);
+        long t = (long)L.hp * L.wp * P;
+        long plane = (long)L.hp * L.wp;
+        hipLaunchKernelGGL(local_dist_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, st,
+                           (const float *)ap, (long)L.wp, 1L, plane, (const float *)bp, (long)L.wp, 1L, plane, L.hp,
+                           L.wp, C, d, 1, vol);
+    } else {
+        long t = (long)h * w * P;
+        hipLaunchKernelGGL(local_dist_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, st, cur, (long)c_sy,
+                           (long)c_sx, (long)c_sc, prev, (long)p_sy, (long)p_sx, (long)p_sc, h, w, C, d, 0, vol);
+    }
+    return vol;
+}
+
+}  // namespace
+
+extern "C" {
+
+int manet_local_workspace_bytes(int h, int w, int C, int max_distance, int downsample, size_t *bytes)
+{
+    if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
+    int rc = check_local(h, w, C, max_distance, downsample);
+    if (rc) return rc;
+    *bytes = local_layout(h, w, C, max_distance, downsample).total;
+    return MANET_OK;
+}
+
+int manet_local_dist_f32(const float *cur, int64_t c_sy, int64_t c_sx, int64_t c_sc, const float *prev,
+                         int64_t p_sy, int64_t p_sx, int64_t p_sc, int h, int w, int C, int max_distance,
+                         int downsample, float *out, void *workspace, size_t workspace_bytes,
+                         manet_stream_t stream)
+{
+    int rc = check_local(h, w, C, max_distance, downsample);
+    if (rc) return rc;
+    if (!cur || !prev || !out) return manet_set_error(MANET_E_INVALID, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int d = max_distance;
+    if (!downsample) {  // the volume is the result: write it straight into out
+        long t = (long)h * w * (2 * d + 1);
+        hipLaunchKernelGGL(local_dist_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, st, cur, (long)c_sy,
+                           (long)c_sx, (long)c_sc, prev, (long)p_sy, (long)p_sx, (long)p_sc, h, w, C, d, 0, out);
+        return manet_check_launch("manet_local_dist_f32");
+    }
+    LocalLayout L = local_layout(h, w, C, d, downsample);
+    if (!workspace || workspace_bytes < L.total)
+        return manet_set_error(MANET_E_WORKSPACE, "local workspace %zu < %zu bytes", workspace_bytes, L.total);
+    float *vol = enqueue_volume(cur, c_sy, c_sx, c_sc, prev, p_sy, p_sx, p_sc, h, w, C, d, 1, (char *)workspace, L, st);
+    long n = (long)h * w * L.PP;
+    hipLaunchKernelGGL(local_upsample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       (const float *)vol, h, w, L.hp, L.wp, L.PP, out);
+    return manet_check_launch("manet_local_dist_f32");
+}
+
+int manet_local_match_f32(const float *prev, int64_t p_sy, int64_t p_sx, int64_t p_sc, const float *cur,
+                          int64_t c_sy, int64_t c_sx, int64_t c_sc, const int32_t *prev_labels, int h, int w,
+                          int C, int n_ids, int max_distance, int downsample, float *out, void *workspace,
+                          size_t workspace_bytes, manet_stream_t stream)
+{
+    int rc = check_local(h, w, C, max_distance, downsample);
+    if (rc) return rc;
+    if (n_ids <= 0 || n_ids > MANET_MAX_IDS)
+        return manet_set_error(MANET_E_INVALID, "n_ids=%d (supported 1..%d)", n_ids, MANET_MAX_IDS);
+    if (!cur || !prev || !prev_labels || !out) return manet_set_error(MANET_E_INVALID, "null pointer");
+    LocalLayout L = local_layout(h, w, C, max_distance, downsample);
+    if (!workspace || workspace_bytes < L.total)
+        return manet_set_error(MANET_E_WORKSPACE, "local workspace %zu < %zu bytes", workspace_bytes, L.total);
+    hipStream_t st = (hipStream_t)stream;
+    // IntVOS.py:370: local_pairwise_distances2(query_embedding, prev_frame_embedding)
+    float *vol = enqueue_volume(cur, c_sy, c_sx, c_sc, prev, p_sy, p_sx, p_sc, h, w, C, max_distance, downsample,
+                                (char *)workspace, L, st);
+    long n = (long)h * w;
+    hipLaunchKernelGGL(local_min_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float *)vol,
+                       downsample ? 1 : 0, prev_labels, h, w, L.hp, L.wp, max_distance, n_ids, out);
+    return manet_check_launch("manet_local_match_f32");
+}
+
+}  // extern "C"

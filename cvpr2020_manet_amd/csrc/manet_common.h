@@ -1,0 +1,37 @@
+// Shared helpers of libmanet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "manet_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+#define MANET_WRONG_LABEL_PADDING_DISTANCE 1e20f  // IntVOS.py:17
+#define MANET_MAX_IDS 64                          // object ids 0..63
+#define MANET_MAX_C 128                           // embedding width (reference: 100)
+#define MANET_MAX_LOCAL_DISTANCE 12               // reference default (config.py:50)
+
+// error text of the last failure on this thread (manet_last_error_string)
+int manet_set_error(int code, const char *fmt, ...);
+
+// status of the launches enqueued so far; never synchronises
+static inline int manet_check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return manet_set_error(MANET_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return MANET_OK;
+}
+
+static inline size_t manet_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// (sigmoid(x) - 0.5) * 2      IntVOS.py:612, :294
+__device__ __forceinline__ float manet_normalize_dist(float x)
+{
+    float s = 1.0f / (1.0f + expf(-x));
+    return (s - 0.5f) * 2.0f;
+}

@@ -1,0 +1,259 @@
+"""torch-tensor front-end of the C ABI (include/manet_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every function
+below hands raw device pointers, element strides and that stream to libmanet_hip.so.  All inputs
+must live on a HIP device -- there is deliberately no CPU path (a silent fallback would void the
+parity claims); CPU tensors raise.
+"""
+import torch
+
+from . import _lib
+
+COMPUTE = {"f32": _lib.COMPUTE_F32, "fp32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16,
+           "bf16x3": _lib.COMPUTE_BF16X3}
+
+_ws_cache = {}
+
+
+def _need_gpu(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("cvpr2020_manet_amd: %s must be a tensor on a HIP device "
+                           "(the matching path has no CPU fallback)" % name)
+
+
+def _stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _workspace(device, tag, nbytes):
+    """Per (device, stream, tag) scratch tensor, grown on demand (torch allocator = plumbing)."""
+    key = (device.index, _stream_ptr(device), tag)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _flat(t, name):
+    """[..., C] -> ([rows, C] view, rows, C); like the reference's .view(-1, C) (IntVOS.py:203-204)
+    but a non-viewable input is copied instead of raising."""
+    _need_gpu(t, name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    t2 = t.reshape(-1, t.shape[-1])
+    return t2, t2.shape[0], t2.shape[1]
+
+
+def _labels(t, name):
+    _need_gpu(t, name)
+    return t.reshape(-1).to(torch.int32).contiguous()
+
+
+def _size_t():
+    import ctypes
+    return ctypes.c_size_t(0)
+
+
+def global_match(reference_embeddings, query_embeddings, reference_labels, n_ids, k_nearest_neighbors=1,
+                 compute="f32", normalize=False, mem=None):
+    """nearest_neighbor_features_per_object on the HIP path (IntVOS.py:160-210), optionally with the
+    fused normalise (IntVOS.py:611-612) and min-merge into `mem` (IntVOS.py:620-622, in place).
+
+    Returns float32 [N, n_ids] (N = number of query pixels), raw or normalised distances.
+    """
+    import ctypes
+    lib = _lib.load()
+    ref, M0, C = _flat(reference_embeddings, "reference_embeddings")
+    qry, N, C2 = _flat(query_embeddings, "query_embeddings")
+    if C != C2:
+        raise ValueError("embedding_dim mismatch: %d vs %d" % (C, C2))
+    lab = _labels(reference_labels, "reference_labels")
+    if lab.numel() != M0:
+        raise ValueError("reference_labels has %d entries for %d reference pixels" % (lab.numel(), M0))
+    dev = qry.device
+    cmp_ = COMPUTE[compute]
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.manet_global_match_workspace_bytes(N, M0, C, n_ids, k_nearest_neighbors, cmp_,
+                                                      ctypes.byref(nbytes)), "manet_global_match_workspace_bytes")
+    ws = _workspace(dev, "global", nbytes.value)
+    out = torch.empty((N, n_ids), dtype=torch.float32, device=dev)
+    mem_ptr = None
+    if mem is not None:
+        _need_gpu(mem, "mem")
+        if mem.dtype != torch.float32 or not mem.is_contiguous() or mem.numel() != N * n_ids:
+            raise ValueError("mem must be a contiguous float32 tensor of N*n_ids elements")
+        mem_ptr = mem.data_ptr()
+    flags = _lib.EPI_NORMALIZE if normalize else 0
+    with torch.cuda.device(dev):
+        rc = lib.manet_global_match(qry.data_ptr(), qry.stride(0), qry.stride(1), ref.data_ptr(),
+                                    ref.stride(0) if M0 > 0 else C, ref.stride(1) if M0 > 0 else 1,
+                                    lab.data_ptr(), N, M0, C, n_ids, k_nearest_neighbors, cmp_,
+                                    out.data_ptr(), mem_ptr, flags, ws.data_ptr(), ws.numel(),
+                                    _stream_ptr(dev))
+    _lib.check(rc, "manet_global_match")
+    return out
+
+
+class PreparedBank:
+    """A memory bank sorted by object id and packed for the MFMA loop, reusable across frames
+    (test.py:237-259 matches every frame of a clip against the same annotated frame)."""
+
+    def __init__(self, reference_embeddings, reference_labels, n_ids, compute="f32"):
+        import ctypes
+        lib = _lib.load()
+        ref, M0, C = _flat(reference_embeddings, "reference_embeddings")
+        lab = _labels(reference_labels, "reference_labels")
+        if lab.numel() != M0:
+            raise ValueError("reference_labels has %d entries for %d reference pixels" % (lab.numel(), M0))
+        self.M0, self.C, self.n_ids, self.compute = M0, C, n_ids, COMPUTE[compute]
+        self.device = ref.device
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(lib.manet_bank_workspace_bytes(M0, C, n_ids, self.compute, ctypes.byref(nbytes)),
+                   "manet_bank_workspace_bytes")
+        self.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = lib.manet_bank_prepare(ref.data_ptr(), ref.stride(0) if M0 > 0 else C,
+                                        ref.stride(1) if M0 > 0 else 1, lab.data_ptr(), M0, C, n_ids,
+                                        self.compute, self.ws.data_ptr(), self.ws.numel(),
+                                        _stream_ptr(self.device))
+        _lib.check(rc, "manet_bank_prepare")
+
+    def match(self, query_embeddings, k_nearest_neighbors=1, normalize=False, mem=None, out=None):
+        import ctypes
+        lib = _lib.load()
+        qry, N, C = _flat(query_embeddings, "query_embeddings")
+        if C != self.C:
+            raise ValueError("embedding_dim mismatch: %d vs %d" % (C, self.C))
+        dev = qry.device
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(lib.manet_match_workspace_bytes(N, self.M0, C, self.n_ids, k_nearest_neighbors,
+                                                   self.compute, ctypes.byref(nbytes)),
+                   "manet_match_workspace_bytes")
+        ws = _workspace(dev, "match", nbytes.value)
+        if out is None:
+            out = torch.empty((N, self.n_ids), dtype=torch.float32, device=dev)
+        mem_ptr = None
+        if mem is not None:
+            _need_gpu(mem, "mem")
+            if mem.dtype != torch.float32 or not mem.is_contiguous() or mem.numel() != N * self.n_ids:
+                raise ValueError("mem must be a contiguous float32 tensor of N*n_ids elements")
+            mem_ptr = mem.data_ptr()
+        flags = _lib.EPI_NORMALIZE if normalize else 0
+        with torch.cuda.device(dev):
+            rc = lib.manet_global_match_prepared(qry.data_ptr(), qry.stride(0), qry.stride(1),
+                                                 self.ws.data_ptr(), N, self.M0, C, self.n_ids,
+                                                 k_nearest_neighbors, self.compute, out.data_ptr(), mem_ptr,
+                                                 flags, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "manet_global_match_prepared")
+        return out
+
+
+def normalize_merge_(x, mem=None, normalize=True):
+    """In place: x = (sigmoid(x)-0.5)*2 if normalize; if mem: x = mem = min(x, mem)
+    (IntVOS.py:611-612, :620-622, :718-723)."""
+    lib = _lib.load()
+    _need_gpu(x, "x")
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("x must be contiguous float32")
+    mem_ptr = None
+    if mem is not None:
+        _need_gpu(mem, "mem")
+        if mem.dtype != torch.float32 or not mem.is_contiguous() or mem.numel() != x.numel():
+            raise ValueError("mem must be contiguous float32 with x's element count")
+        mem_ptr = mem.data_ptr()
+    with torch.cuda.device(x.device):
+        rc = lib.manet_normalize_merge_f32(x.data_ptr(), mem_ptr, x.numel(), int(bool(normalize)),
+                                           _stream_ptr(x.device))
+    _lib.check(rc, "manet_normalize_merge_f32")
+    return x
+
+
+def _hwc(t, name):
+    _need_gpu(t, name)
+    if t.dim() != 3:
+        raise ValueError("%s must be [height, width, embedding_dim]" % name)
+    return t if t.dtype == torch.float32 else t.float()
+
+
+def local_dist(x, y, max_distance, downsample=True):
+    """local_pairwise_distances2(x=query, y=prev) (IntVOS.py:266-315) -> [h, w, (2d+1)^2]."""
+    import ctypes
+    lib = _lib.load()
+    x = _hwc(x, "x")
+    y = _hwc(y, "y")
+    h, w, C = x.shape
+    if tuple(y.shape) != (h, w, C):
+        raise ValueError("x and y must have the same shape")
+    dev = x.device
+    P = 2 * max_distance + 1
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.manet_local_workspace_bytes(h, w, C, max_distance, int(bool(downsample)),
+                                               ctypes.byref(nbytes)), "manet_local_workspace_bytes")
+    ws = _workspace(dev, "local", nbytes.value)
+    out = torch.empty((h, w, P * P), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.manet_local_dist_f32(x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), y.data_ptr(),
+                                      y.stride(0), y.stride(1), y.stride(2), h, w, C, max_distance,
+                                      int(bool(downsample)), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      _stream_ptr(dev))
+    _lib.check(rc, "manet_local_dist_f32")
+    return out
+
+
+def local_match(prev_frame_embedding, query_embedding, prev_frame_labels, n_ids, max_distance=12,
+                downsample=True):
+    """local_previous_frame_nearest_neighbor_features_per_object (IntVOS.py:345-434) -> [h, w, n_ids]."""
+    import ctypes
+    lib = _lib.load()
+    prev = _hwc(prev_frame_embedding, "prev_frame_embedding")
+    cur = _hwc(query_embedding, "query_embedding")
+    h, w, C = cur.shape
+    if tuple(prev.shape) != (h, w, C):
+        raise ValueError("prev_frame_embedding and query_embedding must have the same shape")
+    lab = _labels(prev_frame_labels, "prev_frame_labels")
+    if lab.numel() != h * w:
+        raise ValueError("prev_frame_labels must have height*width entries")
+    dev = cur.device
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.manet_local_workspace_bytes(h, w, C, max_distance, int(bool(downsample)),
+                                               ctypes.byref(nbytes)), "manet_local_workspace_bytes")
+    ws = _workspace(dev, "local", nbytes.value)
+    out = torch.empty((h, w, n_ids), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.manet_local_match_f32(prev.data_ptr(), prev.stride(0), prev.stride(1), prev.stride(2),
+                                       cur.data_ptr(), cur.stride(0), cur.stride(1), cur.stride(2),
+                                       lab.data_ptr(), h, w, C, n_ids, max_distance, int(bool(downsample)),
+                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "manet_local_match_f32")
+    return out
+
+
+def correlation_out_dims(H, W, pad_size, kernel_size, max_displacement, stride1, stride2):
+    import ctypes
+    lib = _lib.load()
+    oc, oh, ow = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.manet_correlation_out_dims(H, W, pad_size, kernel_size, max_displacement, stride1, stride2,
+                                              ctypes.byref(oc), ctypes.byref(oh), ctypes.byref(ow)),
+               "manet_correlation_out_dims")
+    return oc.value, oh.value, ow.value
+
+
+def correlation_forward(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2):
+    """correlation_cuda.forward (correlation_cuda.cc:10-87) -> [B, (2r+1)^2, outH, outW] fp32."""
+    lib = _lib.load()
+    _need_gpu(input1, "input1")
+    _need_gpu(input2, "input2")
+    a = input1.float().contiguous()
+    b = input2.float().contiguous()
+    if a.dim() != 4 or a.shape != b.shape:
+        raise ValueError("input1 and input2 must be [B, C, H, W] of the same shape")
+    B, C, H, W = a.shape
+    oc, oh, ow = correlation_out_dims(H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    out = torch.empty((B, oc, oh, ow), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        rc = lib.manet_correlation_forward_f32(a.data_ptr(), b.data_ptr(), B, C, H, W, pad_size, kernel_size,
+                                               max_displacement, stride1, stride2, out.data_ptr(),
+                                               _stream_ptr(a.device))
+    _lib.check(rc, "manet_correlation_forward_f32")
+    return out

@@ -1,0 +1,156 @@
+/*
+ * manet_hip.h -- C ABI of libmanet_hip.so: the MI355X (gfx950) implementation of MANet's
+ * per-frame matching path.  This is the drop-in boundary: every entry point takes raw device
+ * pointers, explicit sizes / element strides and a HIP stream, returns an int status, never
+ * throws, never allocates, never synchronises the device.  Work is enqueued on `stream`
+ * (pass the caller's current stream; the reference's native op does the same:
+ * correlation_cuda.cc:76).  Scratch memory is caller-provided; its size comes from the matching
+ * *_workspace_bytes query (the reference's native op resizes caller-provided scratch tensors:
+ * correlation_cuda.cc:36-42).
+ *
+ * Reference interfaces replaced (paths relative to the reference repo root):
+ *   manet_global_match_*      networks/IntVOS.py:160-210  nearest_neighbor_features_per_object
+ *                             (+ :113-157 chunk loop, :100-109 pixel selection, :62-97 masked
+ *                             min / top-k, :23-40 pairwise distances) and, fused as an epilogue,
+ *                             :611-612 normalisation and :615-622 / :716-723 min-aggregation.
+ *   manet_normalize_merge_f32 networks/IntVOS.py:611-622, :718-723 (stand-alone form).
+ *   manet_local_dist_f32      networks/IntVOS.py:266-315  local_pairwise_distances2
+ *   manet_local_match_f32     networks/IntVOS.py:345-434
+ *                             local_previous_frame_nearest_neighbor_features_per_object
+ *   manet_correlation_forward_f32
+ *                             correlation_package/correlation_cuda.cc:10-87 (pybind `forward`)
+ *                             + correlation_cuda_kernel.cu:46-147.
+ *
+ * Status codes: 0 = ok; negative = error (see MANET_E_*); manet_last_error_string() gives the
+ * text of the last error raised on the calling thread.
+ * Thread-safety: all functions are re-entrant and keep no state between calls.
+ */
+#ifndef MANET_HIP_H
+#define MANET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *manet_stream_t; /* a hipStream_t */
+
+#define MANET_OK 0
+#define MANET_E_INVALID (-1)   /* bad argument (shape, null pointer, unsupported value) */
+#define MANET_E_WORKSPACE (-2) /* workspace too small */
+#define MANET_E_LAUNCH (-3)    /* hipGetLastError() after a launch was not hipSuccess */
+#define MANET_E_NODEVICE (-4)  /* no usable HIP device */
+
+/* arithmetic type of the QK^T contraction */
+#define MANET_COMPUTE_F32 0     /* v_mfma_f32_32x32x2_f32, exact fp32 (bit-equal to an fmaf chain) */
+#define MANET_COMPUTE_BF16 1    /* v_mfma_f32_32x32x16_bf16 on inputs rounded to bf16, fp32 accumulate */
+#define MANET_COMPUTE_BF16X3 2  /* split-bf16 (hi+lo, 3 MFMAs): fp32-class accuracy at bf16 rate */
+
+/* flags of the fused epilogue of manet_global_match */
+#define MANET_EPI_NORMALIZE 1 /* g = (sigmoid(g) - 0.5) * 2            IntVOS.py:611-612 */
+
+const char *manet_version(void);
+const char *manet_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Global nearest-neighbour matching (IntVOS.py:160-210).
+ *
+ *   query  [N][C]  fp32, element strides (q_stride_n, q_stride_c)  -- the caller's view of its
+ *                  C-major [C,h,w] embedding is (1, h*w); a row-major [N,C] tensor is (C, 1).
+ *   bank   [M0][C] fp32, element strides (b_stride_m, b_stride_c)  -- the reference pixel set
+ *                  (a T-frame memory bank is T frames stacked along M0).
+ *   labels [M0]    int32; rows whose label is outside 0..n_ids-1 (e.g. -1 = unlabelled) never
+ *                  match any object (IntVOS.py:100-109 drops them, :137 masks them).
+ *   n_ids          number of object ids, ids = 0..n_ids-1 (IntVOS.py:200: arange(0, gt_ids+1)).
+ *   k_nn           1 = masked minimum (IntVOS.py:84-85); 2..MANET_MAX_KNN = mean of the k smallest
+ *                  with invalid entries replaced by the largest valid one (IntVOS.py:87-94).
+ *   out    [N][n_ids] fp32 contiguous (= the reference's [1,h,w,n_ids,1]).
+ *   mem_inout      NULL, or [N][n_ids] fp32: the stored global map of this frame; the result is
+ *                  min-merged with it and written back to both (IntVOS.py:620-622).
+ *   epilogue_flags MANET_EPI_* bits.
+ *   compute        MANET_COMPUTE_*.
+ *   workspace      device scratch of at least manet_global_match_workspace_bytes(...) bytes,
+ *                  256-byte aligned.  Contents are undefined on entry and on return.
+ */
+#define MANET_MAX_KNN 8
+
+int manet_global_match_workspace_bytes(int64_t N, int64_t M0, int C, int n_ids, int k_nn,
+                                       int compute, size_t *bytes);
+
+int manet_global_match(const float *query, int64_t q_stride_n, int64_t q_stride_c,
+                       const float *bank, int64_t b_stride_m, int64_t b_stride_c,
+                       const int32_t *labels, int64_t N, int64_t M0, int C, int n_ids, int k_nn,
+                       int compute, float *out, float *mem_inout, int epilogue_flags,
+                       void *workspace, size_t workspace_bytes, manet_stream_t stream);
+
+/* Two-step form of the same operation, for callers that match many query frames against one
+ * bank (test.py:237-259 propagates a whole clip against one annotated frame):
+ * prepare once (sort rows by object, pad, pre-compute |k|^2), then match per frame.
+ * `bank_ws` must stay untouched between the two calls; `match_ws` is per-call scratch. */
+int manet_bank_workspace_bytes(int64_t M0, int C, int n_ids, int compute, size_t *bytes);
+int manet_match_workspace_bytes(int64_t N, int64_t M0, int C, int n_ids, int k_nn, int compute,
+                                size_t *bytes);
+int manet_bank_prepare(const float *bank, int64_t b_stride_m, int64_t b_stride_c,
+                       const int32_t *labels, int64_t M0, int C, int n_ids, int compute,
+                       void *bank_ws, size_t bank_ws_bytes, manet_stream_t stream);
+int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t q_stride_c,
+                                const void *bank_ws, int64_t N, int64_t M0, int C, int n_ids,
+                                int k_nn, int compute, float *out, float *mem_inout,
+                                int epilogue_flags, void *match_ws, size_t match_ws_bytes,
+                                manet_stream_t stream);
+
+/* Stand-alone normalise / min-merge (IntVOS.py:611-622, :718-723), in place on x[n]
+ * (and on mem_inout[n] when not NULL). */
+int manet_normalize_merge_f32(float *x, float *mem_inout, int64_t n, int normalize,
+                              manet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Local (2d+1)^2 window matching against the previous frame.
+ *
+ * Embeddings are [h][w][C] fp32 with element strides (s_y, s_x, s_c); the reference's callers
+ * pass permute(1,2,0) views of C-major storage, i.e. (w, 1, h*w).
+ *
+ * manet_local_dist_f32 (IntVOS.py:266-315, local_pairwise_distances2(x=cur, y=prev)):
+ *   downsample != 0: 2x2 average pooling, window on the pooled grid, padding distance inf,
+ *                    (sigmoid-0.5)*2, bilinear (align_corners) resize back to (h, w);
+ *   downsample == 0: window on the full grid, raw distances (inf outside the image).
+ *   out [h][w][(2d+1)^2] fp32 contiguous.
+ *
+ * manet_local_match_f32 (IntVOS.py:345-434): the same distances, never materialised at full
+ *   resolution, masked by the previous frame's labels gathered at stride-2 offsets
+ *   (labels[y+2(by-d)][x+2(bx-d)], 0 outside the image) and reduced by min per object id;
+ *   unmatched -> 1.0.   labels [h][w] int32 contiguous; out [h][w][n_ids] fp32 contiguous.
+ */
+int manet_local_workspace_bytes(int h, int w, int C, int max_distance, int downsample,
+                                size_t *bytes);
+
+int manet_local_dist_f32(const float *cur, int64_t c_sy, int64_t c_sx, int64_t c_sc,
+                         const float *prev, int64_t p_sy, int64_t p_sx, int64_t p_sc, int h, int w,
+                         int C, int max_distance, int downsample, float *out, void *workspace,
+                         size_t workspace_bytes, manet_stream_t stream);
+
+int manet_local_match_f32(const float *prev, int64_t p_sy, int64_t p_sx, int64_t p_sc,
+                          const float *cur, int64_t c_sy, int64_t c_sx, int64_t c_sc,
+                          const int32_t *prev_labels, int h, int w, int C, int n_ids,
+                          int max_distance, int downsample, float *out, void *workspace,
+                          size_t workspace_bytes, manet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* correlation_package forward (correlation_cuda.cc:10-87).
+ *   in1, in2 [B][C][H][W] fp32 contiguous; out [B][(2r+1)^2][outH][outW] fp32 contiguous with
+ *   r = max_displacement / stride2 and the shape rule of correlation_cuda.cc:25-34, which
+ *   manet_correlation_out_dims reproduces.  out = sum / (kernel_size^2 * C), fp32 accumulate.
+ *   No scratch is needed (the reference's padded NHWC copies rInput1/2 are not materialised). */
+int manet_correlation_out_dims(int H, int W, int pad_size, int kernel_size, int max_displacement,
+                               int stride1, int stride2, int *out_c, int *out_h, int *out_w);
+
+int manet_correlation_forward_f32(const float *in1, const float *in2, int B, int C, int H, int W,
+                                  int pad_size, int kernel_size, int max_displacement, int stride1,
+                                  int stride2, float *out, manet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MANET_HIP_H */
