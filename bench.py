@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Headline benchmark: propagated frames/s of MANet's matching path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A "step" is one propagated frame: global nearest-neighbour match of the current frame against the
+T-frame memory bank with the fused normalise + min-aggregation (IntVOS.py:609-622) and the local
+(2d+1)^2 window match against the previous frame (IntVOS.py:629-631), embeddings already resident
+in HBM (they come out of the encoder on the GPU; test.py:149-154).  Workload = BASELINE.json
+configs[1]: 480p grid 120x214, C=100, 5-frame fully labelled bank (M = 128 400, the worst case
+after rough_ROI), 1 object (+ background = 2 ids), fp32.  The one-shot API is timed, i.e. the bank
+is re-sorted/re-packed every frame exactly as the reference recomputes everything every frame.
+
+Multi-GPU: frames of the clip are sharded, K per rank (weak scaling); the timed region contains the
+single RCCL all-gather that distributes the memory bank + halo frame, then K frames per rank.
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and
+`cpu_baseline` objects.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# BASELINE.json configs[1] (+ the reference's default local window, config.py:50)
+H, W, C = 120, 214, 100
+T_BANK = 5
+N_IDS = 2
+LOCAL_D = 12
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def synth_frame(gen, device):
+    """C-major embedding as extract_feature produces it (post-ReLU): relu(randn) * 0.1."""
+    return (torch.relu(torch.randn(C, H, W, generator=gen, device=device)) * 0.1).contiguous()
+
+
+def blob_labels(n_ids, shift, device):
+    """previous-frame labels: one rectangle per object, nearest-resized grid resolution"""
+    lab = torch.zeros(H, W, dtype=torch.int32, device=device)
+    for o in range(1, n_ids):
+        y0 = (15 * o + 3 * shift) % (H - 50)
+        x0 = (40 * o + 5 * shift) % (W - 80)
+        lab[y0:y0 + 45, x0:x0 + 70] = o
+    return lab
+
+
+def cpu_baseline(bank_rows, bank_lab, cur, prev, prev_lab):
+    """The CPU oracle (a C port of the reference path, kind="port") on the host cores, on a bounded
+    sample of the same frame: a subset of query pixels against the FULL bank for the global match
+    (cost is linear in query pixels), the whole frame for the local match.  ~10-30 s."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    qry = cur.permute(1, 2, 0).cpu().numpy()
+    ref = bank_rows.cpu().numpy()
+    lab = bank_lab.cpu().numpy().reshape(-1, 1, 1)
+    ref3 = ref.reshape(-1, 1, C)
+    N = H * W
+
+    def run(nq):
+        q = np.ascontiguousarray(qry.reshape(-1, C)[:nq]).reshape(nq, 1, C)
+        t0 = time.perf_counter()
+        orc.global_match(ref3, q, lab, 1, n_ids=N_IDS, test_mode=True)
+        return time.perf_counter() - t0
+
+    probe_n = 4 * cores
+    t_probe = run(probe_n)
+    per_q = t_probe / probe_n
+    nq = int(min(N, max(probe_n, 12.0 / per_q)))
+    nq -= nq % cores or 0
+    nq = max(nq, cores)
+    t_glob = run(nq)
+    t0 = time.perf_counter()
+    orc.local_match(prev.permute(1, 2, 0).cpu().numpy(), qry, prev_lab.cpu().numpy(), N_IDS, LOCAL_D)
+    t_loc = time.perf_counter() - t0
+    frame_s = t_glob / nq * N + t_loc
+    return {"value": 1.0 / frame_s, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "global match: %d of %d query pixels x full %d-row bank (%.1f s, scaled linearly); "
+                      "local match d=%d: whole frame (%.1f s); oracle/manet_oracle.c with OpenMP on %d threads"
+                      % (nq, N, ref.shape[0], t_glob, LOCAL_D, t_loc, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the matching path has no CPU fallback")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from cvpr2020_manet_amd import _lib, clip_parallel, ops
+    lib = _lib.load()
+
+    K, Wm = args.steps, args.warmup
+    gen = torch.Generator(device=device).manual_seed(20200614 + 2 + 1000 * rank)
+    # this rank's K frames of the clip (synthetic embeddings, resident in HBM) + 1 warm-up halo
+    n_local = K
+    frames = [synth_frame(gen, device) for _ in range(min(n_local, 8))]  # cycled: 8 x 10.3 MB
+    local_emb = torch.stack(frames)  # [f, C, H, W]
+    F_total = world * n_local
+    my_start, _ = clip_parallel.shard_frames(F_total, world, rank)
+    # the bank: T annotated frames spread over the clip; labels uniform over the ids (fully labelled)
+    bank_frames = sorted({int(round(i * (F_total - 1) / max(T_BANK - 1, 1))) for i in range(T_BANK)})
+    while len(bank_frames) < T_BANK:  # tiny clips: duplicate-free fill
+        for f in range(F_total):
+            if f not in bank_frames:
+                bank_frames.append(f)
+                break
+        else:
+            break
+    bank_frames = sorted(bank_frames)[:T_BANK]
+    lab_gen = torch.Generator(device=device).manual_seed(20200614 + 2)
+    bank_labels = {f: torch.randint(0, N_IDS, (H, W), generator=lab_gen, device=device, dtype=torch.int32)
+                   for f in bank_frames}
+
+    def frame_emb(i):  # embedding of local frame i (cycled over the resident ones)
+        return local_emb[i % local_emb.shape[0]]
+
+    def build_bank():
+        """every rank gets the full bank (+ halo): ONE all-gather over RCCL when world > 1"""
+        if world > 1:
+            # the rank's slab needs the embeddings of the bank frames it owns
+            owned = torch.stack([frame_emb(i) for i in range(n_local)]) if n_local <= 8 else None
+            if owned is None:
+                # K > 8: frames are cycled; materialise only what the exchange reads
+                class _View:
+                    shape = (n_local, C, H, W)
+                    device = local_emb.device
+
+                    def __getitem__(self, i):
+                        return frame_emb(i if i >= 0 else n_local + i)
+                owned = _View()
+            bank_emb, bank_lab, halo = clip_parallel.exchange_bank_and_halo(owned, my_start, bank_frames,
+                                                                            bank_labels, F_total)
+        else:
+            bank_emb = torch.stack([frame_emb(f) for f in bank_frames])
+            bank_lab = torch.stack([bank_labels[f] for f in bank_frames])
+            halo = None
+        # stacked T-frame bank as the API expects it: rows = pixels of all frames (IntVOS.py:203-204)
+        bank_rows = bank_emb.permute(0, 2, 3, 1).reshape(-1, C)
+        return bank_rows, bank_lab.reshape(-1), halo
+
+    gmap = torch.ones(104, H * W, N_IDS, device=device)  # IntVOS.py:617
+    prev_labs = [blob_labels(N_IDS, s, device) for s in range(8)]
+
+    def step(i, bank_rows, bank_lab, halo):
+        cur = frame_emb(i)
+        prev = frame_emb(i - 1) if i > 0 else (halo if halo is not None else frame_emb(0))
+        g = ops.global_match(bank_rows, cur.permute(1, 2, 0), bank_lab, N_IDS, normalize=True,
+                             mem=gmap[i % 104])
+        l = ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), prev_labs[i % 8], N_IDS, LOCAL_D)
+        return g, l
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up (untimed)
+    bank_rows, bank_lab, halo = build_bank()
+    for i in range(Wm):
+        step(i, bank_rows, bank_lab, halo)
+    barrier()
+
+    # timed: the bank exchange + exactly K frames
+    _lib.check(lib.manet_profile_begin(K), "manet_profile_begin")
+    barrier()
+    t0 = time.perf_counter()
+    bank_rows, bank_lab, halo = build_bank()
+    for i in range(K):
+        step(i, bank_rows, bank_lab, halo)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms = (ctypes.c_float * K)()
+    nrec = ctypes.c_int(0)
+    _lib.check(lib.manet_profile_end(ms, K, ctypes.byref(nrec)), "manet_profile_end")
+    kern_ms = float(np.mean([ms[i] for i in range(nrec.value)])) if nrec.value else float("nan")
+
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        N, M = H * W, T_BANK * H * W
+        flops = 2.0 * N * M * C  # algorithmic flops of one launch
+        achieved = flops / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_global_match_f32.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "propagated frames/sec at 480p, 5-frame memory",
+            "value": world * K / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 480p grid %dx%d, C=%d, %d-frame fully-labelled bank "
+                                   "(M=%d), %d ids, fp32; step = global match + fused normalise/min-merge + "
+                                   "local match d=%d; one-shot API (bank re-packed every frame)"
+                                   % (H, W, C, T_BANK, M, N_IDS, LOCAL_D),
+                       "frames_per_gpu": K, "bank_exchange": "1 RCCL all-gather in the timed region" if world > 1
+                       else "none (1 GPU)"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "global_match_f32_kernel<13>", "kernel_ms": kern_ms,
+                         "algorithmic_flops_per_launch": flops},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(bank_rows, bank_lab, frame_emb(0), frame_emb(1), prev_labs[0])
+        elif not args.no_cpu_baseline:
+            line["cpu_baseline"] = None  # measured on rank 0 at N=1 only (see the N=1 line)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

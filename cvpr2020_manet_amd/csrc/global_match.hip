@@ -410,8 +410,10 @@ void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int 
     // per call (cheap, host side): the attribute is per device and the library keeps no state
     (void)hipFuncSetAttribute((const void *)global_match_f32_kernel<NG>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    manet_profile_record(st, true);
     hipLaunchKernelGGL(global_match_f32_kernel<NG>, dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack,
                        bpack, meta, n_ids, nQT, S, N_pad, keys);
+    manet_profile_record(st, false);
 }
 
 }  // namespace

@@ -27,6 +27,10 @@ static inline int manet_check_launch(const char *what)
     return MANET_OK;
 }
 
+// opt-in launch timing of the dominant kernel (manet_profile_begin/_end, used by bench.py):
+// when enabled, the launcher of the global-match main kernel brackets it with two HIP events.
+void manet_profile_record(hipStream_t st, bool start);
+
 static inline size_t manet_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // (sigmoid(x) - 0.5) * 2      IntVOS.py:612, :294

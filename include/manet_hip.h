@@ -150,6 +150,14 @@ int manet_correlation_forward_f32(const float *in1, const float *in2, int B, int
                                   int pad_size, int kernel_size, int max_displacement, int stride1,
                                   int stride2, float *out, manet_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Opt-in measurement hook (not part of the data path, used by bench.py): between _begin and _end
+ * every launch of the dominant kernel (the global-match MFMA kernel) is bracketed by two HIP
+ * events on its own stream.  manet_profile_end synchronises on those events (the only call in
+ * this library that blocks) and returns the per-launch durations in milliseconds. */
+int manet_profile_begin(int max_launches);
+int manet_profile_end(float *ms_out, int capacity, int *n_launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,153 @@
+"""GPU parity of the local-window matching and correlation HIP paths (through the C ABI) against the
+committed reference vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+# expf on the device vs glibc/torch differ in the last ulp; distances to fp32 rounding.
+RTOL, ATOL = 1e-5, 2e-6
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from cvpr2020_manet_amd import ops as o
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def chw_view(chw):
+    return dev(chw).permute(1, 2, 0)
+
+
+LOCAL_CASES = ["C16_12x15_d2", "C16_12x15_d4", "C100_10x14_d3", "C8_9x11_d1"]
+
+
+@pytest.mark.parametrize("ds", [1, 0])
+@pytest.mark.parametrize("case", LOCAL_CASES)
+def test_golden_reference_vectors(ops, case, ds):
+    g = load_golden("local_ds%d_%s" % (ds, case))
+    d, n_ids = int(g["d"]), int(g["n_ids"])
+    dist = ops.local_dist(chw_view(g["cur_chw"]), chw_view(g["prev_chw"]), d, downsample=bool(ds)).cpu().numpy()
+    ref = g["dist"]
+    assert np.array_equal(np.isinf(dist), np.isinf(ref))
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(dist[fin], ref[fin], rtol=RTOL, atol=ATOL)
+    out = ops.local_match(chw_view(g["prev_chw"]), chw_view(g["cur_chw"]), dev(g["labels"]), n_ids, d,
+                          downsample=bool(ds)).cpu().numpy()
+    np.testing.assert_allclose(out.reshape(g["out"].shape), g["out"], rtol=RTOL, atol=ATOL)
+
+
+def _case(seed, h, w, C, n_ids, scale=0.1):
+    rng = np.random.default_rng(seed)
+    prev = (np.maximum(rng.standard_normal((C, h, w)), 0) * scale).astype(np.float32)
+    cur = (np.maximum(rng.standard_normal((C, h, w)), 0) * scale).astype(np.float32)
+    lab = rng.integers(-1, n_ids, size=(h, w, 1)).astype(np.int32)
+    return prev, cur, lab
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 31, 45, 100, 3, 4, 1),    # odd sizes -> pooled 15x22
+    (2, 30, 54, 100, 2, 12, 1),   # reference default window (625 offsets)
+    (3, 17, 19, 100, 10, 2, 1),   # more ids than one pass of the min kernel (8)
+    (4, 21, 18, 64, 3, 3, 0),     # no downsample
+    (5, 8, 8, 5, 2, 0, 1),        # d = 0 (single offset)
+    (6, 2, 3, 7, 2, 1, 1),        # pooled grid 1x1
+])
+def test_vs_oracle(ops, oracle, shape):
+    seed, h, w, C, n_ids, d, ds = shape
+    prev, cur, lab = _case(seed, h, w, C, n_ids)
+    out = ops.local_match(chw_view(prev), chw_view(cur), dev(lab), n_ids, d, downsample=bool(ds)).cpu().numpy()
+    want = oracle.local_match(np.transpose(prev, (1, 2, 0)), np.transpose(cur, (1, 2, 0)), lab, n_ids, d,
+                              downsample=bool(ds)).reshape(h, w, n_ids)
+    np.testing.assert_allclose(out, want, rtol=RTOL, atol=ATOL)
+    dist = ops.local_dist(chw_view(cur), chw_view(prev), d, downsample=bool(ds)).cpu().numpy()
+    wd = oracle.local_dist(np.transpose(cur, (1, 2, 0)), np.transpose(prev, (1, 2, 0)), d, downsample=bool(ds))
+    assert np.array_equal(np.isinf(dist), np.isinf(wd))
+    fin = np.isfinite(wd)
+    np.testing.assert_allclose(dist[fin], wd[fin], rtol=RTOL, atol=ATOL)
+
+
+def test_row_major_inputs_give_the_same_result(ops):
+    prev, cur, lab = _case(9, 24, 30, 100, 3)
+    a = ops.local_match(chw_view(prev), chw_view(cur), dev(lab), 3, 4)
+    b = ops.local_match(chw_view(prev).contiguous(), chw_view(cur).contiguous(), dev(lab), 3, 4)
+    assert torch.equal(a, b)
+
+
+def test_int_seghead_style_self_match(ops, oracle):
+    """int_seghead matches a frame against itself with scribble labels incl. -1 (IntVOS.py:709-711)."""
+    prev, _, lab = _case(10, 20, 26, 100, 3)
+    out = ops.local_match(chw_view(prev), chw_view(prev), dev(lab), 3, 4).cpu().numpy()
+    want = oracle.local_match(np.transpose(prev, (1, 2, 0)), np.transpose(prev, (1, 2, 0)), lab, 3, 4).reshape(20, 26, 3)
+    np.testing.assert_allclose(out, want, rtol=RTOL, atol=ATOL)
+    # a pixel whose own label is o has distance 0 to itself at the centre offset -> exactly 0
+    own = lab[..., 0]
+    for o in range(3):
+        assert np.all(out[own == o, o] == 0.0)
+
+
+def test_full_size_properties_cfg3(ops):
+    """BASELINE cfg3: 120x214 grid, C=100, d=4, 4 ids."""
+    torch.manual_seed(20200614 + 3)
+    C, h, w, d, n_ids = 100, 120, 214, 4, 4
+    prev = torch.relu(torch.randn(C, h, w, device="cuda")) * 0.1
+    cur = torch.relu(torch.randn(C, h, w, device="cuda")) * 0.1
+    lab = torch.zeros(h, w, dtype=torch.int32, device="cuda")
+    lab[20:60, 30:90] = 1; lab[70:100, 100:180] = 2; lab[5:15, 150:200] = 3
+    out = ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), lab, n_ids, d)
+    assert out.shape == (h, w, n_ids)
+    assert out.min().item() >= 0.0 and out.max().item() <= 1.0  # normalised distances
+    # far from object 3 (further than 2d pixels) nothing can match it -> exactly 1.0
+    far = torch.ones(h, w, dtype=torch.bool, device="cuda"); far[0:15 + 2 * d + 1, 150 - 2 * d:200 + 2 * d + 1] = False
+    assert torch.all(out[..., 3][far] == 1.0)
+    # self match: distance 0 for the pixel's own label
+    same = ops.local_match(cur.permute(1, 2, 0), cur.permute(1, 2, 0), lab, n_ids, d)
+    assert torch.all(same.gather(2, lab.long()[..., None]) == 0.0)
+    # the fused path equals masked-min over the materialised volume (IntVOS.py:428-432)
+    vol = ops.local_dist(cur.permute(1, 2, 0), prev.permute(1, 2, 0), d)  # [h,w,81]
+    P = 2 * d + 1
+    padl = torch.nn.functional.pad(lab.float()[None, None], (2 * d,) * 4)
+    offl = torch.nn.functional.unfold(padl, kernel_size=(h, w), stride=(2, 2)).view(h, w, P * P, 1)
+    mask = offl == torch.arange(n_ids, device="cuda").float()
+    want = torch.where(mask, vol[..., None].expand(-1, -1, -1, n_ids), torch.ones((), device="cuda")).min(dim=2).values
+    assert torch.equal(out, want)
+
+
+def test_correlation_vs_oracle(ops, oracle):
+    rng = np.random.default_rng(3)
+    for (B, C, H, W, pad, K, md, s1, s2) in [(2, 5, 9, 8, 3, 3, 2, 2, 2), (1, 100, 20, 27, 4, 1, 4, 1, 1),
+                                              (1, 7, 12, 12, 6, 1, 6, 1, 2)]:
+        a = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        b = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        out = ops.correlation_forward(dev(a), dev(b), pad, K, md, s1, s2).cpu().numpy()
+        want = oracle.correlation_forward(a, b, pad, K, md, s1, s2)
+        assert out.shape == want.shape
+        np.testing.assert_array_equal(out, want)  # same fmaf chain order
+
+
+def test_correlation_tied_to_reference_distance(ops):
+    g = load_golden("correlation_tie")
+    a, b, d = g["in1"], g["in2"], int(g["d"])
+    C, h, w = a.shape
+    corr = ops.correlation_forward(dev(a[None]), dev(b[None]), d, 1, d, 1, 1).cpu().numpy()
+    xs = (a.astype(np.float64) ** 2).sum(0)
+    ys = (b.astype(np.float64) ** 2).sum(0)
+    P = 2 * d + 1
+    for dy in range(P):
+        for dx in range(P):
+            for y in range(h):
+                for x in range(w):
+                    yy, xx = y + dy - d, x + dx - d
+                    r = g["dist"][y, x, dy * P + dx]
+                    if 0 <= yy < h and 0 <= xx < w:
+                        assert abs(xs[y, x] + ys[yy, xx] - 2 * C * corr[0, dy * P + dx, y, x] - r) < 1e-4 * max(1.0, r)
+                    else:
+                        assert corr[0, dy * P + dx, y, x] == 0.0
