@@ -89,9 +89,15 @@ def _flat2d(a):
     # check the leading dims collapse into one stride (torch .view(-1, C) semantics)
     lead_shape, lead_st = list(a.shape[:-1]), st[:-1]
     while len(lead_shape) > 1:
-        if lead_shape[-2] != 1 and lead_shape[-1] != 1 and lead_st[-2] != lead_st[-1] * lead_shape[-1]:
+        if lead_shape[-1] == 1:      # a size-1 dim carries no stride information
+            merged = lead_st[-2]
+        elif lead_shape[-2] == 1:
+            merged = lead_st[-1]
+        elif lead_st[-2] == lead_st[-1] * lead_shape[-1]:
+            merged = lead_st[-1]
+        else:
             raise ValueError("leading dims are not collapsible; pass a .view(-1, C)-able array")
-        lead_st[-2:] = [lead_st[-1]]
+        lead_st[-2:] = [merged]
         lead_shape[-2:] = [lead_shape[-2] * lead_shape[-1]]
     return rows, C, lead_st[0], st[-1]
 

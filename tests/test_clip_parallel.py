@@ -1,0 +1,85 @@
+"""Frame sharding + the single bank/halo all-gather, on CPU with the gloo backend, world_size 2 and 3
+(the N>1 path of bench.py; on the GPU box the same code runs over RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cvpr2020_manet_amd import clip_parallel as cp
+
+
+def test_shard_frames_partition():
+    for F in [1, 7, 8, 64, 65]:
+        for world in [1, 2, 3, 8]:
+            spans = [cp.shard_frames(F, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == F
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+            for f in range(F):
+                r = cp.owner_of(f, F, world)
+                assert spans[r][0] <= f < spans[r][1]
+
+
+def test_bank_slots():
+    slots, table = cp.bank_slots([0, 3, 9, 10, 15], 16, 4)  # ranks own 4 frames each
+    assert slots == 2
+    assert table == [(0, 0, 0), (0, 1, 3), (2, 0, 9), (2, 1, 10), (3, 0, 15)]
+    assert cp.slab_bytes(100, 120, 214, 5, 8) == 4 * (1 * (100 * 120 * 214 + 120 * 214) + 100 * 120 * 214)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _clip(F, C, h, w):
+    g = torch.Generator().manual_seed(7)
+    emb = torch.relu(torch.randn(F, C, h, w, generator=g))
+    lab = torch.randint(-1, 3, (F, h, w), generator=g, dtype=torch.int32)  # includes -1 (NaN bit pattern)
+    return emb, lab
+
+
+def _worker(rank, world, port, F, bank_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        C, h, w = 5, 6, 7
+        emb, lab = _clip(F, C, h, w)
+        s, e = cp.shard_frames(F, world, rank)
+        local = emb[s:e].clone()
+        labels = {f: lab[f] for f in bank_frames if s <= f < e}  # a rank only knows its own frames' labels
+        bank_emb, bank_lab, halo = cp.exchange_bank_and_halo(local, s, bank_frames, labels, F)
+        order = sorted(bank_frames)
+        ok = torch.equal(bank_emb, emb[order]) and torch.equal(bank_lab, lab[order])
+        if rank == 0 or s == 0:
+            ok = ok and (halo is None or rank > 0)
+        if rank > 0 and s > 0:
+            ok = ok and halo is not None and torch.equal(halo, emb[s - 1])
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,F,bank", [(2, 8, [0, 2, 5, 6, 7]), (3, 7, [1, 3]), (2, 3, [2])])
+def test_exchange_bank_and_halo_gloo(world, F, bank):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, F, bank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert res == [(r, True) for r in range(world)]

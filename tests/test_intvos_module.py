@@ -1,0 +1,220 @@
+"""The drop-in networks/IntVOS.py counterpart against the reference's own class (golden e2e_tiny.npz,
+made by running the reference's IntVOS.int_seghead / prop_seghead / forward with tiny heads).
+
+* CPU (host logic): the three ops entry points are replaced -- IN THIS TEST ONLY -- by oracle-backed
+  stand-ins so that the dict plumbing, return arity, label scaling, memory updates (a7, a12) and
+  head-input assembly can be checked without a GPU.  The product has no such path.
+* GPU: the same script through the real HIP ops.
+"""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import load_golden
+
+
+class TinyExtractor(nn.Module):  # same stand-in encoder as oracle/gen_golden.py
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(3, 6, 3, stride=4, padding=1)
+        self.cls_conv = nn.Identity()
+        self.upsample4 = nn.Identity()
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+def tiny_cfg():
+    from cvpr2020_manet_amd.config import make_cfg
+    return make_cfg(["--TEST_MODE", "True", "--MODEL_SEMANTIC_EMBEDDING_DIM", "12",
+                     "--MODEL_HEAD_EMBEDDING_DIM", "8", "--MODEL_ASPP_OUTDIM", "6",
+                     "--MODEL_MAX_LOCAL_DISTANCE", "2"])
+
+
+def build_model(g, device):
+    from cvpr2020_manet_amd.networks import IntVOS as M
+    model = M.IntVOS(tiny_cfg(), TinyExtractor())
+    sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd::")}
+    assert sorted(model.state_dict().keys()) == sorted(sd.keys()) == sorted(g["sd_keys"].tolist())
+    model.load_state_dict(sd, strict=True)
+    return model.to(device).eval()
+
+
+def run_script(model, g, device):
+    """the exact call sequence of oracle/gen_golden.py:variant_e2e"""
+    t = lambda a: torch.from_numpy(a).to(device)
+    imgs, scrib, scrib2 = t(g["imgs"]), t(g["scrib"]), t(g["scrib2"])
+    nobj = int(g["nobj"])
+    F_, H, W = imgs.shape[0], imgs.shape[2], imgs.shape[3]
+    out = {}
+    up = lambda x: torch.argmax(nn.functional.interpolate(x, size=(H, W), mode="bilinear", align_corners=True), dim=1)
+    with torch.no_grad():
+        embs = model.extract_feature(imgs)
+        out["embs"] = embs
+        gmap, lmaps, seq, start = {}, ({}, {}), "clip", 1
+        gt = torch.Tensor([nobj])
+        tmp, lmaps = model.int_seghead(ref_frame_embedding=embs[start:start + 1], ref_scribble_label=scrib,
+                                       prev_round_label=None, global_map_tmp_dic=gmap, local_map_dics=lmaps,
+                                       interaction_num=1, seq_names=[seq], gt_ids=gt, frame_num=[start],
+                                       first_inter=True)
+        out["int_logits"] = tmp[seq]
+        pred = up(tmp[seq]); out["int_pred"] = pred
+        prev_label, prev_emb = pred.unsqueeze(0), embs[start:start + 1]
+        for ii in (2, 3):
+            res = model.prop_seghead(embs[start:start + 1], prev_emb, embs[ii:ii + 1], scrib, prev_label,
+                                     normalize_nearest_neighbor_distances=True, use_local_map=True,
+                                     seq_names=[seq], gt_ids=gt, k_nearest_neighbors=1, global_map_tmp_dic=gmap,
+                                     local_map_dics=lmaps, interaction_num=1, start_annotated_frame=start,
+                                     frame_num=[ii], dynamic_seghead=model.dynamic_seghead)
+            assert len(res) == 3  # (dic, global_map_tmp_dic, local_map_dics): IntVOS.py:681
+            tmp, gmap, lmaps = res
+            out["prop1_logits_%d" % ii] = tmp[seq]
+            prev_label, prev_emb = up(tmp[seq]).unsqueeze(0), embs[ii:ii + 1]
+        out["gmap_round1"] = gmap[seq][:F_].clone()
+        start2 = 2
+        prev_round = out["int_pred"].float().unsqueeze(0)
+        tmp, lmaps = model.int_seghead(ref_frame_embedding=embs[start2:start2 + 1], ref_scribble_label=scrib2,
+                                       prev_round_label=prev_round, global_map_tmp_dic=gmap, local_map_dics=lmaps,
+                                       interaction_num=2, seq_names=[seq], gt_ids=gt, frame_num=[start2],
+                                       first_inter=False)
+        out["int2_logits"] = tmp[seq]
+        prev_label = up(tmp[seq]).unsqueeze(0)
+        tmp, gmap, lmaps = model.prop_seghead(embs[start2:start2 + 1], embs[start2:start2 + 1], embs[3:4], scrib2,
+                                              prev_label, normalize_nearest_neighbor_distances=True,
+                                              use_local_map=True, seq_names=[seq], gt_ids=gt,
+                                              k_nearest_neighbors=1, global_map_tmp_dic=gmap, local_map_dics=lmaps,
+                                              interaction_num=2, start_annotated_frame=start2, frame_num=[3],
+                                              dynamic_seghead=model.dynamic_seghead)
+        out["prop2_logits_3"] = tmp[seq]
+        out["gmap_round2"] = gmap[seq][:F_].clone()
+        out["lmap_tmp"] = lmaps[0][seq][:F_, :2].clone()
+        out["lmap_dist"] = lmaps[1][seq][:F_, :2].clone()
+        out["gmap_shape"] = torch.tensor(gmap[seq].shape)
+        out["lmap_tmp_shape"] = torch.tensor(lmaps[0][seq].shape)
+        out["lmap_dist_shape"] = torch.tensor(lmaps[1][seq].shape)
+        x3 = torch.cat([imgs[1:2], imgs[2:3], imgs[3:4]], 0)
+        dic = model.forward(x3, scrib, t(g["forward_prev_label"]), seq_names=[seq], gt_ids=gt,
+                            k_nearest_neighbors=1, global_map_tmp_dic=None, local_map_dics=None, interaction_num=1,
+                            start_annotated_frame=1, frame_num=[3])
+        assert isinstance(dic, dict)  # IntVOS.py:675-676: a bare dict when there is no global memory
+        out["forward_logits"] = dic[seq]
+        # prop_seghead with a global memory but no local memory returns a pair (IntVOS.py:678-679)
+        res = model.prop_seghead(embs[1:2], embs[2:3], embs[3:4], scrib, prev_label, seq_names=[seq], gt_ids=gt,
+                                 global_map_tmp_dic={}, local_map_dics=None, interaction_num=1,
+                                 start_annotated_frame=1, frame_num=[3], dynamic_seghead=model.dynamic_seghead)
+        assert len(res) == 2
+    return out
+
+
+def compare(out, g, tol_logits):
+    for k in ["gmap_shape", "lmap_tmp_shape", "lmap_dist_shape"]:
+        assert out[k].tolist() == g[k].tolist(), k  # [104,h,w,n_ids,1], [104,9,h,w,n_ids,1], [104,9]
+    np.testing.assert_allclose(out["embs"].cpu().numpy(), g["embs"], rtol=1e-4, atol=1e-5)
+    for k in ["gmap_round1", "gmap_round2", "lmap_tmp", "lmap_dist"]:
+        np.testing.assert_allclose(out[k].cpu().numpy(), g[k], rtol=1e-4, atol=2e-5, err_msg=k)
+    for k in ["int_logits", "prop1_logits_2", "prop1_logits_3", "int2_logits", "prop2_logits_3", "forward_logits"]:
+        np.testing.assert_allclose(out[k].cpu().numpy(), g[k], rtol=tol_logits, atol=tol_logits, err_msg=k)
+    np.testing.assert_array_equal(out["int_pred"].cpu().numpy(), g["int_pred"])
+
+
+def test_state_dict_names_match_reference_default_model():
+    """822-entry checkpoint compatibility starts with the IntVOS-owned names."""
+    from cvpr2020_manet_amd.config import make_cfg
+    from cvpr2020_manet_amd.networks import IntVOS as M
+
+    class Stub(nn.Module):
+        def forward(self, x):
+            return x
+
+    model = M.IntVOS(make_cfg(["--TEST_MODE", "True"]), Stub())
+    g = load_golden("statedict_default")
+    keys = sorted(model.state_dict().keys())
+    assert keys == g["keys"].tolist()
+    shapes = [str(tuple(model.state_dict()[k].shape)) for k in keys]
+    assert shapes == g["shapes"].tolist()
+    # aliased parameters really are the same tensors (IntVOS.py:537-543)
+    assert model.semantic_embedding[0].weight is model.seperate_conv.weight
+    assert model.semantic_embedding[3].weight is model.embedding_conv.weight
+
+
+def test_host_logic_on_cpu_with_oracle_backed_ops(monkeypatch, oracle):
+    from cvpr2020_manet_amd import ops
+
+    def fake_global(reference_embeddings, query_embeddings, reference_labels, n_ids, k_nearest_neighbors=1,
+                    compute="f32", normalize=False, mem=None):
+        C = query_embeddings.shape[-1]
+        raw = oracle.global_match(reference_embeddings.reshape(-1, 1, C).numpy(),
+                                  query_embeddings.reshape(-1, 1, C).numpy(),
+                                  reference_labels.reshape(-1, 1, 1).numpy(), k_nearest_neighbors, n_ids=n_ids)
+        gq, m = oracle.normalize_merge(raw.reshape(-1, n_ids), None if mem is None else mem.numpy().reshape(-1, n_ids),
+                                       normalize=normalize)
+        if mem is not None:
+            mem.copy_(torch.from_numpy(m).view_as(mem))
+        return torch.from_numpy(gq)
+
+    def fake_local(prev, cur, labels, n_ids, max_distance=12, downsample=True):
+        h, w, _ = cur.shape
+        return torch.from_numpy(oracle.local_match(prev.numpy(), cur.numpy(), labels.numpy(), n_ids, max_distance,
+                                                   downsample).reshape(h, w, n_ids))
+
+    def fake_merge(x, mem=None, normalize=True):
+        gq, m = oracle.normalize_merge(x.numpy().reshape(-1), None if mem is None else mem.numpy().reshape(-1), normalize)
+        x.copy_(torch.from_numpy(gq).view_as(x))
+        if mem is not None:
+            mem.copy_(torch.from_numpy(m).view_as(mem))
+        return x
+
+    monkeypatch.setattr(ops, "global_match", fake_global)
+    monkeypatch.setattr(ops, "local_match", fake_local)
+    monkeypatch.setattr(ops, "normalize_merge_", fake_merge)
+    g = load_golden("e2e_tiny")
+    model = build_model(g, "cpu")
+    compare(run_script(model, g, "cpu"), g, tol_logits=2e-4)
+
+
+def test_cpu_tensors_are_refused_by_the_product_path():
+    from cvpr2020_manet_amd.networks import IntVOS as M
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        M.nearest_neighbor_features_per_object(torch.zeros(4, 4, 8), torch.zeros(4, 4, 8),
+                                               torch.zeros(4, 4, 1, dtype=torch.int32), 1, gt_ids=torch.tensor(1.))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        M.local_previous_frame_nearest_neighbor_features_per_object(
+            torch.zeros(4, 4, 8), torch.zeros(4, 4, 8), torch.zeros(4, 4, 1, dtype=torch.int32),
+            torch.arange(2).int(), max_distance=1)
+
+
+@pytest.mark.gpu
+def test_end_to_end_on_gpu_matches_reference_class():
+    g = load_golden("e2e_tiny")
+    model = build_model(g, "cuda")
+    # logits pass through MIOpen convolutions: fp32 rounding of a different conv algorithm
+    compare(run_script(model, g, "cuda"), g, tol_logits=5e-4)
+
+
+@pytest.mark.gpu
+def test_module_functions_on_gpu_match_reference():
+    from cvpr2020_manet_amd.networks import IntVOS as M
+    M.set_cfg(tiny_cfg())
+    g = load_golden("global_k1_tm1")
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out, ids = M.nearest_neighbor_features_per_object(dev(g["ref_chw"]).permute(1, 2, 0), dev(g["qry_chw"]).permute(1, 2, 0),
+                                                      dev(g["labels"]), 1, gt_ids=torch.tensor(3.), n_chunks=7)
+    assert out.shape == g["out"].shape and ids.dtype == torch.int32 and ids.tolist() == g["ids"].tolist()
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-5, atol=2e-6)
+    g = load_golden("global_k1_noids_tm1")
+    out, ids = M.nearest_neighbor_features_per_object(dev(g["ref_chw"]).permute(1, 2, 0), dev(g["qry_chw"]).permute(1, 2, 0),
+                                                      dev(g["labels"]), 1, gt_ids=None)
+    assert ids.tolist() == g["ids"].tolist()
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-5, atol=2e-6)
+    g = load_golden("local_ds1_C16_12x15_d2")
+    out = M.local_previous_frame_nearest_neighbor_features_per_object(
+        dev(g["prev_chw"]).permute(1, 2, 0), dev(g["cur_chw"]).permute(1, 2, 0), dev(g["labels"]),
+        torch.arange(int(g["n_ids"])).int().cuda(), max_distance=int(g["d"]))
+    assert out.shape == g["out"].shape
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-5, atol=2e-6)
+    dist = M.local_pairwise_distances2(dev(g["cur_chw"]).permute(1, 2, 0), dev(g["prev_chw"]).permute(1, 2, 0),
+                                       max_distance=int(g["d"]))
+    np.testing.assert_allclose(dist.cpu().numpy(), g["dist"], rtol=1e-5, atol=2e-6)
