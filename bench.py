@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", type=str, default="", help="experiments only: key=value,... for manet_tune_set")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,6 +116,9 @@ def main():
 
     from cvpr2020_manet_amd import _lib, clip_parallel, ops
     lib = _lib.load()
+    for kv in filter(None, args.tune.split(",")):
+        k_, v_ = kv.split("=")
+        _lib.check(lib.manet_tune_set(int(k_), int(v_)), "manet_tune_set")
 
     K, Wm = args.steps, args.warmup
     gen = torch.Generator(device=device).manual_seed(20200614 + 2 + 1000 * rank)
@@ -239,7 +243,7 @@ def main():
                        else "none (1 GPU)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "global_match_f32_kernel<13>", "kernel_ms": kern_ms,
+                         "kernel": "global_match_f32_kernel<50>", "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": flops},
         }
         if not args.no_cpu_baseline and world == 1:

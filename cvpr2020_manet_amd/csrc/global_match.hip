@@ -37,7 +37,6 @@ constexpr int BT = 64;        // bank rows per tile (2 MFMA M blocks)
 constexpr int META_INTS = 256;
 constexpr int META_T = 0;          // [0]        number of bank tiles actually used
 constexpr int META_SEG = 1;        // [1..65]    first tile of object o (entry n_ids = T)
-constexpr int META_CUR = 66;       // [66..129]  scatter cursors (row slots)
 constexpr int META_CNT = 130;      // [130..193] rows per object
 
 __host__ __device__ constexpr int ng_of(int C) { return (C + 7) / 8; }
@@ -49,18 +48,22 @@ __host__ __device__ constexpr size_t bank_tile_bytes(int NG)
 // query block: NG x [2][32][4] floats, then 32 |q|^2
 __host__ __device__ constexpr size_t query_block_bytes(int NG) { return (size_t)NG * 2 * QB * 4 * 4 + QB * 4; }
 
-int pick_ng(int C)
+// number of v_mfma_f32_32x32x2 k-steps (2 k each) the kernel is instantiated for; NG = k-groups of 8
+int pick_ks(int C)
 {
-    if (C <= 32) return 4;
-    if (C <= 104) return 13;
-    return 16;
+    if (C <= 32) return 16;
+    if (C <= 100) return 50;   // the reference's embedding width: 50 MFMAs, not 52
+    if (C <= 104) return 52;
+    return 64;
 }
+int pick_ng(int C) { return (pick_ks(C) + 3) / 4; }
 
 struct BankLayout {
     int NG;
     size_t tile_bytes;
     long T_max;  // upper bound on tiles: every object wastes < 1 tile
-    size_t off_meta, off_src, off_pack, total;
+    long nblocks;  // pre-pass blocks of RPB rows
+    size_t off_meta, off_hist, off_src, off_pack, total;
 };
 
 BankLayout bank_layout(int64_t M0, int C, int n_ids)
@@ -69,8 +72,10 @@ BankLayout bank_layout(int64_t M0, int C, int n_ids)
     L.NG = pick_ng(C);
     L.tile_bytes = bank_tile_bytes(L.NG);
     L.T_max = (long)((M0 + BT - 1) / BT) + n_ids;
+    L.nblocks = (long)((M0 + 255) / 256);
     L.off_meta = 0;
-    L.off_src = manet_align_up(META_INTS * sizeof(int), 256);
+    L.off_hist = manet_align_up(META_INTS * sizeof(int), 256);
+    L.off_src = manet_align_up(L.off_hist + (size_t)(L.nblocks > 0 ? L.nblocks : 1) * n_ids * sizeof(int), 256);
     L.off_pack = manet_align_up(L.off_src + (size_t)L.T_max * BT * sizeof(int), 1024);
     L.total = manet_align_up(L.off_pack + (size_t)L.T_max * L.tile_bytes, 1024);
     return L;
@@ -110,28 +115,59 @@ int pick_splits(int nQT, long T_max)
 }
 
 // ---------------------------------------------------------------------------------------------
-// pre-pass 1: rows per object (IntVOS.py:137: a row counts for object o iff label == o)
-__global__ void label_count_kernel(const int *__restrict__ labels, long M0, int n_ids, int *meta)
+// Bank pre-pass = a stable counting sort of the rows by object id, without global atomics
+// (deterministic packing order):
+//   label_hist_kernel      per block of 256 rows: rows per object            -> hist[block][o]
+//   label_scan_kernel      one wave per object: exclusive prefix over blocks -> base[block][o], cnt[o]
+//   label_segments_kernel  tile range of every object (rows padded to whole 64-row tiles)
+//   label_scatter_kernel   slot of row i = seg_start[o]*64 + base[block][o] + rank inside the block
+//   pack_rows_kernel       gather + transpose the rows into the MFMA operand image
+// A row counts for object o iff label == o (IntVOS.py:137); other labels (-1 = unlabelled) are
+// dropped, which is what _selected_pixel (:100-109) / the 1e20 mask (:81-83) amount to for a minimum.
+constexpr int RPB = 256;  // rows per pre-pass block
+
+__global__ __launch_bounds__(RPB) void label_hist_kernel(const int *__restrict__ labels, long M0, int n_ids,
+                                                         int *__restrict__ hist)
 {
-    __shared__ int hist[MANET_MAX_IDS];
-    if (threadIdx.x < MANET_MAX_IDS) hist[threadIdx.x] = 0;
+    __shared__ int h[MANET_MAX_IDS];
+    if (threadIdx.x < MANET_MAX_IDS) h[threadIdx.x] = 0;
     __syncthreads();
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M0; i += (long)gridDim.x * blockDim.x) {
+    long i = (long)blockIdx.x * RPB + threadIdx.x;
+    if (i < M0) {
         int lab = labels[i];
-        if (lab >= 0 && lab < n_ids) atomicAdd(&hist[lab], 1);
+        if (lab >= 0 && lab < n_ids) atomicAdd(&h[lab], 1);  // LDS atomic
     }
     __syncthreads();
-    if (threadIdx.x < n_ids && hist[threadIdx.x]) atomicAdd(&meta[META_CNT + threadIdx.x], hist[threadIdx.x]);
+    if (threadIdx.x < n_ids) hist[(long)blockIdx.x * n_ids + threadIdx.x] = h[threadIdx.x];
 }
 
-// pre-pass 2: tile ranges per object (each object's rows padded up to whole 64-row tiles)
-__global__ void label_scan_kernel(int n_ids, int *meta)
+// grid = n_ids blocks of one wave: exclusive prefix of hist[:, o] over the blocks, in place
+__global__ __launch_bounds__(64) void label_scan_kernel(int *__restrict__ hist, int nblocks, int n_ids,
+                                                        int *__restrict__ meta)
+{
+    const int o = blockIdx.x, lane = threadIdx.x;
+    int carry = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += 64) {
+        int b = b0 + lane;
+        int v = (b < nblocks) ? hist[(long)b * n_ids + o] : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (b < nblocks) hist[(long)b * n_ids + o] = carry + incl - v;
+        carry += __shfl(incl, 63);
+    }
+    if (lane == 0) meta[META_CNT + o] = carry;
+}
+
+__global__ void label_segments_kernel(int n_ids, int *meta)
 {
     if (threadIdx.x == 0) {
         int t = 0;
         for (int o = 0; o < n_ids; ++o) {
             meta[META_SEG + o] = t;
-            meta[META_CUR + o] = t * BT;
             t += (meta[META_CNT + o] + BT - 1) / BT;
         }
         meta[META_SEG + n_ids] = t;
@@ -139,39 +175,48 @@ __global__ void label_scan_kernel(int n_ids, int *meta)
     }
 }
 
-// pre-pass 3: slot -> source row map (slots not hit stay -1 = padding row)
-__global__ void label_scatter_kernel(const int *__restrict__ labels, long M0, int n_ids, int *meta,
-                                     int *__restrict__ src_of)
+// slot -> source row map (slots not hit stay -1 = padding row)
+__global__ __launch_bounds__(RPB) void label_scatter_kernel(const int *__restrict__ labels, long M0, int n_ids,
+                                                            const int *__restrict__ base,
+                                                            const int *__restrict__ meta,
+                                                            int *__restrict__ src_of)
 {
-    const int lane = threadIdx.x & 63;
-    const long base = ((long)blockIdx.x * blockDim.x + threadIdx.x) - lane;  // wave's first row
-    for (long w0 = base; w0 < M0; w0 += (long)gridDim.x * blockDim.x) {
-        long i = w0 + lane;
-        int lab = (i < M0) ? labels[i] : -1;
-        bool active = (lab >= 0 && lab < n_ids);
-        // one atomic per (wave, object): ranks inside the wave come from a ballot
-        while (true) {
-            unsigned long long pending = __ballot(active);
-            if (!pending) break;
-            int leader = __ffsll((long long)pending) - 1;
-            int L = __shfl(lab, leader);
-            bool mine = active && (lab == L);
-            unsigned long long mm = __ballot(mine);
-            int rank = __popcll(mm & ((1ull << lane) - 1ull));
-            int start = 0;
-            if (lane == leader) start = atomicAdd(&meta[META_CUR + L], __popcll(mm));
-            start = __shfl(start, leader);
-            if (mine) {
-                src_of[start + rank] = (int)i;
-                active = false;
-            }
+    __shared__ int wcnt[RPB / 64][MANET_MAX_IDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = threadIdx.x; j < (RPB / 64) * MANET_MAX_IDS; j += RPB) (&wcnt[0][0])[j] = 0;
+    __syncthreads();
+    const long i = (long)blockIdx.x * RPB + threadIdx.x;
+    const int lab = (i < M0) ? labels[i] : -1;
+    const bool valid = (lab >= 0 && lab < n_ids);
+    bool active = valid;
+    int rank = 0;
+    while (true) {  // ranks inside the wave from ballots, one pass per object present in the wave
+        unsigned long long pending = __ballot(active);
+        if (!pending) break;
+        int leader = __ffsll((long long)pending) - 1;
+        int L = __shfl(lab, leader);
+        bool mine = active && (lab == L);
+        unsigned long long mm = __ballot(mine);
+        if (mine) {
+            rank = __popcll(mm & ((1ull << lane) - 1ull));
+            active = false;
         }
+        if (lane == leader) wcnt[wave][L] = __popcll(mm);
+    }
+    __syncthreads();
+    if (valid) {
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += wcnt[w][lab];
+        int slot = meta[META_SEG + lab] * BT + base[(long)blockIdx.x * n_ids + lab] + before + rank;
+        src_of[slot] = (int)i;
     }
 }
 
-// pre-pass 4 (bank, ROWS = 64) and query pack (ROWS = 32): write rows in the MFMA operand image
+// bank (ROWS = 64) and query (ROWS = 32) pack: rows -> MFMA operand image
 //   out[tile] = [g][h][row][j] floats with k = 8g + 2j + h (zero beyond C), then |row|^2[ROWS]
-// |row|^2 is the k-ascending fmaf chain of the oracle (IntVOS.py:32,35).
+// Rows are staged through LDS so that both the global reads (along k for row-major sources, along
+// rows for C-major sources) and the 16-byte image writes are coalesced.  |row|^2 is the
+// k-ascending fmaf chain of the oracle (IntVOS.py:32,35).
 template <int ROWS>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict__ src, long s_row,
                                                         long s_c, const int *__restrict__ src_of,
@@ -181,39 +226,48 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict_
 {
     const long tile = blockIdx.x;
     if (meta && tile >= meta[META_T]) return;
-    __shared__ int s_src[ROWS];
+    extern __shared__ __attribute__((aligned(16))) char pack_smem[];
+    const int KP = 8 * NG + 1;  // odd row stride: column reads are conflict-free
+    float *rows = (float *)pack_smem;                  // [ROWS][KP]
+    int *s_src = (int *)(rows + (long)ROWS * KP);      // [ROWS]
     const int tid = threadIdx.x;
     if (tid < ROWS) {
         long slot = tile * ROWS + tid;
         s_src[tid] = src_of ? src_of[slot] : (slot < n_rows ? (int)slot : -1);
     }
     __syncthreads();
+    if (s_c == 1) {  // row-major source: lanes along k
+        for (int idx = tid; idx < ROWS * C; idx += 256) {
+            int r = idx / C, k = idx - r * C;
+            int sr = s_src[r];
+            rows[r * KP + k] = (sr >= 0) ? src[(long)sr * s_row + k] : 0.0f;
+        }
+    } else {  // C-major (or generic) source: lanes along rows
+        for (int idx = tid; idx < ROWS * C; idx += 256) {
+            int k = idx / ROWS, r = idx - k * ROWS;
+            int sr = s_src[r];
+            rows[r * KP + k] = (sr >= 0) ? src[(long)sr * s_row + (long)k * s_c] : 0.0f;
+        }
+    }
+    for (int idx = tid; idx < ROWS * (8 * NG - C); idx += 256) {
+        int r = idx / (8 * NG - C), k = C + idx - r * (8 * NG - C);
+        rows[r * KP + k] = 0.0f;
+    }
+    __syncthreads();
     float *out = (float *)(dst + tile * tile_bytes);
     for (int item = tid; item < NG * 2 * ROWS; item += 256) {
         int r = item % ROWS, gh = item / ROWS;
         int g = gh >> 1, h = gh & 1;
-        int s = s_src[r];
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (s >= 0) {
-            const float *row = src + (long)s * s_row;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int k = 8 * g + 2 * j + h;
-                if (k < C) v[j] = row[(long)k * s_c];
-            }
-        }
+        const float *row = rows + r * KP + 8 * g + h;
+        f32x4 v = {row[0], row[2], row[4], row[6]};
         *(f32x4 *)(out + ((long)gh * ROWS + r) * 4) = v;
     }
     if (tid < ROWS) {
-        int s = s_src[tid];
         float n = pad_norm;
-        if (s >= 0) {
-            const float *row = src + (long)s * s_row;
+        if (s_src[tid] >= 0) {
             n = 0.0f;
-            for (int k = 0; k < C; ++k) {
-                float x = row[(long)k * s_c];
-                n = fmaf(x, x, n);
-            }
+            const float *row = rows + tid * KP;
+            for (int k = 0; k < C; ++k) n = fmaf(row[k], row[k], n);
         }
         out[(long)NG * 2 * ROWS * 4 + tid] = n;
     }
@@ -234,14 +288,15 @@ __device__ __forceinline__ float float_of(unsigned k)
 
 // ---------------------------------------------------------------------------------------------
 // main kernel, fp32: one workgroup = 256 queries x one bank split
-template <int NG>
+template <int KS>
 __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__restrict__ qpack,
                                                                   const char *__restrict__ bpack,
                                                                   const int *__restrict__ meta,
                                                                   int n_ids, int nQT, int S,
                                                                   long N_pad,
-                                                                  unsigned *__restrict__ keys)
+                                                                  unsigned *__restrict__ keys, int block_map)
 {
+    constexpr int NG = (KS + 3) / 4;
     constexpr size_t TILE_BYTES = bank_tile_bytes(NG);
     constexpr int PIECES = (int)(TILE_BYTES / 1024);
     constexpr size_t QBLK_BYTES = query_block_bytes(NG);
@@ -256,10 +311,19 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
     // XCD-aware mapping: block b runs on XCD b % 8 (observed, used for speed only).  All blocks
     // of one XCD that are resident together share a bank split -> the split streams through L2.
     const int b = blockIdx.x;
-    const int xcd = b & 7;
-    const int idx = b >> 3;
-    const int qt = idx % nQT;
-    const int s = xcd + 8 * (idx / nQT);
+    int qt, s;
+    if (block_map == 0) {
+        const int xcd = b & 7;
+        const int idx = b >> 3;
+        qt = idx % nQT;
+        s = xcd + 8 * (idx / nQT);
+    } else if (block_map == 1) {  // tuning only: query tile fastest, no XCD awareness
+        qt = b % nQT;
+        s = b / nQT;
+    } else {                      // tuning only: split fastest
+        s = b % S;
+        qt = b / S;
+    }
     const int T = meta[META_T];
     const int t0 = (int)((long)s * T / S);
     const int t1 = (int)((long)(s + 1) * T / S);
@@ -328,10 +392,12 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
             f32x4 a1 = A[(g * 2 + h) * BT + 32 + l31];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], q0[g][j], c00, 0, 0, 0);
-                c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], q1[g][j], c01, 0, 0, 0);
-                c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], q0[g][j], c10, 0, 0, 0);
-                c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], q1[g][j], c11, 0, 0, 0);
+                if (g * 4 + j < KS) {  // compile-time: k-steps beyond C are all-zero, skip them
+                    c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], q0[g][j], c00, 0, 0, 0);
+                    c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], q1[g][j], c01, 0, 0, 0);
+                    c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], q0[g][j], c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], q1[g][j], c11, 0, 0, 0);
+                }
             }
         }
         // epilogue: register r of block rb holds bank row rb*32 + (r&3) + 8*(r>>2) + 4*h
@@ -402,17 +468,17 @@ int check_common(int64_t N, int64_t M0, int C, int n_ids, int k_nn, int compute)
     return MANET_OK;
 }
 
-template <int NG>
+template <int KS>
 void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S,
                      long N_pad, unsigned *keys, hipStream_t st)
 {
-    size_t lds = 2 * bank_tile_bytes(NG);
+    size_t lds = 2 * bank_tile_bytes((KS + 3) / 4);
     // per call (cheap, host side): the attribute is per device and the library keeps no state
-    (void)hipFuncSetAttribute((const void *)global_match_f32_kernel<NG>,
+    (void)hipFuncSetAttribute((const void *)global_match_f32_kernel<KS>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     manet_profile_record(st, true);
-    hipLaunchKernelGGL(global_match_f32_kernel<NG>, dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack,
-                       bpack, meta, n_ids, nQT, S, N_pad, keys);
+    hipLaunchKernelGGL(global_match_f32_kernel<KS>, dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack,
+                       bpack, meta, n_ids, nQT, S, N_pad, keys, manet_tune_get(MANET_TUNE_BLOCK_MAP, 0));
     manet_profile_record(st, false);
 }
 
@@ -462,24 +528,24 @@ int manet_bank_prepare(const float *bank, int64_t b_stride_m, int64_t b_stride_c
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)bank_ws;
     int *meta = (int *)(ws + L.off_meta);
+    int *hist = (int *)(ws + L.off_hist);
     int *src_of = (int *)(ws + L.off_src);
     (void)hipMemsetAsync(meta, 0, META_INTS * sizeof(int), st);
     (void)hipMemsetAsync(src_of, 0xff, (size_t)L.T_max * BT * sizeof(int), st);
     if (M0 > 0) {
-        unsigned blocks = (unsigned)((M0 + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(label_count_kernel, dim3(blocks), dim3(256), 0, st, labels, (long)M0, n_ids, meta);
+        hipLaunchKernelGGL(label_hist_kernel, dim3((unsigned)L.nblocks), dim3(RPB), 0, st, labels, (long)M0, n_ids, hist);
+        hipLaunchKernelGGL(label_scan_kernel, dim3((unsigned)n_ids), dim3(64), 0, st, hist, (int)L.nblocks, n_ids, meta);
     }
-    hipLaunchKernelGGL(label_scan_kernel, dim3(1), dim3(64), 0, st, n_ids, meta);
-    if (M0 > 0) {
-        unsigned blocks = (unsigned)((M0 + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(label_scatter_kernel, dim3(blocks), dim3(256), 0, st, labels, (long)M0, n_ids, meta,
-                           src_of);
+    hipLaunchKernelGGL(label_segments_kernel, dim3(1), dim3(64), 0, st, n_ids, meta);
+    if (M0 > 0)
+        hipLaunchKernelGGL(label_scatter_kernel, dim3((unsigned)L.nblocks), dim3(RPB), 0, st, labels, (long)M0, n_ids,
+                           (const int *)hist, (const int *)meta, src_of);
+    {
+        size_t lds = (size_t)BT * (8 * L.NG + 1) * sizeof(float) + BT * sizeof(int);
+        hipLaunchKernelGGL(pack_rows_kernel<BT>, dim3((unsigned)L.T_max), dim3(256), lds, st, bank, (long)b_stride_m,
+                           (long)b_stride_c, (const int *)src_of, (const int *)meta, (long)M0, C, L.NG,
+                           ws + L.off_pack, (long)L.tile_bytes, MANET_WRONG_LABEL_PADDING_DISTANCE);
     }
-    hipLaunchKernelGGL(pack_rows_kernel<BT>, dim3((unsigned)L.T_max), dim3(256), 0, st, bank, (long)b_stride_m,
-                       (long)b_stride_c, (const int *)src_of, (const int *)meta, (long)M0, C, L.NG,
-                       ws + L.off_pack, (long)L.tile_bytes, MANET_WRONG_LABEL_PADDING_DISTANCE);
     return manet_check_launch("manet_bank_prepare");
 }
 
@@ -501,16 +567,24 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
     const int *meta = (const int *)(bws + BL.off_meta);
     unsigned *keys = (unsigned *)(mws + ML.off_keys);
     (void)hipMemsetAsync(keys, 0xff, (size_t)n_ids * ML.N_pad * sizeof(unsigned), st);
-    hipLaunchKernelGGL(pack_rows_kernel<QB>, dim3((unsigned)(ML.N_pad / QB)), dim3(256), 0, st, query,
-                       (long)q_stride_n, (long)q_stride_c, (const int *)nullptr, (const int *)nullptr, (long)N, C,
-                       ML.NG, mws + ML.off_q, (long)ML.qblk_bytes, 0.0f);
-    const int S = pick_splits(ML.nQT, BL.T_max);
+    {
+        size_t lds = (size_t)QB * (8 * ML.NG + 1) * sizeof(float) + QB * sizeof(int);
+        hipLaunchKernelGGL(pack_rows_kernel<QB>, dim3((unsigned)(ML.N_pad / QB)), dim3(256), lds, st, query,
+                           (long)q_stride_n, (long)q_stride_c, (const int *)nullptr, (const int *)nullptr, (long)N,
+                           C, ML.NG, mws + ML.off_q, (long)ML.qblk_bytes, 0.0f);
+    }
+    int S = pick_splits(ML.nQT, BL.T_max);
+    {
+        int forced = manet_tune_get(MANET_TUNE_SPLITS, 0);  // tuning only
+        if (forced > 0) S = (forced + 7) / 8 * 8;
+    }
     const char *qpack = mws + ML.off_q;
     const char *bpack = bws + BL.off_pack;
-    switch (ML.NG) {
-    case 4: launch_main_f32<4>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); break;
-    case 13: launch_main_f32<13>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); break;
-    default: launch_main_f32<16>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); break;
+    switch (pick_ks(C)) {
+    case 16: launch_main_f32<16>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); break;
+    case 50: launch_main_f32<50>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); break;
+    case 52: launch_main_f32<52>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); break;
+    default: launch_main_f32<64>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); break;
     }
     long total = (long)N * n_ids;
     hipLaunchKernelGGL(global_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,

@@ -40,47 +40,156 @@ __global__ void pool2x2_kernel(const float *__restrict__ a, long a_sy, long a_sx
 // IntVOS.py:288-294 (pooled grid, normalised) and :300-313 (full grid, raw).
 // x = current/query frame, y = previous frame, both [H][W][C] with element strides.
 // pooled_out != 0: out[l][H][W] = (sigmoid(dist)-0.5)*2 ; else out[H][W][P*P] = dist.
-__global__ __launch_bounds__(256) void local_dist_kernel(const float *__restrict__ x, long x_sy, long x_sx,
-                                                         long x_sc, const float *__restrict__ y, long y_sy,
-                                                         long y_sx, long y_sc, int H, int W, int C, int d,
-                                                         int pooled_out, float *__restrict__ out)
+//
+// Workgroup = RY grid rows x 16 columns, all P*P offsets.  Thread = (row ry, window row dy, pair of
+// columns): 2 x P running sums in registers.  Per chunk of LD_CC channels the y halo tile
+// [(RY+2d) rows][16+2d cols] (out-of-image = the reference's 1e20 padding, IntVOS.py:287, so
+// (x-1e20)^2 = inf needs no bounds logic in the inner loop) and the x tile are staged in LDS with
+// row-contiguous global reads; a thread then slides its 2+2d wide window over the P offsets out
+// of registers: (2+2d)/2 ds_read_b64 feed 2*P sub+fma pairs.  Channels are accumulated in ascending
+// order with fmaf -- the same arithmetic as the oracle.
+constexpr int LD_TX = 16;  // columns per workgroup
+constexpr int LD_CC = 8;   // channels per LDS stage
+constexpr int LD_NJ = 5;   // halo-plane elements per thread: (8+24) rows x 40 cols <= 5 x 256
+__global__ __launch_bounds__(256, 2) void local_dist_kernel(const float *__restrict__ x, long x_sy, long x_sx,
+                                                            long x_sc, const float *__restrict__ y, long y_sy,
+                                                            long y_sx, long y_sc, int H, int W, int C, int d, int RY,
+                                                            int pooled_out, float *__restrict__ out)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int P = 2 * d + 1;
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)H * W * P) return;
-    int px = (int)(i % W);
-    int py = (int)((i / W) % H);
-    int dy = (int)(i / ((long)W * H));
-    int yy = py + dy - d;
-    const bool row_in = (yy >= 0 && yy < H);
-    float acc[MAXP];
+    const int RYH = RY + 2 * d;               // halo rows
+    const int CW = (LD_TX + 2 * d + 3) & ~3;  // halo row stride (floats), 16 B aligned rows
+    const int yplane = RYH * CW, xplane = RY * LD_TX;
+    const int buf_floats = LD_CC * (yplane + xplane);  // one stage: ys [LD_CC][RYH][CW] then xs [LD_CC][RY][16]
+    float *smem = (float *)smem_raw;
+    const int tid = threadIdx.x;
+    const int px0 = blockIdx.x * LD_TX, py0 = blockIdx.y * RY;
+
+    // staging map, fixed for the whole kernel: this thread's LD_NJ elements of the halo plane and its
+    // one element of the x plane (global offsets without the channel term; -1 = outside the image)
+    long yoff[LD_NJ];
+    int ylds[LD_NJ];
 #pragma unroll
-    for (int dx = 0; dx < MAXP; ++dx) acc[dx] = 0.0f;
-    const float *xp = x + (long)py * x_sy + (long)px * x_sx;
-    const float *yr = y + (long)(row_in ? yy : 0) * y_sy;
-    for (int c = 0; c < C; ++c) {
-        float a = xp[(long)c * x_sc];
-        const float *yc = yr + (long)c * y_sc;
+    for (int j = 0; j < LD_NJ; ++j) {
+        int e = tid + 256 * j;
+        ylds[j] = (e < yplane) ? e : -1;
+        int r = e / CW, col = e - r * CW;
+        int yy = py0 - d + r, xx = px0 - d + col;
+        yoff[j] = (e < yplane && yy >= 0 && yy < H && xx >= 0 && xx < W) ? ((long)yy * y_sy + (long)xx * y_sx) : -1;
+    }
+    long xoff = -1;
+    const bool has_x = tid < xplane;
+    if (has_x) {
+        int r = tid / LD_TX, col = tid - r * LD_TX;
+        if (py0 + r < H && px0 + col < W) xoff = (long)(py0 + r) * x_sy + (long)(px0 + col) * x_sx;
+    }
+    float ry_[LD_CC][LD_NJ], rx_[LD_CC];
+    auto load_regs = [&](int c0) {  // all loads of a stage issued back to back
 #pragma unroll
-        for (int dx = 0; dx < MAXP; ++dx) {
-            if (dx < P) {
-                int xx = px + dx - d;
-                float bv = (row_in && xx >= 0 && xx < W) ? yc[(long)xx * y_sx] : 1e20f;  // IntVOS.py:287
-                float df = a - bv;
-                acc[dx] = acc[dx] + df * df;
+        for (int c = 0; c < LD_CC; ++c) {
+            const bool cin = (c0 + c) < C;
+#pragma unroll
+            for (int j = 0; j < LD_NJ; ++j)
+                ry_[c][j] = (cin && yoff[j] >= 0) ? y[yoff[j] + (long)(c0 + c) * y_sc] : (cin ? 1e20f : 0.0f);
+            rx_[c] = (cin && xoff >= 0) ? x[xoff + (long)(c0 + c) * x_sc] : 0.0f;
+        }
+    };
+    auto store_lds = [&](int buf) {
+        float *ys = smem + (long)buf * buf_floats;
+        float *xs = ys + LD_CC * yplane;
+#pragma unroll
+        for (int c = 0; c < LD_CC; ++c) {
+#pragma unroll
+            for (int j = 0; j < LD_NJ; ++j)
+                if (ylds[j] >= 0) ys[c * yplane + ylds[j]] = ry_[c][j];
+            if (has_x) xs[c * xplane + tid] = rx_[c];
+        }
+    };
+
+    // thread -> (ry, dy, g): g = column pair
+    const int g = tid & 7;
+    const int dy = (tid >> 3) % P;
+    const int ry = (tid >> 3) / P;
+    const bool active = ry < RY;
+    float acc0[MAXP], acc1[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) acc0[i] = acc1[i] = 0.0f;
+
+    load_regs(0);
+    store_lds(0);
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = 0; c0 < C; c0 += LD_CC, buf ^= 1) {
+        const bool more = (c0 + LD_CC) < C;
+        if (more) load_regs(c0 + LD_CC);  // next stage's global loads fly under this stage's math
+        if (active) {
+            const float *ys = smem + (long)buf * buf_floats;
+            const float *xs = ys + LD_CC * yplane;
+#pragma nounroll
+            for (int c = 0; c < LD_CC; ++c) {  // channels beyond C were staged as x = y = 0 (adds 0) / 1e20 (already inf)
+                const float *yrow = ys + c * yplane + (ry + dy) * CW + 2 * g;
+                const float2 xv = *(const float2 *)(xs + c * xplane + ry * LD_TX + 2 * g);
+                float win[MAXP + 1];
+#pragma unroll
+                for (int i = 0; i < (MAXP + 1) / 2; ++i) {
+                    if (2 * i < P + 1) {
+                        float2 t = *(const float2 *)(yrow + 2 * i);
+                        win[2 * i] = t.x;
+                        win[2 * i + 1] = t.y;
+                    }
+                }
+#pragma unroll
+                for (int dx = 0; dx < MAXP; ++dx) {
+                    if (dx < P) {
+                        float d0 = xv.x - win[dx];
+                        float d1 = xv.y - win[dx + 1];
+                        acc0[dx] = fmaf(d0, d0, acc0[dx]);
+                        acc1[dx] = fmaf(d1, d1, acc1[dx]);
+                    }
+                }
             }
         }
+        if (more) store_lds(buf ^ 1);
+        __syncthreads();
     }
+    if (!active) return;
+    const int py = py0 + ry, pxa = px0 + 2 * g;
+    if (py >= H) return;
 #pragma unroll
     for (int dx = 0; dx < MAXP; ++dx) {
         if (dx < P) {
-            int l = dy * P + dx;
-            if (pooled_out)
-                out[((long)l * H + py) * W + px] = manet_normalize_dist(acc[dx]);
-            else
-                out[((long)py * W + px) * (P * P) + l] = acc[dx];
+            const int l = dy * P + dx;
+            if (pooled_out) {
+                float *o = out + ((long)l * H + py) * W + pxa;
+                if (pxa < W) o[0] = manet_normalize_dist(acc0[dx]);
+                if (pxa + 1 < W) o[1] = manet_normalize_dist(acc1[dx]);
+            } else {
+                if (pxa < W) out[((long)py * W + pxa) * (P * P) + l] = acc0[dx];
+                if (pxa + 1 < W) out[((long)py * W + pxa + 1) * (P * P) + l] = acc1[dx];
+            }
         }
     }
+}
+
+struct DistLaunch {
+    int RY;
+    dim3 grid;
+    size_t lds;
+};
+static DistLaunch dist_launch(int H, int W, int d)
+{
+    DistLaunch L;
+    const int P = 2 * d + 1;
+    int ry = 32 / P;  // 256 threads = 32 (row, dy) slots x 8 column pairs
+    if (ry < 1) ry = 1;
+    if (ry > 8) ry = 8;
+    if (ry > H) ry = H;
+    L.RY = ry;
+    L.grid = dim3((unsigned)((W + LD_TX - 1) / LD_TX), (unsigned)((H + ry - 1) / ry));
+    const int CW = (LD_TX + 2 * d + 3) & ~3;
+    L.lds = 2 * (size_t)LD_CC * ((size_t)(ry + 2 * d) * CW + (size_t)ry * LD_TX) * sizeof(float);  // 2 stages
+    return L;
 }
 
 // F.interpolate(..., mode='bilinear', align_corners=True) coefficients (IntVOS.py:295):
@@ -112,14 +221,21 @@ __device__ __forceinline__ float bilin_sample(const float *__restrict__ pl, int 
 // IntVOS.py:398-408 (label unfold, stride 2, zero padding) + :428-432 (where / min).
 // pooled != 0: dvol = [P*P][hp][wp] normalised pooled volume, sampled bilinearly at (y, x);
 // pooled == 0: dvol = [h][w][P*P] full-resolution raw distances.
-constexpr int NI = 8;  // object ids per pass
-__global__ __launch_bounds__(256) void local_min_kernel(const float *__restrict__ dvol, int pooled,
-                                                        const int *__restrict__ labels, int h, int w, int hp,
-                                                        int wp, int d, int n_ids, float *__restrict__ out)
+// Workgroup = 64 consecutive pixels x LM_WAVES waves; wave k takes window rows by = k, k+LM_WAVES, ..
+// (lanes run along x, so tap and label loads are row segments); partial minima meet in LDS.
+constexpr int NI = 8;        // object ids per pass
+constexpr int LM_WAVES = 8;  // waves per workgroup
+__global__ __launch_bounds__(64 * LM_WAVES) void local_min_kernel(const float *__restrict__ dvol, int pooled,
+                                                                  const int *__restrict__ labels, int h, int w,
+                                                                  int hp, int wp, int d, int n_ids,
+                                                                  float *__restrict__ out)
 {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)h * w) return;
-    const int y = (int)(i / w), x = (int)(i - (long)y * w);
+    __shared__ float red[LM_WAVES][NI][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + lane;
+    const bool valid = i < (long)h * w;
+    const int y = valid ? (int)(i / w) : 0, x = valid ? (int)(i - (long)y * w) : 0;
     const int P = 2 * d + 1;
     Bilin cy = {0, 0, 0.f, 0.f}, cx = {0, 0, 0.f, 0.f};
     if (pooled) {
@@ -131,21 +247,34 @@ __global__ __launch_bounds__(256) void local_min_kernel(const float *__restrict_
         float m[NI];
 #pragma unroll
         for (int k = 0; k < NI; ++k) m[k] = INFINITY;
-        for (int by = 0; by < P; ++by) {
-            const int yy = y + 2 * (by - d);
-            const bool yin = (yy >= 0 && yy < h);
-            for (int bx = 0; bx < P; ++bx) {
-                const int xx = x + 2 * (bx - d);
-                const int lab = (yin && xx >= 0 && xx < w) ? labels[(long)yy * w + xx] : 0;
-                const int l = by * P + bx;
-                const float v = pooled ? bilin_sample(dvol + (long)l * plane, wp, cy, cx) : dvol[i * (P * P) + l];
+        if (valid) {
+            for (int by = wave; by < P; by += LM_WAVES) {
+                const int yy = y + 2 * (by - d);
+                const bool yin = (yy >= 0 && yy < h);
+#pragma unroll 5
+                for (int bx = 0; bx < P; ++bx) {
+                    const int xx = x + 2 * (bx - d);
+                    const int lab = (yin && xx >= 0 && xx < w) ? labels[(long)yy * w + xx] : 0;
+                    const int l = by * P + bx;
+                    const float v = pooled ? bilin_sample(dvol + (long)l * plane, wp, cy, cx) : dvol[i * (P * P) + l];
 #pragma unroll
-                for (int k = 0; k < NI; ++k) m[k] = fminf(m[k], (lab == o0 + k) ? v : 1.0f);
+                    for (int k = 0; k < NI; ++k) m[k] = fminf(m[k], (lab == o0 + k) ? v : 1.0f);
+                }
             }
         }
 #pragma unroll
-        for (int k = 0; k < NI; ++k)
-            if (o0 + k < n_ids) out[i * n_ids + o0 + k] = m[k];
+        for (int k = 0; k < NI; ++k) red[wave][k][lane] = m[k];
+        __syncthreads();
+        if (wave == 0 && valid) {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                float r = red[0][k][lane];
+#pragma unroll
+                for (int ww = 1; ww < LM_WAVES; ++ww) r = fminf(r, red[ww][k][lane]);
+                if (o0 + k < n_ids) out[i * n_ids + o0 + k] = r;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -202,16 +331,16 @@ float *enqueue_volume(const float *cur, int64_t c_sy, int64_t c_sx, int64_t c_sc
         long n = (long)C * L.hp * L.wp;
         hipLaunchKernelGGL(pool2x2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cur, (long)c_sy,
                            (long)c_sx, (long)c_sc, prev, (long)p_sy, (long)p_sx, (long)p_sc, C, L.hp, L.wp, ap, bp);
-        long t = (long)L.hp * L.wp * P;
         long plane = (long)L.hp * L.wp;
-        hipLaunchKernelGGL(local_dist_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, st,
-                           (const float *)ap, (long)L.wp, 1L, plane, (const float *)bp, (long)L.wp, 1L, plane, L.hp,
-                           L.wp, C, d, 1, vol);
+        DistLaunch DL = dist_launch(L.hp, L.wp, d);
+        hipLaunchKernelGGL(local_dist_kernel, DL.grid, dim3(256), DL.lds, st, (const float *)ap, (long)L.wp, 1L, plane,
+                           (const float *)bp, (long)L.wp, 1L, plane, L.hp, L.wp, C, d, DL.RY, 1, vol);
     } else {
-        long t = (long)h * w * P;
-        hipLaunchKernelGGL(local_dist_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, st, cur, (long)c_sy,
-                           (long)c_sx, (long)c_sc, prev, (long)p_sy, (long)p_sx, (long)p_sc, h, w, C, d, 0, vol);
+        DistLaunch DL = dist_launch(h, w, d);
+        hipLaunchKernelGGL(local_dist_kernel, DL.grid, dim3(256), DL.lds, st, cur, (long)c_sy, (long)c_sx, (long)c_sc,
+                           prev, (long)p_sy, (long)p_sx, (long)p_sc, h, w, C, d, DL.RY, 0, vol);
     }
+    (void)P;
     return vol;
 }
 
@@ -239,9 +368,9 @@ int manet_local_dist_f32(const float *cur, int64_t c_sy, int64_t c_sx, int64_t c
     hipStream_t st = (hipStream_t)stream;
     const int d = max_distance;
     if (!downsample) {  // the volume is the result: write it straight into out
-        long t = (long)h * w * (2 * d + 1);
-        hipLaunchKernelGGL(local_dist_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, st, cur, (long)c_sy,
-                           (long)c_sx, (long)c_sc, prev, (long)p_sy, (long)p_sx, (long)p_sc, h, w, C, d, 0, out);
+        DistLaunch DL = dist_launch(h, w, d);
+        hipLaunchKernelGGL(local_dist_kernel, DL.grid, dim3(256), DL.lds, st, cur, (long)c_sy, (long)c_sx, (long)c_sc,
+                           prev, (long)p_sy, (long)p_sx, (long)p_sc, h, w, C, d, DL.RY, 0, out);
         return manet_check_launch("manet_local_dist_f32");
     }
     LocalLayout L = local_layout(h, w, C, d, downsample);
@@ -272,8 +401,8 @@ int manet_local_match_f32(const float *prev, int64_t p_sy, int64_t p_sx, int64_t
     float *vol = enqueue_volume(cur, c_sy, c_sx, c_sc, prev, p_sy, p_sx, p_sc, h, w, C, max_distance, downsample,
                                 (char *)workspace, L, st);
     long n = (long)h * w;
-    hipLaunchKernelGGL(local_min_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float *)vol,
-                       downsample ? 1 : 0, prev_labels, h, w, L.hp, L.wp, max_distance, n_ids, out);
+    hipLaunchKernelGGL(local_min_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * LM_WAVES), 0, st,
+                       (const float *)vol, downsample ? 1 : 0, prev_labels, h, w, L.hp, L.wp, max_distance, n_ids, out);
     return manet_check_launch("manet_local_match_f32");
 }
 

@@ -34,7 +34,19 @@ void manet_profile_record(hipStream_t st, bool start)
     (void)hipEventRecord(g_prof.ev[g_prof.used++], st);
 }
 
+static int g_tune[MANET_TUNE_COUNT] = {0};
+static bool g_tune_set[MANET_TUNE_COUNT] = {false};
+int manet_tune_get(int key, int dflt) { return (key >= 0 && key < MANET_TUNE_COUNT && g_tune_set[key]) ? g_tune[key] : dflt; }
+
 extern "C" {
+
+int manet_tune_set(int key, int value)
+{
+    if (key < 0 || key >= MANET_TUNE_COUNT) return manet_set_error(MANET_E_INVALID, "tune key %d", key);
+    g_tune[key] = value;
+    g_tune_set[key] = true;
+    return MANET_OK;
+}
 
 int manet_profile_begin(int max_launches)
 {

@@ -156,6 +156,10 @@ int manet_correlation_forward_f32(const float *in1, const float *in2, int B, int
  * events on its own stream.  manet_profile_end synchronises on those events (the only call in
  * this library that blocks) and returns the per-launch durations in milliseconds. */
 int manet_profile_begin(int max_launches);
+/* Tuning knobs for experiments (process-wide; the defaults are the shipped configuration):
+ * key 0 = block -> (query tile, bank split) mapping of the global-match kernel (0 XCD-aware),
+ * key 1 = forced number of bank splits (0 = automatic). */
+int manet_tune_set(int key, int value);
 int manet_profile_end(float *ms_out, int capacity, int *n_launches);
 
 #ifdef __cplusplus

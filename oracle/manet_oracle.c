@@ -234,7 +234,7 @@ void oracle_local_dist_f32(const float *x, long xs_y, long xs_x, long xs_c,
                             float a = x[py * xs_y + px * xs_x + c * xs_c];
                             float b = oob ? 1e20f : y[yy * ys_y + xx * ys_x + c * ys_c];
                             float df = a - b;
-                            acc = acc + df * df; /* torch.pow(.,2) then sum: two roundings */
+                            acc = fmaf(df, df, acc); /* one rounding less than torch.pow(.,2)+sum; same as the HIP kernel */
                         }
                         out[((long)py * w + px) * PP + dy * P + dx] = acc;
                     }
@@ -267,7 +267,7 @@ void oracle_local_dist_f32(const float *x, long xs_y, long xs_x, long xs_c,
                         float a = xp[((long)c * hp + py) * wp + px];
                         float b = oob ? 1e20f : yp[((long)c * hp + yy) * wp + xx];
                         float df = a - b;
-                        acc = acc + df * df;
+                        acc = fmaf(df, df, acc);
                     }
                     dp[((long)(dy * P + dx) * hp + py) * wp + px] = normalize_dist(acc);
                 }
