@@ -104,14 +104,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the matching path has no CPU fallback")
+    # MANET_BENCH_BACKEND=gloo: dry run of the N>1 flow on fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("MANET_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
 
     from cvpr2020_manet_amd import _lib, clip_parallel, ops

@@ -51,6 +51,20 @@ def bank_slots(bank_frames, num_frames, world_size):
     return slots, table
 
 
+def _all_gather_flat(slab, world, group):
+    """ONE all-gather of equal-size flat slabs.  backend "nccl" (= RCCL): device buffers travel over
+    xGMI directly.  gloo has no device all-gather, so device slabs are staged through host memory
+    there (CPU tests, single-GPU dry runs of the N>1 flow)."""
+    if dist.get_backend(group) == "gloo" and slab.is_cuda:
+        host = slab.cpu()
+        out = torch.empty(world * host.numel(), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out.to(slab.device)
+    out = torch.empty(world * slab.numel(), dtype=slab.dtype, device=slab.device)
+    dist.all_gather_into_tensor(out, slab, group=group)
+    return out
+
+
 def exchange_bank_and_halo(local_embeddings, local_start, bank_frames, bank_labels, num_frames,
                            group=None):
     """One all-gather that gives every rank the full memory bank and its halo frame.
@@ -81,9 +95,7 @@ def exchange_bank_and_halo(local_embeddings, local_start, bank_frames, bank_labe
         slab[off:off + lab_elems] = lab.view(torch.float32)  # bit-cast, travels unchanged
     if f_local > 0:
         slab[slots * (frame_elems + lab_elems):] = local_embeddings[f_local - 1].reshape(-1)
-    gathered = torch.empty(world * slab_elems, dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(gathered, slab, group=group)
-    gathered = gathered.view(world, slab_elems)
+    gathered = _all_gather_flat(slab, world, group).view(world, slab_elems)
     order = sorted(table, key=lambda t: t[2])
     bank_emb = torch.stack([gathered[r, s * frame_elems:(s + 1) * frame_elems].view(C, h, w)
                             for (r, s, f) in order])

@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int MAXP = 2 * MANET_MAX_LOCAL_DISTANCE + 1;
+// (window width P = 2d+1 <= 2*MANET_MAX_LOCAL_DISTANCE+1 = 25)
 
 // IntVOS.py:282-284  F.avg_pool2d(x, (2,2), (2,2)): window summed row-major, times 1/4 (exact)
 __global__ void pool2x2_kernel(const float *__restrict__ a, long a_sy, long a_sx, long a_sc,
@@ -51,13 +51,16 @@ __global__ void pool2x2_kernel(const float *__restrict__ a, long a_sy, long a_sx
 constexpr int LD_TX = 16;  // columns per workgroup
 constexpr int LD_CC = 8;   // channels per LDS stage
 constexpr int LD_NJ = 5;   // halo-plane elements per thread: (8+24) rows x 40 cols <= 5 x 256
+template <int D>  // window radius: compile-time so the 2 x P accumulators unroll without predicates
 __global__ __launch_bounds__(256, 2) void local_dist_kernel(const float *__restrict__ x, long x_sy, long x_sx,
                                                             long x_sc, const float *__restrict__ y, long y_sy,
-                                                            long y_sx, long y_sc, int H, int W, int C, int d, int RY,
+                                                            long y_sx, long y_sc, int H, int W, int C, int RY,
                                                             int pooled_out, float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int P = 2 * d + 1;
+    constexpr int d = D;
+    constexpr int P = 2 * d + 1;
+    constexpr int MAXP = P;  // shadows the file-level bound: arrays are exactly P wide here
     const int RYH = RY + 2 * d;               // halo rows
     const int CW = (LD_TX + 2 * d + 3) & ~3;  // halo row stride (floats), 16 B aligned rows
     const int yplane = RYH * CW, xplane = RY * LD_TX;
@@ -172,6 +175,11 @@ __global__ __launch_bounds__(256, 2) void local_dist_kernel(const float *__restr
     }
 }
 
+struct DistLaunch;
+template <int D>
+static void launch_dist_d(const DistLaunch &DL, hipStream_t st, const float *x, long x_sy, long x_sx, long x_sc,
+                          const float *y, long y_sy, long y_sx, long y_sc, int H, int W, int C, int pooled_out,
+                          float *out);
 struct DistLaunch {
     int RY;
     dim3 grid;
@@ -190,6 +198,27 @@ static DistLaunch dist_launch(int H, int W, int d)
     const int CW = (LD_TX + 2 * d + 3) & ~3;
     L.lds = 2 * (size_t)LD_CC * ((size_t)(ry + 2 * d) * CW + (size_t)ry * LD_TX) * sizeof(float);  // 2 stages
     return L;
+}
+template <int D>
+static void launch_dist_d(const DistLaunch &DL, hipStream_t st, const float *x, long x_sy, long x_sx, long x_sc,
+                          const float *y, long y_sy, long y_sx, long y_sc, int H, int W, int C, int pooled_out,
+                          float *out)
+{
+    hipLaunchKernelGGL(local_dist_kernel<D>, DL.grid, dim3(256), DL.lds, st, x, x_sy, x_sx, x_sc, y, y_sy, y_sx, y_sc,
+                       H, W, C, DL.RY, pooled_out, out);
+}
+static void launch_dist(int d, hipStream_t st, const float *x, long x_sy, long x_sx, long x_sc, const float *y,
+                        long y_sy, long y_sx, long y_sc, int H, int W, int C, int pooled_out, float *out)
+{
+    DistLaunch DL = dist_launch(H, W, d);
+#define MANET_LD_CASE(D_) case D_: launch_dist_d<D_>(DL, st, x, x_sy, x_sx, x_sc, y, y_sy, y_sx, y_sc, H, W, C, pooled_out, out); break;
+    switch (d) {
+        MANET_LD_CASE(0) MANET_LD_CASE(1) MANET_LD_CASE(2) MANET_LD_CASE(3) MANET_LD_CASE(4) MANET_LD_CASE(5)
+        MANET_LD_CASE(6) MANET_LD_CASE(7) MANET_LD_CASE(8) MANET_LD_CASE(9) MANET_LD_CASE(10) MANET_LD_CASE(11)
+        MANET_LD_CASE(12)
+    default: break;  // check_local() rejected it already
+    }
+#undef MANET_LD_CASE
 }
 
 // F.interpolate(..., mode='bilinear', align_corners=True) coefficients (IntVOS.py:295):
@@ -332,13 +361,11 @@ float *enqueue_volume(const float *cur, int64_t c_sy, int64_t c_sx, int64_t c_sc
         hipLaunchKernelGGL(pool2x2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cur, (long)c_sy,
                            (long)c_sx, (long)c_sc, prev, (long)p_sy, (long)p_sx, (long)p_sc, C, L.hp, L.wp, ap, bp);
         long plane = (long)L.hp * L.wp;
-        DistLaunch DL = dist_launch(L.hp, L.wp, d);
-        hipLaunchKernelGGL(local_dist_kernel, DL.grid, dim3(256), DL.lds, st, (const float *)ap, (long)L.wp, 1L, plane,
-                           (const float *)bp, (long)L.wp, 1L, plane, L.hp, L.wp, C, d, DL.RY, 1, vol);
+        launch_dist(d, st, (const float *)ap, (long)L.wp, 1L, plane, (const float *)bp, (long)L.wp, 1L, plane, L.hp,
+                    L.wp, C, 1, vol);
     } else {
-        DistLaunch DL = dist_launch(h, w, d);
-        hipLaunchKernelGGL(local_dist_kernel, DL.grid, dim3(256), DL.lds, st, cur, (long)c_sy, (long)c_sx, (long)c_sc,
-                           prev, (long)p_sy, (long)p_sx, (long)p_sc, h, w, C, d, DL.RY, 0, vol);
+        launch_dist(d, st, cur, (long)c_sy, (long)c_sx, (long)c_sc, prev, (long)p_sy, (long)p_sx, (long)p_sc, h, w, C,
+                    0, vol);
     }
     (void)P;
     return vol;
@@ -368,9 +395,8 @@ int manet_local_dist_f32(const float *cur, int64_t c_sy, int64_t c_sx, int64_t c
     hipStream_t st = (hipStream_t)stream;
     const int d = max_distance;
     if (!downsample) {  // the volume is the result: write it straight into out
-        DistLaunch DL = dist_launch(h, w, d);
-        hipLaunchKernelGGL(local_dist_kernel, DL.grid, dim3(256), DL.lds, st, cur, (long)c_sy, (long)c_sx, (long)c_sc,
-                           prev, (long)p_sy, (long)p_sx, (long)p_sc, h, w, C, d, DL.RY, 0, out);
+        launch_dist(d, st, cur, (long)c_sy, (long)c_sx, (long)c_sc, prev, (long)p_sy, (long)p_sx, (long)p_sc, h, w, C,
+                    0, out);
         return manet_check_launch("manet_local_dist_f32");
     }
     LocalLayout L = local_layout(h, w, C, d, downsample);
