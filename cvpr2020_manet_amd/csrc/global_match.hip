@@ -85,10 +85,12 @@ struct MatchLayout {
     int NG;
     long N_pad;
     int nQT;
-    size_t qblk_bytes, off_q, off_keys, total;
+    size_t qblk_bytes, off_q, off_keys, off_topk, total;
 };
 
-MatchLayout match_layout(int64_t N, int C, int n_ids)
+constexpr int TOPK_SPLITS = 16;  // the top-k path trades a little tail balance for a bounded workspace
+
+MatchLayout match_layout(int64_t N, int C, int n_ids, int k_nn = 1)
 {
     MatchLayout L;
     L.NG = pick_ng(C);
@@ -97,7 +99,10 @@ MatchLayout match_layout(int64_t N, int C, int n_ids)
     L.qblk_bytes = query_block_bytes(L.NG);
     L.off_q = 0;
     L.off_keys = manet_align_up((size_t)(L.N_pad / QB) * L.qblk_bytes, 256);
-    L.total = manet_align_up(L.off_keys + (size_t)n_ids * L.N_pad * sizeof(unsigned), 1024);
+    L.off_topk = manet_align_up(L.off_keys + (size_t)n_ids * L.N_pad * sizeof(unsigned), 1024);
+    L.total = L.off_topk;
+    if (k_nn > 1)
+        L.total = manet_align_up(L.off_topk + (size_t)TOPK_SPLITS * n_ids * L.N_pad * MANET_MAX_KNN * sizeof(float), 1024);
     return L;
 }
 
@@ -288,13 +293,29 @@ __device__ __forceinline__ float float_of(unsigned k)
 
 // ---------------------------------------------------------------------------------------------
 // main kernel, fp32: one workgroup = 256 queries x one bank split
-template <int KS>
+// sorted insert of d into the ascending list m[0..K-1] (drops the largest)
+template <int K>
+__device__ __forceinline__ void topk_insert(float (&m)[K], float d)
+{
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        float lo = fminf(m[j], d);
+        d = fmaxf(m[j], d);
+        m[j] = lo;
+    }
+}
+
+// KNN = 1: masked minimum (IntVOS.py:84-85), splits meet through atomicMin on `keys`.
+// KNN = 8: the MANET_MAX_KNN smallest distances per (query, object) for the top-k path
+//          (IntVOS.py:87-94); every split writes its sorted list to `topk` [S][n_ids][N_pad][8].
+template <int KS, int KNN>
 __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__restrict__ qpack,
                                                                   const char *__restrict__ bpack,
                                                                   const int *__restrict__ meta,
                                                                   int n_ids, int nQT, int S,
                                                                   long N_pad,
-                                                                  unsigned *__restrict__ keys, int block_map)
+                                                                  unsigned *__restrict__ keys,
+                                                                  float *__restrict__ topk, int block_map)
 {
     constexpr int NG = (KS + 3) / 4;
     constexpr size_t TILE_BYTES = bank_tile_bytes(NG);
@@ -363,14 +384,43 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
     int o = 0;
     while (meta[META_SEG + o + 1] <= t0) ++o;  // object owning tile t0
     int seg_end = meta[META_SEG + o + 1];
-    float m0 = MANET_WRONG_LABEL_PADDING_DISTANCE, m1 = MANET_WRONG_LABEL_PADDING_DISTANCE;
+    float m0[KNN], m1[KNN];
+    auto reset = [&]() {
+#pragma unroll
+        for (int j = 0; j < KNN; ++j) m0[j] = m1[j] = (KNN == 1) ? MANET_WRONG_LABEL_PADDING_DISTANCE : INFINITY;
+    };
+    reset();
 
     auto flush = [&](int obj) {
-        float a = fminf(m0, __shfl_xor(m0, 32));
-        float c = fminf(m1, __shfl_xor(m1, 32));
-        if (h == 0) {
-            atomicMin(keys + (size_t)obj * N_pad + qbase, key_of(a));
-            atomicMin(keys + (size_t)obj * N_pad + qbase + 32, key_of(c));
+        if (KNN == 1) {
+            float a = fminf(m0[0], __shfl_xor(m0[0], 32));
+            float c = fminf(m1[0], __shfl_xor(m1[0], 32));
+            if (h == 0) {
+                atomicMin(keys + (size_t)obj * N_pad + qbase, key_of(a));
+                atomicMin(keys + (size_t)obj * N_pad + qbase + 32, key_of(c));
+            }
+        } else {
+            // merge the other half-wave's list into ours, then the lower half writes the split's list
+            float o0[KNN], o1[KNN];
+#pragma unroll
+            for (int j = 0; j < KNN; ++j) {
+                o0[j] = __shfl_xor(m0[j], 32);
+                o1[j] = __shfl_xor(m1[j], 32);
+            }
+#pragma unroll
+            for (int j = 0; j < KNN; ++j) {
+                topk_insert<KNN>(m0, o0[j]);
+                topk_insert<KNN>(m1, o1[j]);
+            }
+            if (h == 0) {
+                float *p0 = topk + (((size_t)s * n_ids + obj) * N_pad + qbase) * KNN;
+                float *p1 = p0 + (size_t)32 * KNN;
+#pragma unroll
+                for (int j = 0; j < KNN; ++j) {
+                    p0[j] = m0[j];
+                    p1[j] = m1[j];
+                }
+            }
         }
     };
 
@@ -380,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
         if (t + 1 < t1) stage(t + 1, buf ^ 1);
         if (t >= seg_end) {  // wave-uniform: crossed into the next object's rows
             flush(o);
-            m0 = m1 = MANET_WRONG_LABEL_PADDING_DISTANCE;
+            reset();
             do { ++o; seg_end = meta[META_SEG + o + 1]; } while (t >= seg_end);
         }
         const char *tb = smem + (size_t)buf * TILE_BYTES;
@@ -409,10 +459,19 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * tq + i;
-                m0 = fminf(m0, fmaf(-2.0f, c00[r], xs0 + y0[i]));  // IntVOS.py:39
-                m1 = fminf(m1, fmaf(-2.0f, c01[r], xs1 + y0[i]));
-                m0 = fminf(m0, fmaf(-2.0f, c10[r], xs0 + y1[i]));
-                m1 = fminf(m1, fmaf(-2.0f, c11[r], xs1 + y1[i]));
+                const float d00 = fmaf(-2.0f, c00[r], xs0 + y0[i]);  // IntVOS.py:39
+                const float d01 = fmaf(-2.0f, c01[r], xs1 + y0[i]);
+                const float d10 = fmaf(-2.0f, c10[r], xs0 + y1[i]);
+                const float d11 = fmaf(-2.0f, c11[r], xs1 + y1[i]);
+                if (KNN == 1) {
+                    m0[0] = fminf(m0[0], fminf(d00, d10));
+                    m1[0] = fminf(m1[0], fminf(d01, d11));
+                } else {
+                    topk_insert<KNN>(m0, d00);
+                    topk_insert<KNN>(m0, d10);
+                    topk_insert<KNN>(m1, d01);
+                    topk_insert<KNN>(m1, d11);
+                }
             }
         }
     }
@@ -430,6 +489,49 @@ __global__ void global_finish_kernel(const unsigned *__restrict__ keys, long N, 
     unsigned k = keys[(size_t)o * N_pad + n];
     // an object with no bank row keeps the initial key: padding distance (IntVOS.py:81-83)
     float g = (k == 0xffffffffu) ? MANET_WRONG_LABEL_PADDING_DISTANCE : float_of(k);
+    if (flags & MANET_EPI_NORMALIZE) g = manet_normalize_dist(g);
+    if (mem) {
+        float mv = mem[i];
+        g = (g <= mv) ? g : mv;
+        mem[i] = g;
+    }
+    out[i] = g;
+}
+
+// top-k epilogue (IntVOS.py:87-94): merge the splits' lists, keep the k smallest; entries >= 1e20
+// are the reference's masked rows (here: tile padding rows / missing rows): replaced by
+// pad = max(valid distances, and 0 if any entry is invalid) -- `dists * valid_mask` zeroes them
+// before the max -- then the mean.  Then the same normalise / merge as the k=1 path.
+__global__ void global_finish_topk_kernel(const float *__restrict__ topk, int S, int k_nn, long N, long N_pad,
+                                          int n_ids, int flags, float *__restrict__ out,
+                                          float *__restrict__ mem)
+{
+    constexpr int K = MANET_MAX_KNN;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * n_ids) return;
+    long n = i / n_ids;
+    int o = (int)(i - n * n_ids);
+    float best[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) best[j] = INFINITY;
+    for (int sp = 0; sp < S; ++sp) {
+        const float *p = topk + (((size_t)sp * n_ids + o) * N_pad + n) * K;
+#pragma unroll
+        for (int j = 0; j < K; ++j) topk_insert<K>(best, p[j]);
+    }
+    float pad = -INFINITY, sum = 0.0f;
+    bool any_invalid = false;
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (j < k_nn) {
+            if (best[j] < MANET_WRONG_LABEL_PADDING_DISTANCE) pad = fmaxf(pad, best[j]);
+            else any_invalid = true;
+        }
+    if (any_invalid) pad = fmaxf(pad, 0.0f);
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (j < k_nn) sum += (best[j] < MANET_WRONG_LABEL_PADDING_DISTANCE) ? best[j] : pad;
+    float g = sum / (float)k_nn;
     if (flags & MANET_EPI_NORMALIZE) g = manet_normalize_dist(g);
     if (mem) {
         float mv = mem[i];
@@ -462,23 +564,26 @@ int check_common(int64_t N, int64_t M0, int C, int n_ids, int k_nn, int compute)
     if (C <= 0 || C > MANET_MAX_C) return manet_set_error(MANET_E_INVALID, "C=%d (supported 1..%d)", C, MANET_MAX_C);
     if (n_ids <= 0 || n_ids > MANET_MAX_IDS)
         return manet_set_error(MANET_E_INVALID, "n_ids=%d (supported 1..%d)", n_ids, MANET_MAX_IDS);
-    if (k_nn != 1) return manet_set_error(MANET_E_INVALID, "k_nn=%d not supported yet (only 1)", k_nn);
+    if (k_nn < 1 || k_nn > MANET_MAX_KNN)
+        return manet_set_error(MANET_E_INVALID, "k_nn=%d (supported 1..%d)", k_nn, MANET_MAX_KNN);
+    if (k_nn > 1 && compute != MANET_COMPUTE_F32)
+        return manet_set_error(MANET_E_INVALID, "k_nn > 1 needs MANET_COMPUTE_F32");
     if (compute != MANET_COMPUTE_F32)
         return manet_set_error(MANET_E_INVALID, "compute=%d not supported yet (only MANET_COMPUTE_F32)", compute);
     return MANET_OK;
 }
 
-template <int KS>
+template <int KS, int KNN>
 void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S,
-                     long N_pad, unsigned *keys, hipStream_t st)
+                     long N_pad, unsigned *keys, float *topk, hipStream_t st)
 {
     size_t lds = 2 * bank_tile_bytes((KS + 3) / 4);
     // per call (cheap, host side): the attribute is per device and the library keeps no state
-    (void)hipFuncSetAttribute((const void *)global_match_f32_kernel<KS>,
+    (void)hipFuncSetAttribute((const void *)global_match_f32_kernel<KS, KNN>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     manet_profile_record(st, true);
-    hipLaunchKernelGGL(global_match_f32_kernel<KS>, dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack,
-                       bpack, meta, n_ids, nQT, S, N_pad, keys, manet_tune_get(MANET_TUNE_BLOCK_MAP, 0));
+    hipLaunchKernelGGL((global_match_f32_kernel<KS, KNN>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack,
+                       bpack, meta, n_ids, nQT, S, N_pad, keys, topk, manet_tune_get(MANET_TUNE_BLOCK_MAP, 0));
     manet_profile_record(st, false);
 }
 
@@ -501,7 +606,7 @@ int manet_match_workspace_bytes(int64_t N, int64_t M0, int C, int n_ids, int k_n
     if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
     int rc = check_common(N, M0, C, n_ids, k_nn, compute);
     if (rc) return rc;
-    *bytes = match_layout(N, C, n_ids).total;
+    *bytes = match_layout(N, C, n_ids, k_nn).total;
     return MANET_OK;
 }
 
@@ -511,7 +616,7 @@ int manet_global_match_workspace_bytes(int64_t N, int64_t M0, int C, int n_ids, 
     if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
     int rc = check_common(N, M0, C, n_ids, k_nn, compute);
     if (rc) return rc;
-    *bytes = bank_layout(M0, C, n_ids).total + match_layout(N, C, n_ids).total;
+    *bytes = bank_layout(M0, C, n_ids).total + match_layout(N, C, n_ids, k_nn).total;
     return MANET_OK;
 }
 
@@ -558,7 +663,7 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
     if (rc) return rc;
     if (!query || !bank_ws || !out || !match_ws) return manet_set_error(MANET_E_INVALID, "null pointer");
     BankLayout BL = bank_layout(M0, C, n_ids);
-    MatchLayout ML = match_layout(N, C, n_ids);
+    MatchLayout ML = match_layout(N, C, n_ids, k_nn);
     if (match_ws_bytes < ML.total)
         return manet_set_error(MANET_E_WORKSPACE, "match workspace %zu < %zu bytes", match_ws_bytes, ML.total);
     hipStream_t st = (hipStream_t)stream;
@@ -578,17 +683,35 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
         int forced = manet_tune_get(MANET_TUNE_SPLITS, 0);  // tuning only
         if (forced > 0) S = (forced + 7) / 8 * 8;
     }
+    if (k_nn > 1) S = TOPK_SPLITS;
     const char *qpack = mws + ML.off_q;
     const char *bpack = bws + BL.off_pack;
-    switch (pick_ks(C)) {
-    case 16: launch_main_f32<16>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); break;
-    case 50: launch_main_f32<50>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); break;
-    case 52: launch_main_f32<52>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); break;
-    default: launch_main_f32<64>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); break;
+    float *topk = (float *)(mws + ML.off_topk);
+    if (k_nn > 1) {
+        // splits that own no tile never write their lists: start from "no candidate"
+        size_t words = (size_t)TOPK_SPLITS * n_ids * ML.N_pad * MANET_MAX_KNN;
+        (void)hipMemsetAsync(topk, 0x7f, words * sizeof(float), st);  // 0x7f7f7f7f = 3.39e38 >= 1e20: invalid
     }
+#define MANET_GM_CASE(KS_)                                                                                    \
+    case KS_:                                                                                                 \
+        if (k_nn == 1) launch_main_f32<KS_, 1>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st); \
+        else launch_main_f32<KS_, MANET_MAX_KNN>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st); \
+        break;
+    switch (pick_ks(C)) {
+        MANET_GM_CASE(16) MANET_GM_CASE(50) MANET_GM_CASE(52)
+    default:
+        if (k_nn == 1) launch_main_f32<64, 1>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st);
+        else launch_main_f32<64, MANET_MAX_KNN>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st);
+        break;
+    }
+#undef MANET_GM_CASE
     long total = (long)N * n_ids;
-    hipLaunchKernelGGL(global_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       (const unsigned *)keys, (long)N, ML.N_pad, n_ids, epilogue_flags, out, mem_inout);
+    if (k_nn == 1)
+        hipLaunchKernelGGL(global_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           (const unsigned *)keys, (long)N, ML.N_pad, n_ids, epilogue_flags, out, mem_inout);
+    else
+        hipLaunchKernelGGL(global_finish_topk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           (const float *)topk, S, k_nn, (long)N, ML.N_pad, n_ids, epilogue_flags, out, mem_inout);
     return manet_check_launch("manet_global_match_prepared");
 }
 
@@ -601,7 +724,7 @@ int manet_global_match(const float *query, int64_t q_stride_n, int64_t q_stride_
     if (rc) return rc;
     if (!workspace) return manet_set_error(MANET_E_INVALID, "workspace == NULL");
     size_t bbytes = bank_layout(M0, C, n_ids).total;
-    size_t mbytes = match_layout(N, C, n_ids).total;
+    size_t mbytes = match_layout(N, C, n_ids, k_nn).total;
     if (workspace_bytes < bbytes + mbytes)
         return manet_set_error(MANET_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, bbytes + mbytes);
     char *ws = (char *)workspace;

@@ -71,6 +71,8 @@ def global_match(reference_embeddings, query_embeddings, reference_labels, n_ids
     lab = _labels(reference_labels, "reference_labels")
     if lab.numel() != M0:
         raise ValueError("reference_labels has %d entries for %d reference pixels" % (lab.numel(), M0))
+    if k_nearest_neighbors > 1 and M0 < k_nearest_neighbors:
+        raise RuntimeError("selected index k out of range")  # what torch.topk raises (IntVOS.py:87)
     dev = qry.device
     cmp_ = COMPUTE[compute]
     nbytes = ctypes.c_size_t(0)
@@ -125,6 +127,8 @@ class PreparedBank:
         qry, N, C = _flat(query_embeddings, "query_embeddings")
         if C != self.C:
             raise ValueError("embedding_dim mismatch: %d vs %d" % (C, self.C))
+        if k_nearest_neighbors > 1 and self.M0 < k_nearest_neighbors:
+            raise RuntimeError("selected index k out of range")
         dev = qry.device
         nbytes = ctypes.c_size_t(0)
         _lib.check(lib.manet_match_workspace_bytes(N, self.M0, C, self.n_ids, k_nearest_neighbors,

@@ -119,6 +119,34 @@ def test_edge_cases(ops, oracle):
     assert np.all(out.cpu().numpy() == np.float32(1e20))
 
 
+@pytest.mark.parametrize("tm", [1, 0])
+def test_topk_golden_reference_vectors(ops, tm):
+    """k_nearest_neighbors = 3 (IntVOS.py:87-94).  TEST_MODE only changes which rows exist."""
+    g = load_golden("global_k3_tm%d" % tm)
+    n_ids = int(g["gt_ids"]) + 1
+    ref, lab = chw_view(g["ref_chw"]).reshape(-1, 16), dev(g["labels"]).reshape(-1)
+    if tm:  # the drop-in module filters unlabelled rows first (IntVOS.py:135-136)
+        keep = lab != -1
+        ref, lab = ref[keep], lab[keep]
+    out = ops.global_match(ref, chw_view(g["qry_chw"]), lab, n_ids, k_nearest_neighbors=3)
+    np.testing.assert_allclose(out.cpu().numpy().reshape(g["out"].shape), g["out"], rtol=RTOL_REF, atol=ATOL_REF)
+
+
+@pytest.mark.parametrize("k", [2, 5, 8])
+def test_topk_vs_oracle(ops, oracle, k):
+    q, kk, lab = _case(31 + k, 30, 41, 60, 41, 100, 4, unlabeled_frac=0.2)
+    lab[lab == 3] = -1
+    lab[0, 0:3, 0] = 3  # object 3 has only 3 rows: fewer than k for k = 5, 8 -> pad rule
+    out = ops.global_match(chw_view(kk), chw_view(q), dev(lab), 5, k_nearest_neighbors=k).cpu().numpy()
+    want = oracle.global_match(np.transpose(kk, (1, 2, 0)), np.transpose(q, (1, 2, 0)), lab, k, n_ids=5,
+                               test_mode=False).reshape(-1, 5)
+    assert np.all(want[:, 4] == 0.0)  # absent object: all invalid -> pad 0 -> mean 0
+    np.testing.assert_allclose(out, want, rtol=1e-6, atol=1e-7)  # same distances, mean in the same order
+    with pytest.raises(RuntimeError, match="out of range"):
+        ops.global_match(chw_view(kk).reshape(-1, 100)[:k - 1], chw_view(q), dev(lab).reshape(-1)[:k - 1], 5,
+                         k_nearest_neighbors=k)
+
+
 def test_prepared_bank_equals_one_shot(ops):
     q, k, lab = _case(21, 30, 40, 60, 40, 100, 3)
     one = ops.global_match(chw_view(k), chw_view(q), dev(lab), 3)
