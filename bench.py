@@ -97,6 +97,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", type=str, default="", help="experiments only: key=value,... for manet_tune_set")
+    ap.add_argument("--compute", type=str, default="f32", choices=["f32", "bf16", "bf16x3"],
+                    help="arithmetic of the QK^T contraction (headline = f32, BASELINE configs[1])")
+    ap.add_argument("--cfg", type=int, default=2, choices=[2, 3, 5],
+                    help="BASELINE config: 2 = 480p T=5 2 ids d=12 (headline); 3 = 480p T=5 4 ids d=4; "
+                         "5 = 720p T=10 6 ids d=4")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,10 +131,17 @@ def main():
         k_, v_ = kv.split("=")
         _lib.check(lib.manet_tune_set(int(k_), int(v_)), "manet_tune_set")
 
+    global H, W, T_BANK, N_IDS, LOCAL_D
+    if args.cfg == 3:
+        N_IDS, LOCAL_D = 4, 4
+    elif args.cfg == 5:
+        H, W, T_BANK, N_IDS, LOCAL_D = 180, 320, 10, 6, 4
+    peak = FP32_MFMA_PEAK_TFLOPS if args.compute == "f32" else 2500.0  # dense bf16 MFMA peak (guide)
     K, Wm = args.steps, args.warmup
     gen = torch.Generator(device=device).manual_seed(20200614 + 2 + 1000 * rank)
     # this rank's K frames of the clip (synthetic embeddings, resident in HBM) + 1 warm-up halo
-    n_local = K
+    # (the clip is at least long enough to contain T_BANK distinct annotated frames; only K are timed)
+    n_local = max(K, -(-T_BANK // world))
     frames = [synth_frame(gen, device) for _ in range(min(n_local, 8))]  # cycled: 8 x 10.3 MB
     local_emb = torch.stack(frames)  # [f, C, H, W]
     F_total = world * n_local
@@ -182,7 +194,7 @@ def main():
         cur = frame_emb(i)
         prev = frame_emb(i - 1) if i > 0 else (halo if halo is not None else frame_emb(0))
         g = ops.global_match(bank_rows, cur.permute(1, 2, 0), bank_lab, N_IDS, normalize=True,
-                             mem=gmap[i % 104])
+                             mem=gmap[i % 104], compute=args.compute)
         l = ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), prev_labs[i % 8], N_IDS, LOCAL_D)
         return g, l
 
@@ -218,7 +230,8 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        N, M = H * W, T_BANK * H * W
+        N, M = H * W, int(bank_rows.shape[0])
+        assert M == T_BANK * H * W, "bank must hold T_BANK distinct frames"
         flops = 2.0 * N * M * C  # algorithmic flops of one launch
         achieved = flops / (kern_ms * 1e-3) / 1e12
         traffic = None
@@ -239,17 +252,19 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.compute,
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 480p grid %dx%d, C=%d, %d-frame fully-labelled bank "
-                                   "(M=%d), %d ids, fp32; step = global match + fused normalise/min-merge + "
+            "config": {"workload": "BASELINE configs[%d]: grid %dx%d, C=%d, %d-frame fully-labelled bank "
+                                   "(M=%d), %d ids, %s; step = global match + fused normalise/min-merge + "
                                    "local match d=%d; one-shot API (bank re-packed every frame)"
-                                   % (H, W, C, T_BANK, M, N_IDS, LOCAL_D),
+                                   % (args.cfg - 1, H, W, C, T_BANK, M, N_IDS, args.compute, LOCAL_D),
                        "frames_per_gpu": K, "bank_exchange": "1 RCCL all-gather in the timed region" if world > 1
                        else "none (1 GPU)"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "global_match_f32_kernel<50>", "kernel_ms": kern_ms,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic if (args.compute == "f32" and args.cfg == 2) else None,
+                         "kernel": "global_match_f32_kernel<50,1>" if args.compute == "f32" else
+                                   "global_match_bf16_kernel<7,%s>" % ("true" if args.compute == "bf16x3" else "false"),
+                         "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": flops},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -39,16 +39,20 @@ constexpr int META_T = 0;          // [0]        number of bank tiles actually u
 constexpr int META_SEG = 1;        // [1..65]    first tile of object o (entry n_ids = T)
 constexpr int META_CNT = 130;      // [130..193] rows per object
 
-__host__ __device__ constexpr int ng_of(int C) { return (C + 7) / 8; }
-// bank tile: NG x [2 parities][64 rows][4 k] floats, then 64 |k|^2, padded to whole 1 KiB pieces
-__host__ __device__ constexpr size_t bank_tile_bytes(int NG)
+// Packed operand image of one row block: `units` 16-byte units per row, stored [unit][row][16 B],
+// then the rows' squared norms (fp32).
+//   f32    unit u = 2g+h holds k = 8g + 2j + h, j = 0..3 (4 floats)      -> v_mfma_f32_32x32x2_f32
+//   bf16   unit u = 2s+h holds k = 16s + 8h + e, e = 0..7 (8 bf16)        -> v_mfma_f32_32x32x16_bf16
+//   bf16x3 the bf16 image of hi = bf16(x), then the image of lo = bf16(x - hi)
+__host__ __device__ constexpr size_t bank_tile_bytes_u(int units)
 {
-    return ((size_t)NG * 2 * BT * 4 * 4 + BT * 4 + 1023) / 1024 * 1024;
+    return ((size_t)units * BT * 16 + BT * 4 + 1023) / 1024 * 1024;  // whole 1 KiB global_load_lds pieces
 }
-// query block: NG x [2][32][4] floats, then 32 |q|^2
-__host__ __device__ constexpr size_t query_block_bytes(int NG) { return (size_t)NG * 2 * QB * 4 * 4 + QB * 4; }
+__host__ __device__ constexpr size_t query_block_bytes_u(int units) { return (size_t)units * QB * 16 + QB * 4; }
+__host__ __device__ constexpr size_t bank_tile_bytes(int NG) { return bank_tile_bytes_u(2 * NG); }
+__host__ __device__ constexpr size_t query_block_bytes(int NG) { return query_block_bytes_u(2 * NG); }
 
-// number of v_mfma_f32_32x32x2 k-steps (2 k each) the kernel is instantiated for; NG = k-groups of 8
+// number of v_mfma_f32_32x32x2 k-steps (2 k each) the f32 kernel is instantiated for
 int pick_ks(int C)
 {
     if (C <= 32) return 16;
@@ -56,21 +60,57 @@ int pick_ks(int C)
     if (C <= 104) return 52;
     return 64;
 }
-int pick_ng(int C) { return (pick_ks(C) + 3) / 4; }
+// number of v_mfma_f32_32x32x16_bf16 k-steps (16 k each) the bf16 kernels are instantiated for
+int pick_ksb(int C)
+{
+    if (C <= 32) return 2;
+    if (C <= 112) return 7;
+    return 8;
+}
+
+struct Geom {
+    int compute;
+    int steps;   // MFMA k-steps of the instantiation
+    int units;   // 16-byte units per row of the packed image
+    int kpad;    // k extent covered by the image
+    int qt;      // queries per workgroup
+    size_t tile_bytes, qblk_bytes;
+};
+
+Geom geom_of(int C, int compute)
+{
+    Geom G;
+    G.compute = compute;
+    if (compute == MANET_COMPUTE_F32) {
+        G.steps = pick_ks(C);
+        int NG = (G.steps + 3) / 4;
+        G.units = 2 * NG;
+        G.kpad = 8 * NG;
+        G.qt = QT;
+    } else {
+        G.steps = pick_ksb(C);
+        G.units = 2 * G.steps * (compute == MANET_COMPUTE_BF16X3 ? 2 : 1);
+        G.kpad = 16 * G.steps;
+        G.qt = 512;  // 8 waves: the bf16 MFMA eats a bank tile 14x faster, so share it between more queries
+    }
+    G.tile_bytes = bank_tile_bytes_u(G.units);
+    G.qblk_bytes = query_block_bytes_u(G.units);
+    return G;
+}
 
 struct BankLayout {
-    int NG;
+    Geom G;
     size_t tile_bytes;
     long T_max;  // upper bound on tiles: every object wastes < 1 tile
     long nblocks;  // pre-pass blocks of RPB rows
     size_t off_meta, off_hist, off_src, off_pack, total;
 };
 
-BankLayout bank_layout(int64_t M0, int C, int n_ids)
+BankLayout bank_layout(int64_t M0, int C, int n_ids, int compute)
 {
     BankLayout L;
-    L.NG = pick_ng(C);
-    L.tile_bytes = bank_tile_bytes(L.NG);
+    L.G = geom_of(C, compute);
+    L.tile_bytes = L.G.tile_bytes;
     L.T_max = (long)((M0 + BT - 1) / BT) + n_ids;
     L.nblocks = (long)((M0 + 255) / 256);
     L.off_meta = 0;
@@ -82,7 +122,7 @@ BankLayout bank_layout(int64_t M0, int C, int n_ids)
 }
 
 struct MatchLayout {
-    int NG;
+    Geom G;
     long N_pad;
     int nQT;
     size_t qblk_bytes, off_q, off_keys, off_topk, total;
@@ -90,13 +130,13 @@ struct MatchLayout {
 
 constexpr int TOPK_SPLITS = 16;  // the top-k path trades a little tail balance for a bounded workspace
 
-MatchLayout match_layout(int64_t N, int C, int n_ids, int k_nn = 1)
+MatchLayout match_layout(int64_t N, int C, int n_ids, int compute, int k_nn = 1)
 {
     MatchLayout L;
-    L.NG = pick_ng(C);
-    L.nQT = (int)((N + QT - 1) / QT);
-    L.N_pad = (long)L.nQT * QT;
-    L.qblk_bytes = query_block_bytes(L.NG);
+    L.G = geom_of(C, compute);
+    L.nQT = (int)((N + L.G.qt - 1) / L.G.qt);
+    L.N_pad = (long)L.nQT * L.G.qt;
+    L.qblk_bytes = L.G.qblk_bytes;
     L.off_q = 0;
     L.off_keys = manet_align_up((size_t)(L.N_pad / QB) * L.qblk_bytes, 256);
     L.off_topk = manet_align_up(L.off_keys + (size_t)n_ids * L.N_pad * sizeof(unsigned), 1024);
@@ -217,22 +257,33 @@ __global__ __launch_bounds__(RPB) void label_scatter_kernel(const int *__restric
     }
 }
 
-// bank (ROWS = 64) and query (ROWS = 32) pack: rows -> MFMA operand image
-//   out[tile] = [g][h][row][j] floats with k = 8g + 2j + h (zero beyond C), then |row|^2[ROWS]
+// fp32 -> bf16, round to nearest even (NaN stays quiet NaN); same bits as the oracle's bf16_round
+__device__ __forceinline__ unsigned f2bf(float x)
+{
+    unsigned u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf2f(unsigned b) { return __uint_as_float(b << 16); }
+
+// bank (ROWS = 64) and query (ROWS = 32) pack: rows -> MFMA operand image (see Geom), then |row|^2.
 // Rows are staged through LDS so that both the global reads (along k for row-major sources, along
-// rows for C-major sources) and the 16-byte image writes are coalesced.  |row|^2 is the
-// k-ascending fmaf chain of the oracle (IntVOS.py:32,35).
+// rows for C-major sources) and the 16-byte image writes are coalesced.  |row|^2 is the k-ascending
+// fmaf chain of the oracle (IntVOS.py:32,35) -- over the bf16-rounded values in MANET_COMPUTE_BF16
+// (the path then IS the reference formula on rounded embeddings), over the fp32 values otherwise.
 template <int ROWS>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict__ src, long s_row,
                                                         long s_c, const int *__restrict__ src_of,
                                                         const int *__restrict__ meta, long n_rows,
-                                                        int C, int NG, char *__restrict__ dst,
-                                                        long tile_bytes, float pad_norm)
+                                                        int C, int compute, int units, int kpad,
+                                                        char *__restrict__ dst, long tile_bytes,
+                                                        float pad_norm)
 {
     const long tile = blockIdx.x;
     if (meta && tile >= meta[META_T]) return;
     extern __shared__ __attribute__((aligned(16))) char pack_smem[];
-    const int KP = 8 * NG + 1;  // odd row stride: column reads are conflict-free
+    const int KP = kpad + 1;  // odd row stride: column reads are conflict-free
     float *rows = (float *)pack_smem;                  // [ROWS][KP]
     int *s_src = (int *)(rows + (long)ROWS * KP);      // [ROWS]
     const int tid = threadIdx.x;
@@ -254,27 +305,55 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict_
             rows[r * KP + k] = (sr >= 0) ? src[(long)sr * s_row + (long)k * s_c] : 0.0f;
         }
     }
-    for (int idx = tid; idx < ROWS * (8 * NG - C); idx += 256) {
-        int r = idx / (8 * NG - C), k = C + idx - r * (8 * NG - C);
+    for (int idx = tid; idx < ROWS * (kpad - C); idx += 256) {
+        int r = idx / (kpad - C), k = C + idx - r * (kpad - C);
         rows[r * KP + k] = 0.0f;
     }
     __syncthreads();
-    float *out = (float *)(dst + tile * tile_bytes);
-    for (int item = tid; item < NG * 2 * ROWS; item += 256) {
-        int r = item % ROWS, gh = item / ROWS;
-        int g = gh >> 1, h = gh & 1;
-        const float *row = rows + r * KP + 8 * g + h;
-        f32x4 v = {row[0], row[2], row[4], row[6]};
-        *(f32x4 *)(out + ((long)gh * ROWS + r) * 4) = v;
+    char *out = dst + tile * tile_bytes;
+    if (compute == MANET_COMPUTE_F32) {
+        for (int item = tid; item < units * ROWS; item += 256) {
+            int r = item % ROWS, u = item / ROWS;
+            const float *row = rows + r * KP + 8 * (u >> 1) + (u & 1);
+            f32x4 v = {row[0], row[2], row[4], row[6]};
+            *(f32x4 *)(out + ((long)u * ROWS + r) * 16) = v;
+        }
+    } else {
+        const int hi_units = (compute == MANET_COMPUTE_BF16X3) ? units / 2 : units;
+        for (int item = tid; item < units * ROWS; item += 256) {
+            int r = item % ROWS, u = item / ROWS;
+            const bool lo = u >= hi_units;
+            const int uu = lo ? u - hi_units : u;
+            const float *row = rows + r * KP + 16 * (uu >> 1) + 8 * (uu & 1);
+            unsigned w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x0 = row[2 * e], x1 = row[2 * e + 1];
+                unsigned b0 = f2bf(x0), b1 = f2bf(x1);
+                if (lo) {
+                    b0 = f2bf(x0 - bf2f(b0));
+                    b1 = f2bf(x1 - bf2f(b1));
+                }
+                w[e] = b0 | (b1 << 16);
+            }
+            *(uint4 *)(out + ((long)u * ROWS + r) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
     }
     if (tid < ROWS) {
         float n = pad_norm;
         if (s_src[tid] >= 0) {
             n = 0.0f;
             const float *row = rows + tid * KP;
-            for (int k = 0; k < C; ++k) n = fmaf(row[k], row[k], n);
+            if (compute == MANET_COMPUTE_BF16) {
+                for (int k = 0; k < C; ++k) {
+                    float x = bf2f(f2bf(row[k]));
+                    n = fmaf(x, x, n);
+                }
+            } else {
+                for (int k = 0; k < C; ++k) n = fmaf(row[k], row[k], n);
+            }
         }
-        out[(long)NG * 2 * ROWS * 4 + tid] = n;
+        *(float *)(out + (long)units * ROWS * 16 + tid * 4) = n;
     }
 }
 
@@ -478,6 +557,149 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
     flush(o);
 }
 
+// ---------------------------------------------------------------------------------------------
+// main kernel, bf16 operands (MANET_COMPUTE_BF16 / _BF16X3): one workgroup = 512 queries x one bank
+// split, 8 waves.  Same structure as the f32 kernel (swapped operands, object-pure 64-row tiles,
+// lane-local running min, double-buffered global_load_lds staging, atomicMin across splits); the
+// contraction is v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+//   X3 = false: one MFMA per 16 k on embeddings rounded to bf16 (7 instead of 50 MFMAs per block at C=100)
+//   X3 = true : hi*hi + hi*lo + lo*hi with x = hi + lo, hi = bf16(x), lo = bf16(x - hi): the dropped
+//               lo*lo term is <= 2^-16 relative, i.e. fp32-class distances at 3/16 of the f32 MFMA cost.
+template <int KSB, bool X3>
+__global__ __launch_bounds__(512) void global_match_bf16_kernel(const char *__restrict__ qpack,
+                                                                const char *__restrict__ bpack,
+                                                                const int *__restrict__ meta, int n_ids,
+                                                                int nQT, int S, long N_pad,
+                                                                unsigned *__restrict__ keys, int block_map)
+{
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    constexpr int UNITS = 2 * KSB * (X3 ? 2 : 1);
+    constexpr int LO = 2 * KSB;  // first unit of the lo image
+    constexpr size_t TILE_BYTES = bank_tile_bytes_u(UNITS);
+    constexpr int PIECES = (int)(TILE_BYTES / 1024);
+    constexpr size_t QBLK_BYTES = query_block_bytes_u(UNITS);
+    constexpr int QTB = 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x TILE_BYTES
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    const int b = blockIdx.x;
+    int qt, s;
+    if (block_map == 0) {
+        const int xcd = b & 7;
+        const int idx = b >> 3;
+        qt = idx % nQT;
+        s = xcd + 8 * (idx / nQT);
+    } else {
+        qt = b % nQT;
+        s = b / nQT;
+    }
+    const int T = meta[META_T];
+    const int t0 = (int)((long)s * T / S);
+    const int t1 = (int)((long)(s + 1) * T / S);
+    if (t0 >= t1) return;
+
+    auto stage = [&](int t, int buf) {
+        const char *g = bpack + (size_t)t * TILE_BYTES + (size_t)lane * 16;
+        char *l = smem + (size_t)buf * TILE_BYTES;
+#pragma unroll
+        for (int p = 0; p < (PIECES + 7) / 8; ++p) {
+            int piece = p * 8 + wave;
+            if (piece < PIECES)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(g + (size_t)piece * 1024),
+                    (__attribute__((address_space(3))) void *)(l + (size_t)piece * 1024), 16, 0, 0);
+        }
+    };
+    stage(t0, 0);
+
+    // B operand: lane holds q[j = lane&31][k = 16s + 8*(lane>>5) + 0..7] for its two query blocks
+    uint4 q0[KSB], q1[KSB], q0l[X3 ? KSB : 1], q1l[X3 ? KSB : 1];
+    float xs0, xs1;
+    {
+        const char *qb0 = qpack + (size_t)(qt * (QTB / QB) + wave * 2) * QBLK_BYTES;
+        const char *qb1 = qb0 + QBLK_BYTES;
+#pragma unroll
+        for (int k = 0; k < KSB; ++k) {
+            q0[k] = *(const uint4 *)(qb0 + ((size_t)(k * 2 + h) * QB + l31) * 16);
+            q1[k] = *(const uint4 *)(qb1 + ((size_t)(k * 2 + h) * QB + l31) * 16);
+            if (X3) {
+                q0l[k] = *(const uint4 *)(qb0 + ((size_t)(LO + k * 2 + h) * QB + l31) * 16);
+                q1l[k] = *(const uint4 *)(qb1 + ((size_t)(LO + k * 2 + h) * QB + l31) * 16);
+            }
+        }
+        xs0 = *(const float *)(qb0 + (size_t)UNITS * QB * 16 + l31 * 4);
+        xs1 = *(const float *)(qb1 + (size_t)UNITS * QB * 16 + l31 * 4);
+    }
+    const long qbase = (long)qt * QTB + wave * 64 + l31;
+
+    int o = 0;
+    while (meta[META_SEG + o + 1] <= t0) ++o;
+    int seg_end = meta[META_SEG + o + 1];
+    float m0 = MANET_WRONG_LABEL_PADDING_DISTANCE, m1 = MANET_WRONG_LABEL_PADDING_DISTANCE;
+    auto flush = [&](int obj) {
+        float a = fminf(m0, __shfl_xor(m0, 32));
+        float c = fminf(m1, __shfl_xor(m1, 32));
+        if (h == 0) {
+            atomicMin(keys + (size_t)obj * N_pad + qbase, key_of(a));
+            atomicMin(keys + (size_t)obj * N_pad + qbase + 32, key_of(c));
+        }
+    };
+#define MANET_BF(x) __builtin_bit_cast(bf16x8_t, x)
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        __syncthreads();
+        if (t + 1 < t1) stage(t + 1, buf ^ 1);
+        if (t >= seg_end) {
+            flush(o);
+            m0 = m1 = MANET_WRONG_LABEL_PADDING_DISTANCE;
+            do { ++o; seg_end = meta[META_SEG + o + 1]; } while (t >= seg_end);
+        }
+        const char *tb = smem + (size_t)buf * TILE_BYTES;
+        const uint4 *A = (const uint4 *)tb;
+        f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+#pragma unroll
+        for (int k = 0; k < KSB; ++k) {
+            uint4 a0 = A[(k * 2 + h) * BT + l31];
+            uint4 a1 = A[(k * 2 + h) * BT + 32 + l31];
+            c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q0[k]), c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q1[k]), c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q0[k]), c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q1[k]), c11, 0, 0, 0);
+            if (X3) {
+                uint4 a0l = A[(LO + k * 2 + h) * BT + l31];
+                uint4 a1l = A[(LO + k * 2 + h) * BT + 32 + l31];
+                c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q0l[k]), c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q1l[k]), c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q0l[k]), c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q1l[k]), c11, 0, 0, 0);
+                c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0l), MANET_BF(q0[k]), c00, 0, 0, 0);
+                c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0l), MANET_BF(q1[k]), c01, 0, 0, 0);
+                c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1l), MANET_BF(q0[k]), c10, 0, 0, 0);
+                c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1l), MANET_BF(q1[k]), c11, 0, 0, 0);
+            }
+        }
+        const float *ysl = (const float *)(tb + (size_t)UNITS * BT * 16);
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            f32x4 y0 = *(const f32x4 *)(ysl + 8 * tq + 4 * h);
+            f32x4 y1 = *(const f32x4 *)(ysl + 32 + 8 * tq + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * tq + i;
+                m0 = fminf(m0, fminf(fmaf(-2.0f, c00[r], xs0 + y0[i]), fmaf(-2.0f, c10[r], xs0 + y1[i])));
+                m1 = fminf(m1, fminf(fmaf(-2.0f, c01[r], xs1 + y0[i]), fmaf(-2.0f, c11[r], xs1 + y1[i])));
+            }
+        }
+    }
+#undef MANET_BF
+    flush(o);
+}
+
 // decode + (sigmoid-0.5)*2 (IntVOS.py:611-612) + min-merge with the stored map (IntVOS.py:620-622)
 __global__ void global_finish_kernel(const unsigned *__restrict__ keys, long N, long N_pad, int n_ids,
                                      int flags, float *__restrict__ out, float *__restrict__ mem)
@@ -568,8 +790,8 @@ int check_common(int64_t N, int64_t M0, int C, int n_ids, int k_nn, int compute)
         return manet_set_error(MANET_E_INVALID, "k_nn=%d (supported 1..%d)", k_nn, MANET_MAX_KNN);
     if (k_nn > 1 && compute != MANET_COMPUTE_F32)
         return manet_set_error(MANET_E_INVALID, "k_nn > 1 needs MANET_COMPUTE_F32");
-    if (compute != MANET_COMPUTE_F32)
-        return manet_set_error(MANET_E_INVALID, "compute=%d not supported yet (only MANET_COMPUTE_F32)", compute);
+    if (compute != MANET_COMPUTE_F32 && compute != MANET_COMPUTE_BF16 && compute != MANET_COMPUTE_BF16X3)
+        return manet_set_error(MANET_E_INVALID, "compute=%d (MANET_COMPUTE_F32 / _BF16 / _BF16X3)", compute);
     return MANET_OK;
 }
 
@@ -587,6 +809,19 @@ void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int 
     manet_profile_record(st, false);
 }
 
+template <int KSB, bool X3>
+void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S, long N_pad,
+                      unsigned *keys, hipStream_t st)
+{
+    size_t lds = 2 * bank_tile_bytes_u(2 * KSB * (X3 ? 2 : 1));
+    (void)hipFuncSetAttribute((const void *)global_match_bf16_kernel<KSB, X3>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    manet_profile_record(st, true);
+    hipLaunchKernelGGL((global_match_bf16_kernel<KSB, X3>), dim3((unsigned)(nQT * S)), dim3(512), lds, st, qpack, bpack,
+                       meta, n_ids, nQT, S, N_pad, keys, manet_tune_get(MANET_TUNE_BLOCK_MAP, 0));
+    manet_profile_record(st, false);
+}
+
 }  // namespace
 
 extern "C" {
@@ -596,7 +831,7 @@ int manet_bank_workspace_bytes(int64_t M0, int C, int n_ids, int compute, size_t
     if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
     int rc = check_common(1, M0, C, n_ids, 1, compute);
     if (rc) return rc;
-    *bytes = bank_layout(M0, C, n_ids).total;
+    *bytes = bank_layout(M0, C, n_ids, compute).total;
     return MANET_OK;
 }
 
@@ -606,7 +841,7 @@ int manet_match_workspace_bytes(int64_t N, int64_t M0, int C, int n_ids, int k_n
     if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
     int rc = check_common(N, M0, C, n_ids, k_nn, compute);
     if (rc) return rc;
-    *bytes = match_layout(N, C, n_ids, k_nn).total;
+    *bytes = match_layout(N, C, n_ids, compute, k_nn).total;
     return MANET_OK;
 }
 
@@ -616,7 +851,7 @@ int manet_global_match_workspace_bytes(int64_t N, int64_t M0, int C, int n_ids, 
     if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
     int rc = check_common(N, M0, C, n_ids, k_nn, compute);
     if (rc) return rc;
-    *bytes = bank_layout(M0, C, n_ids).total + match_layout(N, C, n_ids, k_nn).total;
+    *bytes = bank_layout(M0, C, n_ids, compute).total + match_layout(N, C, n_ids, compute, k_nn).total;
     return MANET_OK;
 }
 
@@ -627,7 +862,7 @@ int manet_bank_prepare(const float *bank, int64_t b_stride_m, int64_t b_stride_c
     int rc = check_common(1, M0, C, n_ids, 1, compute);
     if (rc) return rc;
     if ((M0 > 0 && (!bank || !labels)) || !bank_ws) return manet_set_error(MANET_E_INVALID, "null pointer");
-    BankLayout L = bank_layout(M0, C, n_ids);
+    BankLayout L = bank_layout(M0, C, n_ids, compute);
     if (bank_ws_bytes < L.total)
         return manet_set_error(MANET_E_WORKSPACE, "bank workspace %zu < %zu bytes", bank_ws_bytes, L.total);
     hipStream_t st = (hipStream_t)stream;
@@ -646,10 +881,10 @@ int manet_bank_prepare(const float *bank, int64_t b_stride_m, int64_t b_stride_c
         hipLaunchKernelGGL(label_scatter_kernel, dim3((unsigned)L.nblocks), dim3(RPB), 0, st, labels, (long)M0, n_ids,
                            (const int *)hist, (const int *)meta, src_of);
     {
-        size_t lds = (size_t)BT * (8 * L.NG + 1) * sizeof(float) + BT * sizeof(int);
+        size_t lds = (size_t)BT * (L.G.kpad + 1) * sizeof(float) + BT * sizeof(int);
         hipLaunchKernelGGL(pack_rows_kernel<BT>, dim3((unsigned)L.T_max), dim3(256), lds, st, bank, (long)b_stride_m,
-                           (long)b_stride_c, (const int *)src_of, (const int *)meta, (long)M0, C, L.NG,
-                           ws + L.off_pack, (long)L.tile_bytes, MANET_WRONG_LABEL_PADDING_DISTANCE);
+                           (long)b_stride_c, (const int *)src_of, (const int *)meta, (long)M0, C, compute, L.G.units,
+                           L.G.kpad, ws + L.off_pack, (long)L.tile_bytes, MANET_WRONG_LABEL_PADDING_DISTANCE);
     }
     return manet_check_launch("manet_bank_prepare");
 }
@@ -662,8 +897,8 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
     int rc = check_common(N, M0, C, n_ids, k_nn, compute);
     if (rc) return rc;
     if (!query || !bank_ws || !out || !match_ws) return manet_set_error(MANET_E_INVALID, "null pointer");
-    BankLayout BL = bank_layout(M0, C, n_ids);
-    MatchLayout ML = match_layout(N, C, n_ids, k_nn);
+    BankLayout BL = bank_layout(M0, C, n_ids, compute);
+    MatchLayout ML = match_layout(N, C, n_ids, compute, k_nn);
     if (match_ws_bytes < ML.total)
         return manet_set_error(MANET_E_WORKSPACE, "match workspace %zu < %zu bytes", match_ws_bytes, ML.total);
     hipStream_t st = (hipStream_t)stream;
@@ -673,10 +908,10 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
     unsigned *keys = (unsigned *)(mws + ML.off_keys);
     (void)hipMemsetAsync(keys, 0xff, (size_t)n_ids * ML.N_pad * sizeof(unsigned), st);
     {
-        size_t lds = (size_t)QB * (8 * ML.NG + 1) * sizeof(float) + QB * sizeof(int);
+        size_t lds = (size_t)QB * (ML.G.kpad + 1) * sizeof(float) + QB * sizeof(int);
         hipLaunchKernelGGL(pack_rows_kernel<QB>, dim3((unsigned)(ML.N_pad / QB)), dim3(256), lds, st, query,
                            (long)q_stride_n, (long)q_stride_c, (const int *)nullptr, (const int *)nullptr, (long)N,
-                           C, ML.NG, mws + ML.off_q, (long)ML.qblk_bytes, 0.0f);
+                           C, compute, ML.G.units, ML.G.kpad, mws + ML.off_q, (long)ML.qblk_bytes, 0.0f);
     }
     int S = pick_splits(ML.nQT, BL.T_max);
     {
@@ -692,6 +927,22 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
         size_t words = (size_t)TOPK_SPLITS * n_ids * ML.N_pad * MANET_MAX_KNN;
         (void)hipMemsetAsync(topk, 0x7f, words * sizeof(float), st);  // 0x7f7f7f7f = 3.39e38 >= 1e20: invalid
     }
+    if (compute != MANET_COMPUTE_F32) {
+        const bool x3 = (compute == MANET_COMPUTE_BF16X3);
+#define MANET_GB_CASE(K_)                                                                              \
+    case K_:                                                                                           \
+        if (x3) launch_main_bf16<K_, true>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st);  \
+        else launch_main_bf16<K_, false>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st);    \
+        break;
+        switch (ML.G.steps) {
+            MANET_GB_CASE(2) MANET_GB_CASE(7)
+        default:
+            if (x3) launch_main_bf16<8, true>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st);
+            else launch_main_bf16<8, false>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st);
+            break;
+        }
+#undef MANET_GB_CASE
+    } else {
 #define MANET_GM_CASE(KS_)                                                                                    \
     case KS_:                                                                                                 \
         if (k_nn == 1) launch_main_f32<KS_, 1>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st); \
@@ -705,6 +956,7 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
         break;
     }
 #undef MANET_GM_CASE
+    }
     long total = (long)N * n_ids;
     if (k_nn == 1)
         hipLaunchKernelGGL(global_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
@@ -723,8 +975,8 @@ int manet_global_match(const float *query, int64_t q_stride_n, int64_t q_stride_
     int rc = check_common(N, M0, C, n_ids, k_nn, compute);
     if (rc) return rc;
     if (!workspace) return manet_set_error(MANET_E_INVALID, "workspace == NULL");
-    size_t bbytes = bank_layout(M0, C, n_ids).total;
-    size_t mbytes = match_layout(N, C, n_ids, k_nn).total;
+    size_t bbytes = bank_layout(M0, C, n_ids, compute).total;
+    size_t mbytes = match_layout(N, C, n_ids, compute, k_nn).total;
     if (workspace_bytes < bbytes + mbytes)
         return manet_set_error(MANET_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, bbytes + mbytes);
     char *ws = (char *)workspace;

@@ -147,6 +147,92 @@ def test_topk_vs_oracle(ops, oracle, k):
                          k_nearest_neighbors=k)
 
 
+# ---- bf16 modes (BASELINE cfg3 / cfg5 arithmetic) -----------------------------------------------------
+# MANET_COMPUTE_BF16: the reference formula evaluated on embeddings rounded to bf16 (norms included),
+# products exact in fp32, fp32 accumulation inside v_mfma_f32_32x32x16_bf16 in an order that is not a
+# plain chain -> compared with the oracle's quant_bf16 mode to accumulation-order rounding.
+BF16_RTOL, BF16_ATOL = 1e-5, 3e-6
+# MANET_COMPUTE_BF16X3 (hi/lo split, 3 MFMAs): must meet north_star's fp32 bar against the UNQUANTISED
+# oracle: 1e-3 relative.  Measured worst case is ~1e-5 of |q|^2+|k|^2, asserted 10x tighter than the bar.
+X3_RTOL, X3_ATOL = 1e-4, 3e-6
+
+
+@pytest.mark.parametrize("shape", [
+    (41, 7, 9, 7, 9, 100, 2),
+    (42, 30, 53, 30, 53, 100, 4),     # cfg3-like: 4 ids
+    (43, 40, 64, 80, 64, 100, 6),     # cfg5-like: 6 ids, stacked bank
+    (44, 16, 16, 16, 16, 128, 3),
+    (45, 12, 10, 12, 10, 20, 2),
+])
+def test_bf16_vs_quantised_oracle(ops, oracle, shape):
+    seed, h, w, hr, wr, C, n_ids = shape
+    q, k, lab = _case(seed, h, w, hr, wr, C, n_ids)
+    out = ops.global_match(chw_view(k), chw_view(q), dev(lab), n_ids, compute="bf16").cpu().numpy()
+    want = oracle.global_match(np.transpose(k, (1, 2, 0)), np.transpose(q, (1, 2, 0)), lab, 1, n_ids=n_ids,
+                               quant_bf16=True).reshape(-1, n_ids)
+    np.testing.assert_allclose(out, want, rtol=BF16_RTOL, atol=BF16_ATOL)
+    # and it is the plain fp32 result of the rounded embeddings (bit-exact kernel vs itself is not
+    # implied; same tolerance)
+    qr, kr = oracle.bf16_round(q), oracle.bf16_round(k)
+    out32 = ops.global_match(chw_view(kr), chw_view(qr), dev(lab), n_ids, compute="f32").cpu().numpy()
+    np.testing.assert_allclose(out, out32, rtol=BF16_RTOL, atol=BF16_ATOL)
+
+
+@pytest.mark.parametrize("shape", [
+    (51, 7, 9, 7, 9, 100, 2),
+    (52, 30, 53, 30, 53, 100, 4),
+    (53, 40, 64, 80, 64, 100, 6),
+    (54, 16, 16, 16, 16, 128, 3),
+])
+def test_bf16x3_meets_fp32_bar(ops, oracle, shape):
+    seed, h, w, hr, wr, C, n_ids = shape
+    q, k, lab = _case(seed, h, w, hr, wr, C, n_ids)
+    out = ops.global_match(chw_view(k), chw_view(q), dev(lab), n_ids, compute="bf16x3").cpu().numpy()
+    want = oracle.global_match(np.transpose(k, (1, 2, 0)), np.transpose(q, (1, 2, 0)), lab, 1,
+                               n_ids=n_ids).reshape(-1, n_ids)
+    np.testing.assert_allclose(out, want, rtol=X3_RTOL, atol=X3_ATOL)
+
+
+def test_bf16_golden_reference_vectors(ops):
+    """against the reference's own fp32 outputs: bf16x3 inside the fp32 bar; plain bf16 deviates by the
+    input rounding (2^-9 relative per embedding value) -- bounded here, documented in DESIGN.md"""
+    g = load_golden("global_c100_tm1")
+    n_ids = int(g["gt_ids"]) + 1
+    x3 = ops.global_match(chw_view(g["ref_chw"]), chw_view(g["qry_chw"]), dev(g["labels"]), n_ids, compute="bf16x3")
+    np.testing.assert_allclose(x3.cpu().numpy().reshape(g["out"].shape), g["out"], rtol=1e-3, atol=3e-6)
+    bf = ops.global_match(chw_view(g["ref_chw"]), chw_view(g["qry_chw"]), dev(g["labels"]), n_ids, compute="bf16",
+                          normalize=True)
+    assert np.abs(bf.cpu().numpy().reshape(g["norm"].shape) - g["norm"]).max() < 2e-3  # on the normalised map
+
+
+def test_full_size_properties_cfg5_bf16(ops):
+    """BASELINE cfg5: 720p grid 180x320, C=100, 10-frame bank (M=576000), 6 ids, bf16."""
+    torch.manual_seed(20200614 + 5)
+    C, h, w, T, n_ids = 100, 180, 320, 10, 6
+    q = torch.relu(torch.randn(C, h, w, device="cuda")) * 0.1
+    bank = torch.relu(torch.randn(T, C, h, w, device="cuda")) * 0.1
+    bank[7] = q
+    N = h * w
+    lab = torch.randint(0, n_ids, (T * N,), device="cuda", dtype=torch.int32)
+    bank_rows = bank.permute(0, 2, 3, 1).reshape(-1, C)
+    for mode, tol in (("bf16", 2e-6), ("bf16x3", 2e-5)):
+        out = ops.global_match(bank_rows, q.permute(1, 2, 0), lab, n_ids, compute=mode)
+        own = lab[7 * N:8 * N].long()
+        assert out.gather(1, own[:, None]).abs().max().item() < tol  # self match ~ 0
+        perm = torch.randperm(T * N, device="cuda")
+        outp = ops.global_match(bank_rows[perm], q.permute(1, 2, 0), lab[perm], n_ids, compute=mode)
+        assert torch.equal(out, outp)  # row order never matters, bit for bit
+    # fp64 spot check of bf16 on the rounded embeddings
+    out = ops.global_match(bank_rows, q.permute(1, 2, 0), lab, n_ids, compute="bf16")
+    idx = torch.randint(0, N, (32,), device="cuda")
+    qs = q.permute(1, 2, 0).reshape(-1, C)[idx].bfloat16().double()
+    kb = bank_rows.bfloat16().double()
+    d = (qs * qs).sum(1, keepdim=True) + (kb * kb).sum(1)[None] - 2 * qs @ kb.t()
+    for o in range(n_ids):
+        dm = d.masked_fill((lab != o)[None], float("inf")).min(dim=1).values
+        assert torch.allclose(out[idx, o].double(), dm, rtol=1e-3, atol=3e-6)
+
+
 def test_prepared_bank_equals_one_shot(ops):
     q, k, lab = _case(21, 30, 40, 60, 40, 100, 3)
     one = ops.global_match(chw_view(k), chw_view(q), dev(lab), 3)
@@ -162,6 +248,8 @@ def test_errors_are_loud(ops):
         ops.global_match(torch.from_numpy(k).permute(1, 2, 0), chw_view(q), dev(lab), 2)  # CPU tensor
     with pytest.raises(RuntimeError):
         ops.global_match(chw_view(k), chw_view(q), dev(lab), 100)  # n_ids out of range
+    with pytest.raises(RuntimeError, match="k_nn > 1 needs"):
+        ops.global_match(chw_view(k), chw_view(q), dev(lab), 2, k_nearest_neighbors=2, compute="bf16")
     with pytest.raises(ValueError):
         ops.global_match(chw_view(k), chw_view(q), dev(lab[:4]), 2)
 
