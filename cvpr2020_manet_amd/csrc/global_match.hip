@@ -146,17 +146,29 @@ MatchLayout match_layout(int64_t N, int C, int n_ids, int compute, int k_nn = 1)
     return L;
 }
 
-// number of bank splits: enough workgroups for >= ~16 rounds of the 512 resident slots
-// (256 CUs x 2 workgroups) so the last partial round costs little, but >= 4 tiles per split.
-int pick_splits(int nQT, long T_max)
+// Number of bank splits S (grid = query tiles x S).  Every split re-reads the query operand
+// (S x 4C.N bytes of fabric traffic, the bank itself streams through each XCD's L2 once), so S
+// should be as small as the tail allows: take the smallest multiple of 8 whose last round of
+// workgroups over the `slots` resident workgroup slots is >= 97 % full, with >= 4 tiles per split.
+int pick_splits(int nQT, long T_max, int slots)
 {
-    long want = (16L * 512 + nQT - 1) / nQT;
-    long cap = T_max / 4;
-    long S = want < cap ? want : cap;
-    S = (S + 7) / 8 * 8;
-    if (S < 8) S = 8;
-    if (S > 512) S = 512;
-    return (int)S;
+    long cap = T_max / 4 / 8 * 8;
+    if (cap < 8) cap = 8;
+    if (cap > 256) cap = 256;
+    int best = 8;
+    double best_eff = 0.0;
+    for (int S = 8; S <= cap; S += 8) {
+        double rounds = (double)nQT * S / slots;
+        double full = (double)(long)rounds;
+        if (full < rounds) full += 1.0;
+        double eff = rounds / full;
+        if (eff >= 0.97) return S;
+        if (eff > best_eff) {
+            best_eff = eff;
+            best = S;
+        }
+    }
+    return best;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -913,7 +925,8 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
                            (long)q_stride_n, (long)q_stride_c, (const int *)nullptr, (const int *)nullptr, (long)N,
                            C, compute, ML.G.units, ML.G.kpad, mws + ML.off_q, (long)ML.qblk_bytes, 0.0f);
     }
-    int S = pick_splits(ML.nQT, BL.T_max);
+    // resident workgroup slots: f32 = 2 x 256-thread workgroups per CU, bf16 = 1 x 512-thread workgroup per CU
+    int S = pick_splits(ML.nQT, BL.T_max, compute == MANET_COMPUTE_F32 ? 512 : 256);
     {
         int forced = manet_tune_get(MANET_TUNE_SPLITS, 0);  // tuning only
         if (forced > 0) S = (forced + 7) / 8 * 8;
