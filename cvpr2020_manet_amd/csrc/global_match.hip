@@ -91,7 +91,8 @@ Geom geom_of(int C, int compute)
         G.steps = pick_ksb(C);
         G.units = 2 * G.steps * (compute == MANET_COMPUTE_BF16X3 ? 2 : 1);
         G.kpad = 16 * G.steps;
-        G.qt = 512;  // 8 waves: the bf16 MFMA eats a bank tile 14x faster, so share it between more queries
+        // 8 waves: the bf16 MFMA eats a bank tile 14x faster, so share it between more queries
+        G.qt = (manet_tune_get(MANET_TUNE_BF16_VARIANT, 0) == 1) ? 256 : 512;
     }
     G.tile_bytes = bank_tile_bytes_u(G.units);
     G.qblk_bytes = query_block_bytes_u(G.units);
@@ -410,7 +411,6 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
 {
     constexpr int NG = (KS + 3) / 4;
     constexpr size_t TILE_BYTES = bank_tile_bytes(NG);
-    constexpr int PIECES = (int)(TILE_BYTES / 1024);
     constexpr size_t QBLK_BYTES = query_block_bytes(NG);
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x TILE_BYTES
 
@@ -441,19 +441,30 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
     const int t1 = (int)((long)(s + 1) * T / S);
     if (t0 >= t1) return;
 
-    auto stage = [&](int t, int buf) {
-        const char *g = bpack + (size_t)t * TILE_BYTES + (size_t)lane * 16;
-        char *l = smem + (size_t)buf * TILE_BYTES;
-#pragma unroll
-        for (int p = 0; p < (PIECES + 3) / 4; ++p) {
-            int piece = p * 4 + wave;
-            if (piece < PIECES)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(g + (size_t)piece * 1024),
-                    (__attribute__((address_space(3))) void *)(l + (size_t)piece * 1024), 16, 0, 0);
-        }
-    };
-    stage(t0, 0);
+    // Tile staging through registers (issue the global loads a whole tile-step early, write them to
+    // LDS after the next barrier).  global_load_lds would save the VGPR round trip, but hipcc cannot
+    // tell the DMA's LDS destination from the ds_reads of the other buffer and drains vmcnt(0) in
+    // front of the first ds_read of every tile, which serialises the prefetch.
+    constexpr int NV = (int)(TILE_BYTES / 16);    // 16-byte vectors per tile
+    constexpr int NLD = (NV + 255) / 256;         // per thread
+    u32x4 R[NLD];
+#define MANET_GLOAD(R_, t_)                                                                \
+    {                                                                                      \
+        const u32x4 *g_ = (const u32x4 *)(bpack + (size_t)(t_) * TILE_BYTES);              \
+        _Pragma("unroll") for (int i_ = 0; i_ < NLD; ++i_)                                 \
+        {                                                                                  \
+            const int idx_ = i_ * NTHR + tid;                                              \
+            R_[i_] = g_[idx_ < NV ? idx_ : NV - 1]; /* clamped: always a valid address */  \
+        }                                                                                  \
+    }
+#define MANET_LSTORE(R_, slot_)                                                            \
+    {                                                                                      \
+        u32x4 *l_ = (u32x4 *)(smem + (size_t)(slot_) * TILE_BYTES);                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < NLD; ++i_)                                 \
+            if (i_ * NTHR + tid < NV) l_[i_ * NTHR + tid] = R_[i_];                        \
+    }
+    constexpr int NTHR = 256;
+    MANET_GLOAD(R, t0);
 
     // this wave's 2 x 32 queries, resident in registers for the whole kernel (B operand:
     // lane holds q[j = lane&31][k = 8g + 2jj + (lane>>5)])
@@ -515,10 +526,15 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
         }
     };
 
+    MANET_LSTORE(R, 0);
+    if (t0 + 1 < t1) MANET_GLOAD(R, t0 + 1);
     for (int t = t0; t < t1; ++t) {
         const int buf = (t - t0) & 1;
-        __syncthreads();  // tile t landed (vmcnt(0) before the barrier); buffer buf^1 is free
-        if (t + 1 < t1) stage(t + 1, buf ^ 1);
+        __syncthreads();  // tile t is visible in buffer buf; buffer buf^1 (tile t-1) is free
+        if (t + 1 < t1) {
+            MANET_LSTORE(R, buf ^ 1);                 // tile t+1, loaded during the previous step
+            if (t + 2 < t1) MANET_GLOAD(R, t + 2);    // in flight during this step's MFMAs
+        }
         if (t >= seg_end) {  // wave-uniform: crossed into the next object's rows
             flush(o);
             reset();
@@ -577,8 +593,8 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
 //   X3 = false: one MFMA per 16 k on embeddings rounded to bf16 (7 instead of 50 MFMAs per block at C=100)
 //   X3 = true : hi*hi + hi*lo + lo*hi with x = hi + lo, hi = bf16(x), lo = bf16(x - hi): the dropped
 //               lo*lo term is <= 2^-16 relative, i.e. fp32-class distances at 3/16 of the f32 MFMA cost.
-template <int KSB, bool X3>
-__global__ __launch_bounds__(512) void global_match_bf16_kernel(const char *__restrict__ qpack,
+template <int KSB, bool X3, int NW, int TPS>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void global_match_bf16_kernel(const char *__restrict__ qpack,
                                                                 const char *__restrict__ bpack,
                                                                 const int *__restrict__ meta, int n_ids,
                                                                 int nQT, int S, long N_pad,
@@ -588,10 +604,9 @@ __global__ __launch_bounds__(512) void global_match_bf16_kernel(const char *__re
     constexpr int UNITS = 2 * KSB * (X3 ? 2 : 1);
     constexpr int LO = 2 * KSB;  // first unit of the lo image
     constexpr size_t TILE_BYTES = bank_tile_bytes_u(UNITS);
-    constexpr int PIECES = (int)(TILE_BYTES / 1024);
     constexpr size_t QBLK_BYTES = query_block_bytes_u(UNITS);
-    constexpr int QTB = 512;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x TILE_BYTES
+    constexpr int QTB = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x TPS x TILE_BYTES
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -615,19 +630,30 @@ __global__ __launch_bounds__(512) void global_match_bf16_kernel(const char *__re
     const int t1 = (int)((long)(s + 1) * T / S);
     if (t0 >= t1) return;
 
-    auto stage = [&](int t, int buf) {
-        const char *g = bpack + (size_t)t * TILE_BYTES + (size_t)lane * 16;
-        char *l = smem + (size_t)buf * TILE_BYTES;
-#pragma unroll
-        for (int p = 0; p < (PIECES + 7) / 8; ++p) {
-            int piece = p * 8 + wave;
-            if (piece < PIECES)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(g + (size_t)piece * 1024),
-                    (__attribute__((address_space(3))) void *)(l + (size_t)piece * 1024), 16, 0, 0);
-        }
-    };
-    stage(t0, 0);
+    // register staging (see the f32 kernel) of one STEP = TPS consecutive tiles: one barrier per step
+    constexpr int NV = (int)(TILE_BYTES / 16) * TPS;
+    constexpr int NLD = (NV + NW * 64 - 1) / (NW * 64);
+    constexpr int NTHR = NW * 64;
+    constexpr size_t STEP_BYTES = TILE_BYTES * TPS;
+    u32x4 Ra[NLD];
+    // loads of a step's last partial tile group are clamped into the split's own range
+#define MANET_GLOAD_STEP(R_, t_)                                                                    \
+    {                                                                                               \
+        const u32x4 *g_ = (const u32x4 *)(bpack + (size_t)(t_) * TILE_BYTES);                       \
+        const int lim_ = ((t1 - (t_)) < TPS ? (t1 - (t_)) : TPS) * (int)(TILE_BYTES / 16);          \
+        _Pragma("unroll") for (int i_ = 0; i_ < NLD; ++i_)                                          \
+        {                                                                                           \
+            const int idx_ = i_ * NTHR + tid;                                                       \
+            R_[i_] = g_[idx_ < lim_ ? idx_ : lim_ - 1];                                             \
+        }                                                                                           \
+    }
+#define MANET_LSTORE_STEP(R_, slot_)                                                                \
+    {                                                                                               \
+        u32x4 *l_ = (u32x4 *)(smem + (size_t)(slot_) * STEP_BYTES);                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < NLD; ++i_)                                          \
+            if (i_ * NTHR + tid < NV) l_[i_ * NTHR + tid] = R_[i_];                                 \
+    }
+    MANET_GLOAD_STEP(Ra, t0);
 
     // B operand: lane holds q[j = lane&31][k = 16s + 8*(lane>>5) + 0..7] for its two query blocks
     uint4 q0[KSB], q1[KSB], q0l[X3 ? KSB : 1], q1l[X3 ? KSB : 1];
@@ -662,39 +688,53 @@ __global__ __launch_bounds__(512) void global_match_bf16_kernel(const char *__re
         }
     };
 #define MANET_BF(x) __builtin_bit_cast(bf16x8_t, x)
-    for (int t = t0; t < t1; ++t) {
-        const int buf = (t - t0) & 1;
-        __syncthreads();
-        if (t + 1 < t1) stage(t + 1, buf ^ 1);
-        if (t >= seg_end) {
-            flush(o);
-            m0 = m1 = MANET_WRONG_LABEL_PADDING_DISTANCE;
-            do { ++o; seg_end = meta[META_SEG + o + 1]; } while (t >= seg_end);
-        }
-        const char *tb = smem + (size_t)buf * TILE_BYTES;
-        const uint4 *A = (const uint4 *)tb;
-        f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+    struct Acc {
+        f32x16 c00, c01, c10, c11;
+    };
+    // the 4 x KSB (x3) MFMAs of one 64 x 64 tile block
+    auto mfma_tile = [&](const char *tb, Acc &c) __attribute__((always_inline)) {
+        const u32x4 *A = (const u32x4 *)tb;
+        c.c00 = c.c01 = c.c10 = c.c11 = f32x16{0};
+        if (!X3) {
+            // all A fragments of the tile first (2 x KSB ds_read_b128 in flight), then the MFMAs back to
+            // back behind counted lgkmcnt waits: the matrix pipe never waits for an LDS round trip
+            u32x4 a0[KSB], a1[KSB];
 #pragma unroll
-        for (int k = 0; k < KSB; ++k) {
-            uint4 a0 = A[(k * 2 + h) * BT + l31];
-            uint4 a1 = A[(k * 2 + h) * BT + 32 + l31];
-            c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q0[k]), c00, 0, 0, 0);
-            c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q1[k]), c01, 0, 0, 0);
-            c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q0[k]), c10, 0, 0, 0);
-            c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q1[k]), c11, 0, 0, 0);
-            if (X3) {
-                uint4 a0l = A[(LO + k * 2 + h) * BT + l31];
-                uint4 a1l = A[(LO + k * 2 + h) * BT + 32 + l31];
-                c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q0l[k]), c00, 0, 0, 0);
-                c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q1l[k]), c01, 0, 0, 0);
-                c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q0l[k]), c10, 0, 0, 0);
-                c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q1l[k]), c11, 0, 0, 0);
-                c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0l), MANET_BF(q0[k]), c00, 0, 0, 0);
-                c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0l), MANET_BF(q1[k]), c01, 0, 0, 0);
-                c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1l), MANET_BF(q0[k]), c10, 0, 0, 0);
-                c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1l), MANET_BF(q1[k]), c11, 0, 0, 0);
+            for (int k = 0; k < KSB; ++k) {
+                a0[k] = A[(k * 2 + h) * BT + l31];
+                a1[k] = A[(k * 2 + h) * BT + 32 + l31];
+            }
+#pragma unroll
+            for (int k = 0; k < KSB; ++k) {
+                c.c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0[k]), MANET_BF(q0[k]), c.c00, 0, 0, 0);
+                c.c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0[k]), MANET_BF(q1[k]), c.c01, 0, 0, 0);
+                c.c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1[k]), MANET_BF(q0[k]), c.c10, 0, 0, 0);
+                c.c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1[k]), MANET_BF(q1[k]), c.c11, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KSB; ++k) {
+                u32x4 a0 = A[(k * 2 + h) * BT + l31];
+                u32x4 a1 = A[(k * 2 + h) * BT + 32 + l31];
+                u32x4 a0l = A[(LO + k * 2 + h) * BT + l31];
+                u32x4 a1l = A[(LO + k * 2 + h) * BT + 32 + l31];
+                c.c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q0[k]), c.c00, 0, 0, 0);
+                c.c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q1[k]), c.c01, 0, 0, 0);
+                c.c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q0[k]), c.c10, 0, 0, 0);
+                c.c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q1[k]), c.c11, 0, 0, 0);
+                c.c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q0l[k]), c.c00, 0, 0, 0);
+                c.c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q1l[k]), c.c01, 0, 0, 0);
+                c.c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q0l[k]), c.c10, 0, 0, 0);
+                c.c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q1l[k]), c.c11, 0, 0, 0);
+                c.c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0l), MANET_BF(q0[k]), c.c00, 0, 0, 0);
+                c.c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0l), MANET_BF(q1[k]), c.c01, 0, 0, 0);
+                c.c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1l), MANET_BF(q0[k]), c.c10, 0, 0, 0);
+                c.c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1l), MANET_BF(q1[k]), c.c11, 0, 0, 0);
             }
         }
+    };
+    // running min over the 64 x 64 distances of a finished tile block
+    auto epilogue = [&](const char *tb, const Acc &c) __attribute__((always_inline)) {
         const float *ysl = (const float *)(tb + (size_t)UNITS * BT * 16);
 #pragma unroll
         for (int tq = 0; tq < 4; ++tq) {
@@ -703,11 +743,47 @@ __global__ __launch_bounds__(512) void global_match_bf16_kernel(const char *__re
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * tq + i;
-                m0 = fminf(m0, fminf(fmaf(-2.0f, c00[r], xs0 + y0[i]), fmaf(-2.0f, c10[r], xs0 + y1[i])));
-                m1 = fminf(m1, fminf(fmaf(-2.0f, c01[r], xs1 + y0[i]), fmaf(-2.0f, c11[r], xs1 + y1[i])));
+                m0 = fminf(m0, fminf(fmaf(-2.0f, c.c00[r], xs0 + y0[i]), fmaf(-2.0f, c.c10[r], xs0 + y1[i])));
+                m1 = fminf(m1, fminf(fmaf(-2.0f, c.c01[r], xs1 + y0[i]), fmaf(-2.0f, c.c11[r], xs1 + y1[i])));
+            }
+        }
+    };
+    auto next_object = [&](int t) __attribute__((always_inline)) {
+        if (t >= seg_end) {  // wave-uniform: tile t starts another object's rows
+            flush(o);
+            m0 = m1 = MANET_WRONG_LABEL_PADDING_DISTANCE;
+            do { ++o; seg_end = meta[META_SEG + o + 1]; } while (t >= seg_end);
+        }
+    };
+    {
+        // double-buffered LDS (2 x TPS tiles), register-staged prefetch one step ahead, ONE barrier per
+        // step of TPS tiles.  With the bf16 MFMA a 64-row tile is only ~0.4 us of matrix work per wave, so
+        // the fixed cost of a step (barrier skew, LDS write, first-fragment latency) is amortised over
+        // TPS tiles.  (A ping-pong schedule of the two waves of a SIMD and a dual-accumulator software
+        // pipeline were both measured: within noise of this simpler loop, see DESIGN.md.)
+        Acc c;
+        MANET_LSTORE_STEP(Ra, 0);
+        if (t0 + TPS < t1) MANET_GLOAD_STEP(Ra, t0 + TPS);
+        int buf = 0;
+        for (int t = t0; t < t1; t += TPS, buf ^= 1) {
+            __syncthreads();  // step's tiles visible in `buf`; the other buffer is free
+            if (t + TPS < t1) {
+                MANET_LSTORE_STEP(Ra, buf ^ 1);
+                if (t + 2 * TPS < t1) MANET_GLOAD_STEP(Ra, t + 2 * TPS);
+            }
+#pragma unroll
+            for (int u = 0; u < TPS; ++u) {
+                if (t + u < t1) {
+                    const char *tb = smem + (size_t)buf * STEP_BYTES + (size_t)u * TILE_BYTES;
+                    next_object(t + u);
+                    mfma_tile(tb, c);
+                    epilogue(tb, c);
+                }
             }
         }
     }
+#undef MANET_GLOAD_STEP
+#undef MANET_LSTORE_STEP
 #undef MANET_BF
     flush(o);
 }
@@ -821,17 +897,33 @@ void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int 
     manet_profile_record(st, false);
 }
 
+template <int KSB, bool X3, int NW, int TPS>
+void launch_main_bf16_v(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S, long N_pad,
+                        unsigned *keys, hipStream_t st)
+{
+    size_t lds = 2 * TPS * bank_tile_bytes_u(2 * KSB * (X3 ? 2 : 1));
+    (void)hipFuncSetAttribute((const void *)global_match_bf16_kernel<KSB, X3, NW, TPS>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    manet_profile_record(st, true);
+    hipLaunchKernelGGL((global_match_bf16_kernel<KSB, X3, NW, TPS>), dim3((unsigned)(nQT * S)), dim3(NW * 64), lds, st,
+                       qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, manet_tune_get(MANET_TUNE_BLOCK_MAP, 0));
+    manet_profile_record(st, false);
+}
+
+// workgroup shape of the bf16 kernels: 0 (default) = 8 waves, 2 tiles per barrier for plain bf16;
+// tuning: 1 = 4 waves x 2 workgroups per CU, 2 = 8 waves, 1 tile per barrier, 3 = 8 waves, 4 tiles
+int bf16_variant() { return manet_tune_get(MANET_TUNE_BF16_VARIANT, 0); }
+
 template <int KSB, bool X3>
 void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S, long N_pad,
                       unsigned *keys, hipStream_t st)
 {
-    size_t lds = 2 * bank_tile_bytes_u(2 * KSB * (X3 ? 2 : 1));
-    (void)hipFuncSetAttribute((const void *)global_match_bf16_kernel<KSB, X3>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    manet_profile_record(st, true);
-    hipLaunchKernelGGL((global_match_bf16_kernel<KSB, X3>), dim3((unsigned)(nQT * S)), dim3(512), lds, st, qpack, bpack,
-                       meta, n_ids, nQT, S, N_pad, keys, manet_tune_get(MANET_TUNE_BLOCK_MAP, 0));
-    manet_profile_record(st, false);
+    switch (bf16_variant()) {
+    case 1: launch_main_bf16_v<KSB, X3, 4, X3 ? 1 : 2>(qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, st); break;
+    case 2: launch_main_bf16_v<KSB, X3, 8, 1>(qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, st); break;
+    case 3: launch_main_bf16_v<KSB, X3, 8, X3 ? 2 : 4>(qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, st); break;
+    default: launch_main_bf16_v<KSB, X3, 8, X3 ? 1 : 2>(qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, st); break;
+    }
 }
 
 }  // namespace
@@ -926,7 +1018,7 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
                            C, compute, ML.G.units, ML.G.kpad, mws + ML.off_q, (long)ML.qblk_bytes, 0.0f);
     }
     // resident workgroup slots: f32 = 2 x 256-thread workgroups per CU, bf16 = 1 x 512-thread workgroup per CU
-    int S = pick_splits(ML.nQT, BL.T_max, compute == MANET_COMPUTE_F32 ? 512 : 256);
+    int S = pick_splits(ML.nQT, BL.T_max, (compute == MANET_COMPUTE_F32 || ML.G.qt == 256) ? 512 : 256);
     {
         int forced = manet_tune_get(MANET_TUNE_SPLITS, 0);  // tuning only
         if (forced > 0) S = (forced + 7) / 8 * 8;

@@ -10,6 +10,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define MANET_WRONG_LABEL_PADDING_DISTANCE 1e20f  // IntVOS.py:17
 #define MANET_MAX_IDS 64                          // object ids 0..63
@@ -32,7 +33,7 @@ static inline int manet_check_launch(const char *what)
 void manet_profile_record(hipStream_t st, bool start);
 
 // tuning knobs (manet_tune_set; defaults are the shipped configuration)
-enum { MANET_TUNE_BLOCK_MAP = 0, MANET_TUNE_SPLITS = 1, MANET_TUNE_COUNT = 8 };
+enum { MANET_TUNE_BLOCK_MAP = 0, MANET_TUNE_SPLITS = 1, MANET_TUNE_BF16_VARIANT = 2, MANET_TUNE_COUNT = 8 };
 int manet_tune_get(int key, int dflt);
 
 static inline size_t manet_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -158,7 +158,9 @@ int manet_correlation_forward_f32(const float *in1, const float *in2, int B, int
 int manet_profile_begin(int max_launches);
 /* Tuning knobs for experiments (process-wide; the defaults are the shipped configuration):
  * key 0 = block -> (query tile, bank split) mapping of the global-match kernel (0 XCD-aware),
- * key 1 = forced number of bank splits (0 = automatic). */
+ * key 1 = forced number of bank splits (0 = automatic),
+ * key 2 = workgroup shape of the bf16 kernels (0 = 8 waves, 2 tiles per barrier; 1 = 4 waves;
+ *         2 = 8 waves, 1 tile per barrier; 3 = 8 waves, 4 tiles per barrier). */
 int manet_tune_set(int key, int value);
 int manet_profile_end(float *ms_out, int capacity, int *n_launches);
 
