@@ -49,21 +49,37 @@ __global__ void pool2x2_kernel(const float *__restrict__ a, long a_sy, long a_sx
 // of registers: (2+2d)/2 ds_read_b64 feed 2*P sub+fma pairs.  Channels are accumulated in ascending
 // order with fmaf -- the same arithmetic as the oracle.
 constexpr int LD_TX = 16;  // columns per workgroup
-constexpr int LD_CC = 8;   // channels per LDS stage
-constexpr int LD_NJ = 5;   // halo-plane elements per thread: (8+24) rows x 40 cols <= 5 x 256
+// tile geometry as a function of the window radius d (all compile-time in the kernel):
+__host__ __device__ constexpr int ld_ry(int d)  // grid rows per workgroup: 32 (row, dy) slots
+{
+    return (32 / (2 * d + 1)) < 1 ? 1 : ((32 / (2 * d + 1)) > 8 ? 8 : (32 / (2 * d + 1)));
+}
+__host__ __device__ constexpr int ld_cw(int d) { return (LD_TX + 2 * d + 3) & ~3; }  // halo row stride, 16 B rows
+__host__ __device__ constexpr int ld_yplane(int d) { return (ld_ry(d) + 2 * d) * ld_cw(d); }
+__host__ __device__ constexpr int ld_nj(int d) { return (ld_yplane(d) + 255) / 256; }  // halo elements per thread
+// channels per LDS stage: as many as two stages fit in 64 KiB and ~80 staging registers allow -- a
+// stage costs one global round trip + one barrier, so few, fat stages (4 at d=4, 13 at d=12 for C=100)
+__host__ __device__ constexpr int ld_cc(int d)
+{
+    int by_lds = 65536 / (8 * (ld_yplane(d) + ld_ry(d) * LD_TX));
+    int by_regs = 80 / (ld_nj(d) + 1);
+    int cc = by_lds < by_regs ? by_lds : by_regs;
+    return cc > 25 ? 25 : (cc < 4 ? 4 : cc);
+}
 template <int D>  // window radius: compile-time so the 2 x P accumulators unroll without predicates
 __global__ __launch_bounds__(256, 2) void local_dist_kernel(const float *__restrict__ x, long x_sy, long x_sx,
                                                             long x_sc, const float *__restrict__ y, long y_sy,
-                                                            long y_sx, long y_sc, int H, int W, int C, int RY,
+                                                            long y_sx, long y_sc, int H, int W, int C,
                                                             int pooled_out, float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int d = D;
     constexpr int P = 2 * d + 1;
-    constexpr int MAXP = P;  // shadows the file-level bound: arrays are exactly P wide here
-    const int RYH = RY + 2 * d;               // halo rows
-    const int CW = (LD_TX + 2 * d + 3) & ~3;  // halo row stride (floats), 16 B aligned rows
-    const int yplane = RYH * CW, xplane = RY * LD_TX;
+    constexpr int MAXP = P;  // arrays are exactly P wide
+    constexpr int RY = ld_ry(D), LD_CC = ld_cc(D), LD_NJ = ld_nj(D);
+    constexpr int RYH = RY + 2 * d;  // halo rows
+    constexpr int CW = ld_cw(D);
+    constexpr int yplane = RYH * CW, xplane = RY * LD_TX;
     const int buf_floats = LD_CC * (yplane + xplane);  // one stage: ys [LD_CC][RYH][CW] then xs [LD_CC][RY][16]
     float *smem = (float *)smem_raw;
     const int tid = threadIdx.x;
@@ -189,14 +205,11 @@ static DistLaunch dist_launch(int H, int W, int d)
 {
     DistLaunch L;
     const int P = 2 * d + 1;
-    int ry = 32 / P;  // 256 threads = 32 (row, dy) slots x 8 column pairs
-    if (ry < 1) ry = 1;
-    if (ry > 8) ry = 8;
-    if (ry > H) ry = H;
+    (void)P;
+    int ry = ld_ry(d);  // 256 threads = 32 (row, dy) slots x 8 column pairs
     L.RY = ry;
     L.grid = dim3((unsigned)((W + LD_TX - 1) / LD_TX), (unsigned)((H + ry - 1) / ry));
-    const int CW = (LD_TX + 2 * d + 3) & ~3;
-    L.lds = 2 * (size_t)LD_CC * ((size_t)(ry + 2 * d) * CW + (size_t)ry * LD_TX) * sizeof(float);  // 2 stages
+    L.lds = 2 * (size_t)ld_cc(d) * ((size_t)ld_yplane(d) + (size_t)ry * LD_TX) * sizeof(float);  // 2 stages
     return L;
 }
 template <int D>
@@ -205,7 +218,7 @@ static void launch_dist_d(const DistLaunch &DL, hipStream_t st, const float *x, 
                           float *out)
 {
     hipLaunchKernelGGL(local_dist_kernel<D>, DL.grid, dim3(256), DL.lds, st, x, x_sy, x_sx, x_sc, y, y_sy, y_sx, y_sc,
-                       H, W, C, DL.RY, pooled_out, out);
+                       H, W, C, pooled_out, out);
 }
 static void launch_dist(int d, hipStream_t st, const float *x, long x_sy, long x_sx, long x_sc, const float *y,
                         long y_sy, long y_sx, long y_sc, int H, int W, int C, int pooled_out, float *out)
