@@ -34,6 +34,7 @@ SIGNATURES = {
     "manet_local_match_f32": (_i, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i,
                                    _i, _vp, _vp, _sz, _vp]),
     "manet_correlation_out_dims": (_i, [_i, _i, _i, _i, _i, _i, _i, _ip, _ip, _ip]),
+    "manet_upsample_argmax": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "manet_profile_begin": (_i, [_i]),
     "manet_tune_set": (_i, [_i, _i]),
     "manet_profile_end": (_i, [ctypes.POINTER(ctypes.c_float), _i, _ip]),

@@ -1,0 +1,89 @@
+// Mask step between two propagated frames, MI355X (gfx950).
+//
+// The reference's driver turns the head's logits into the next frame's inputs with three framework
+// calls per frame, on the sequential chain that limits multi-GPU scaling:
+//   test.py:253     pred = F.interpolate(logits [1,n_ids,h,w], size=(H,W), mode='bilinear', align_corners=True)
+//   test.py:255     pred = torch.argmax(pred, dim=1)                       -> [1,H,W] int64
+//   IntVOS.py:598-599 (next call)  F.interpolate(prev_mask.float(), size=(h,w), mode='nearest').int()
+// i.e. a [1,n_ids,H,W] fp32 intermediate (16 n_ids MB at 480p) is written and re-read only to take an
+// argmax.  Here one launch produces both results straight from the [n_ids,h,w] logits:
+//   mask  [H][W]  int64  = argmax_o bilinear(logits[o])(Y,X)            (first maximum wins, as torch)
+//   small [h][w]  int32  = mask[min(floor(y*H/h),H-1)][min(floor(x*W/w),W-1)]   ('nearest' source index)
+// The small grid recomputes its few source pixels instead of waiting for the big one: no second pass.
+#include "manet_common.h"
+
+namespace {
+
+struct Bil {
+    int i0, i1;
+    float l0, l1;
+};
+// aten area_pixel_compute_scale (align_corners=True) + linear source index, as in local_match.hip
+__device__ __forceinline__ Bil bil(int dst, int in_size, int out_size)
+{
+    float scale = (out_size > 1) ? (float)(in_size - 1) / (float)(out_size - 1) : 0.0f;
+    float src = scale * (float)dst;
+    int a = (int)src;
+    if (a > in_size - 1) a = in_size - 1;
+    Bil b;
+    b.i0 = a;
+    b.i1 = a + ((a < in_size - 1) ? 1 : 0);
+    b.l1 = src - (float)a;
+    b.l0 = 1.0f - b.l1;
+    return b;
+}
+
+__device__ __forceinline__ int argmax_at(const float *__restrict__ logits, int n_ids, int h, int w, int Y, int X,
+                                         int H, int W)
+{
+    const Bil by = bil(Y, h, H), bx = bil(X, w, W);
+    const long plane = (long)h * w;
+    int best = 0;
+    float bv = -INFINITY;
+    for (int o = 0; o < n_ids; ++o) {
+        const float *p = logits + o * plane;
+        float v = by.l0 * (bx.l0 * p[by.i0 * w + bx.i0] + bx.l1 * p[by.i0 * w + bx.i1]) +
+                  by.l1 * (bx.l0 * p[by.i1 * w + bx.i0] + bx.l1 * p[by.i1 * w + bx.i1]);
+        if (v > bv || o == 0) {  // strict: the first maximum wins (torch.argmax)
+            bv = v;
+            best = o;
+        }
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(256) void upsample_argmax_kernel(const float *__restrict__ logits, int n_ids, int h,
+                                                              int w, int H, int W, long long *__restrict__ mask,
+                                                              int *__restrict__ small)
+{
+    const long big = (long)H * W;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < big) {
+        if (!mask) return;
+        int Y = (int)(i / W), X = (int)(i - (long)Y * W);
+        mask[i] = argmax_at(logits, n_ids, h, w, Y, X, H, W);
+        return;
+    }
+    i -= big;
+    if (!small || i >= (long)h * w) return;
+    int y = (int)(i / w), x = (int)(i - (long)y * w);
+    // aten nearest_neighbor_compute_source_index: min(floor(dst * (in/out)), in - 1), scale in float
+    float sy = (float)H / (float)h, sx = (float)W / (float)w;
+    int Y = (int)floorf((float)y * sy), X = (int)floorf((float)x * sx);
+    if (Y > H - 1) Y = H - 1;
+    if (X > W - 1) X = W - 1;
+    small[i] = argmax_at(logits, n_ids, h, w, Y, X, H, W);
+}
+
+}  // namespace
+
+extern "C" int manet_upsample_argmax(const float *logits, int n_ids, int h, int w, int H, int W, int64_t *mask_hw,
+                                     int32_t *label_small_hw, manet_stream_t stream)
+{
+    if (!logits || n_ids <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || (!mask_hw && !label_small_hw))
+        return manet_set_error(MANET_E_INVALID, "bad arguments");
+    long total = (long)H * W + (long)h * w;
+    hipLaunchKernelGGL(upsample_argmax_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       logits, n_ids, h, w, H, W, (long long *)mask_hw, (int *)label_small_hw);
+    return manet_check_launch("manet_upsample_argmax");
+}

@@ -261,3 +261,24 @@ def correlation_forward(input1, input2, pad_size, kernel_size, max_displacement,
                                                _stream_ptr(a.device))
     _lib.check(rc, "manet_correlation_forward_f32")
     return out
+
+
+def upsample_argmax(logits, size, want_small=True):
+    """The mask step of the reference's driver in one launch:
+    bilinear(align_corners) upsample of `logits` [1, n_ids, h, w] to `size`=(H, W) + argmax over ids
+    (test.py:253-255) -> int64 [1, H, W]; and that mask nearest-resized back to (h, w) as the next
+    frame's previous-frame label (IntVOS.py:598-599) -> int32 [1, 1, h, w] (None if not wanted)."""
+    lib = _lib.load()
+    _need_gpu(logits, "logits")
+    if logits.dim() != 4 or logits.shape[0] != 1:
+        raise ValueError("logits must be [1, n_ids, h, w]")
+    lg = logits.float().contiguous()
+    _, n_ids, h, w = lg.shape
+    H, W = int(size[0]), int(size[1])
+    mask = torch.empty((1, H, W), dtype=torch.int64, device=lg.device)
+    small = torch.empty((1, 1, h, w), dtype=torch.int32, device=lg.device) if want_small else None
+    with torch.cuda.device(lg.device):
+        rc = lib.manet_upsample_argmax(lg.data_ptr(), n_ids, h, w, H, W, mask.data_ptr(),
+                                       None if small is None else small.data_ptr(), _stream_ptr(lg.device))
+    _lib.check(rc, "manet_upsample_argmax")
+    return mask, small

@@ -151,6 +151,15 @@ int manet_correlation_forward_f32(const float *in1, const float *in2, int B, int
                                   int stride2, float *out, manet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Mask step between two propagated frames (the driver side of the path):
+ *   test.py:253-255   F.interpolate(logits, (H,W), 'bilinear', align_corners=True) -> argmax(dim=1)
+ *   IntVOS.py:598-599 F.interpolate(prev_mask.float(), (h,w), 'nearest').int()   (next frame's input)
+ * logits [n_ids][h][w] fp32 contiguous -> mask_hw [H][W] int64 (may be NULL) and label_small_hw
+ * [h][w] int32 (may be NULL), in one launch, without the [n_ids][H][W] intermediate. */
+int manet_upsample_argmax(const float *logits, int n_ids, int h, int w, int H, int W, int64_t *mask_hw,
+                          int32_t *label_small_hw, manet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Opt-in measurement hook (not part of the data path, used by bench.py): between _begin and _end
  * every launch of the dominant kernel (the global-match MFMA kernel) is bracketed by two HIP
  * events on its own stream.  manet_profile_end synchronises on those events (the only call in

@@ -251,6 +251,22 @@ def variant_correlation():
     save("correlation_tie", in1=a, in2=b, d=d, dist=dist)
 
 
+def variant_mask_step():
+    """8f rank 2: the driver's mask step, executed with the reference's own calls
+    (test.py:253-255: interpolate bilinear align_corners + argmax; IntVOS.py:598-599: nearest + int)."""
+    import torch
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(20200618)
+    for (n_ids, h, w, H, W) in [(3, 10, 13, 40, 52), (5, 12, 21, 47, 85), (2, 30, 54, 120, 214)]:
+        logits = torch.randn(1, n_ids, h, w, generator=g)
+        logits[0, :, 0, 0] = 0.5  # exact tie: first index must win
+        pred = nn.functional.interpolate(logits, size=(H, W), mode="bilinear", align_corners=True)
+        pred = torch.argmax(pred, dim=1)
+        small = torch.nn.functional.interpolate(pred.unsqueeze(0).float(), size=(h, w), mode="nearest").int()
+        save("mask_step_%dx%d_to_%dx%d_n%d" % (h, w, H, W, n_ids), logits=logits, mask=pred, small=small,
+             size=np.array([H, W]))
+
+
 VARIANTS = {
     "global_tm1": lambda: variant_global(True),
     "global_tm0": lambda: variant_global(False),
@@ -259,6 +275,7 @@ VARIANTS = {
     "e2e": variant_e2e,
     "statedict": variant_statedict,
     "correlation": variant_correlation,
+    "mask_step": variant_mask_step,
 }
 
 if __name__ == "__main__":

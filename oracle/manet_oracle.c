@@ -400,3 +400,43 @@ int oracle_correlation_forward_f32(const float *in1, const float *in2, int B, in
             }
     return 0;
 }
+
+/*
+ * Mask step of the driver:
+ *   test.py:253-255   F.interpolate(logits, (H,W), bilinear, align_corners=True) then argmax over ids
+ *                     (first maximum wins)
+ *   IntVOS.py:598-599 F.interpolate(mask.float(), (h,w), 'nearest').int(): source index
+ *                     min(floor(dst * (in/out)), in-1) with the scale in float (aten UpSample.h)
+ * logits [n_ids][h][w]; mask [H][W] int64; small [h][w] int32.
+ */
+void oracle_upsample_argmax(const float *logits, int n_ids, int h, int w, int H, int W, int64_t *mask,
+                            int32_t *small)
+{
+    for (int Y = 0; Y < H; ++Y) {
+        int y0, y1;
+        float hl0, hl1;
+        bilin_coeff(Y, h, H, &y0, &y1, &hl0, &hl1);
+        for (int X = 0; X < W; ++X) {
+            int x0, x1;
+            float wl0, wl1;
+            bilin_coeff(X, w, W, &x0, &x1, &wl0, &wl1);
+            int best = 0;
+            float bv = 0.0f;
+            for (int o = 0; o < n_ids; ++o) {
+                const float *p = logits + (long)o * h * w;
+                float v = hl0 * (wl0 * p[y0 * w + x0] + wl1 * p[y0 * w + x1]) +
+                          hl1 * (wl0 * p[y1 * w + x0] + wl1 * p[y1 * w + x1]);
+                if (o == 0 || v > bv) { bv = v; best = o; }
+            }
+            mask[(long)Y * W + X] = best;
+        }
+    }
+    float sy = (float)H / (float)h, sx = (float)W / (float)w;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            int Y = (int)floorf((float)y * sy), X = (int)floorf((float)x * sx);
+            if (Y > H - 1) Y = H - 1;
+            if (X > W - 1) X = W - 1;
+            small[y * w + x] = (int32_t)mask[(long)Y * W + X];
+        }
+}

@@ -59,6 +59,8 @@ def lib():
         L.oracle_correlation_out_dims.argtypes = [_I] * 7 + [ctypes.POINTER(_I)] * 3
         L.oracle_correlation_forward_f32.restype = _I
         L.oracle_correlation_forward_f32.argtypes = [_f32p, _f32p] + [_I] * 9 + [_f32p]
+        L.oracle_upsample_argmax.restype = None
+        L.oracle_upsample_argmax.argtypes = [_f32p, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int64), _i32p]
         L.oracle_bf16_round.restype = ctypes.c_float
         L.oracle_bf16_round.argtypes = [ctypes.c_float]
         _lib = L
@@ -225,3 +227,15 @@ def local_map_select(local_map_tmp, local_map_dist, new_map, frame, interaction_
     else:
         sel = local_map_tmp[frame][interaction_num - 2]
     return sel[None]
+
+
+def upsample_argmax(logits, size):
+    """test.py:253-255 + IntVOS.py:598-599: logits [1, n_ids, h, w] -> (mask int64 [1,H,W], small int32 [1,1,h,w])."""
+    lg = np.ascontiguousarray(_f32(logits))
+    _, n_ids, h, w = lg.shape
+    H, W = int(size[0]), int(size[1])
+    mask = np.empty((H, W), np.int64)
+    small = np.empty((h, w), np.int32)
+    lib().oracle_upsample_argmax(_ptr(lg), n_ids, h, w, H, W, mask.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                 small.ctypes.data_as(_i32p))
+    return mask[None], small[None, None]

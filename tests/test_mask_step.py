@@ -1,0 +1,57 @@
+"""the driver's mask step (bilinear upsample + argmax + nearest resize back),
+test.py:253-255 + IntVOS.py:598-599.  Integer outputs: the bar is exact equality."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+CASES = ["mask_step_10x13_to_40x52_n3", "mask_step_12x21_to_47x85_n5", "mask_step_30x54_to_120x214_n2"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_calls(oracle, name):
+    g = load_golden(name)
+    mask, small = oracle.upsample_argmax(g["logits"], g["size"])
+    np.testing.assert_array_equal(mask, g["mask"])
+    np.testing.assert_array_equal(small, g["small"])
+
+
+def test_oracle_on_the_end_to_end_vector(oracle):
+    """the reference class's own logits -> the mask the reference driver derived from them"""
+    g = load_golden("e2e_tiny")
+    mask, _ = oracle.upsample_argmax(g["int_logits"], g["int_pred"].shape[1:])
+    np.testing.assert_array_equal(mask, g["int_pred"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_matches_reference_calls(name):
+    from cvpr2020_manet_amd import ops
+    g = load_golden(name)
+    mask, small = ops.upsample_argmax(torch.from_numpy(g["logits"]).cuda(), g["size"])
+    assert mask.dtype == torch.int64 and small.dtype == torch.int32
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["mask"])
+    np.testing.assert_array_equal(small.cpu().numpy(), g["small"])
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_vs_torch_ops_and_oracle(oracle):
+    """480p: [1,4,120,214] -> (480,854).  Equality with the framework ops the reference calls, except where
+    two ids tie to the last bit of a different (but equally valid) fp32 evaluation order."""
+    from cvpr2020_manet_amd import ops
+    torch.manual_seed(5)
+    logits = torch.randn(1, 4, 120, 214, device="cuda")
+    mask, small = ops.upsample_argmax(logits, (480, 854))
+    up = torch.nn.functional.interpolate(logits, size=(480, 854), mode="bilinear", align_corners=True)
+    ref_mask = torch.argmax(up, dim=1)
+    diff = mask != ref_mask
+    if diff.any():  # only exact-to-rounding ties may differ
+        top2 = up[0].topk(2, dim=0).values
+        assert ((top2[0] - top2[1])[diff[0]] < 1e-5).all()
+    assert diff.float().mean().item() < 1e-4
+    ref_small = torch.nn.functional.interpolate(mask.unsqueeze(0).float(), size=(120, 214), mode="nearest").int()
+    assert torch.equal(small, ref_small)
+    om, osm = oracle.upsample_argmax(logits.cpu().numpy(), (480, 854))
+    np.testing.assert_array_equal(mask.cpu().numpy(), om)  # same arithmetic as the oracle: exact
+    np.testing.assert_array_equal(small.cpu().numpy(), osm)
