@@ -202,10 +202,41 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         nn.init.kaiming_normal_(self.conv1.weight, mode="fan_out", nonlinearity="relu")
         nn.init.kaiming_normal_(self.conv2.weight, mode="fan_out", nonlinearity="relu")
 
+    def _fast(self, x):
+        """fused HIP depthwise-7x7 + BN + ReLU (ops.dwconv7x7_bn_relu) is usable: inference on the GPU"""
+        return (not self.training and x.is_cuda and not torch.is_grad_enabled()
+                and self.conv1.kernel_size == (7, 7) and x.dtype == torch.float32)
+
+    def _folded_conv2(self):
+        """conv2 with eval-mode bn2 folded into its weights: bn2(conv2(x)) == conv2'(x)"""
+        scale, shift = ops.fold_bn(self.bn2)
+        w = self.conv2.weight * scale[:, None, None, None]
+        b = self.conv2.bias * scale + shift if self.conv2.bias is not None else shift
+        return w, b
+
     def forward(self, x):
+        if self._fast(x):
+            x = ops.dwconv7x7_bn_relu(x, self.conv1.weight, self.conv1.bias, self.bn1)
+            w, b = self._folded_conv2()
+            return F.conv2d(x, w, b).relu_()
         x = self.relu1(self.bn1(self.conv1(x)))
         x = self.relu2(self.bn2(self.conv2(x)))
         return x
+
+    def forward_shared(self, shared, per_object):
+        """The block applied to cat([shared repeated n times, per_object], 1) without building that tensor
+        (IntVOS.py:665-670 repeats the C-channel embedding once per object): the depthwise stage and the
+        1x1 stage are linear in the channel groups, so the shared group is processed once.
+        shared [1, Cs, h, w], per_object [n, Cp, h, w], Cs + Cp == in_dim."""
+        cs = shared.shape[1]
+        scale, shift = ops.fold_bn(self.bn1)
+        w1, b1 = self.conv1.weight, self.conv1.bias
+        s1 = ops.dwconv7x7_bn_relu(shared, w1[:cs], b1[:cs], scale=scale[:cs], shift=shift[:cs])
+        p1 = ops.dwconv7x7_bn_relu(per_object, w1[cs:], b1[cs:], scale=scale[cs:], shift=shift[cs:])
+        w2, b2 = self._folded_conv2()
+        y = F.conv2d(p1, w2[:, cs:], b2)
+        y += F.conv2d(s1, w2[:, :cs])  # broadcast over the objects
+        return y.relu_()
 
 
 class DynamicSegHead(nn.Module):  # reference IntVOS.py:509-525
@@ -222,6 +253,21 @@ class DynamicSegHead(nn.Module):  # reference IntVOS.py:509-525
 
     def forward(self, x):
         return self.conv(self.layer4(self.layer3(self.layer2(self.layer1(x)))))
+
+    def forward_shared(self, shared, per_object):
+        """forward(cat([shared.repeat(n,1,1,1), per_object], 1)) without materialising the input"""
+        return self.conv(self.layer4(self.layer3(self.layer2(self.layer1.forward_shared(shared, per_object)))))
+
+
+def _run_head(head, embedding_chw, per_object):
+    """head(cat([embedding repeated per object, per_object], 1)) (IntVOS.py:665-671, :741-758).  In
+    inference on the GPU a DynamicSegHead takes the shared-embedding route (no repeat / cat of the C-channel
+    embedding, depthwise stage of those channels computed once); otherwise the reference's literal form."""
+    n = per_object.shape[0]
+    if (isinstance(head, DynamicSegHead) and not head.training and not torch.is_grad_enabled()
+            and embedding_chw.is_cuda and embedding_chw.dtype == torch.float32):
+        return head.forward_shared(embedding_chw.unsqueeze(0), per_object)
+    return head(torch.cat((embedding_chw.unsqueeze(0).repeat((n, 1, 1, 1)), per_object), 1))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -366,13 +412,11 @@ class IntVOS(nn.Module):
 
             # ---- head input [n_ids, C+3, h, w] (:663-673)
             to_cat_previous_frame = (seq_previous_frame_label.float() == ref_obj_ids.float())
-            to_cat_current_frame_embedding = current_frame_embedding[n].unsqueeze(0).repeat((n_ids, 1, 1, 1))
             to_cat_nn_feature_n = nn_features_n.squeeze(0).permute(2, 3, 0, 1)
             to_cat_previous_frame = to_cat_previous_frame.unsqueeze(-1).permute(2, 3, 0, 1).float()
             to_cat_prev_frame_nn_feature_n = prev_frame_nn_features_n.squeeze(0).permute(2, 3, 0, 1)
-            to_cat = torch.cat((to_cat_current_frame_embedding, to_cat_nn_feature_n,
-                                to_cat_prev_frame_nn_feature_n, to_cat_previous_frame), 1)
-            pred_ = dynamic_seghead(to_cat)
+            per_object = torch.cat((to_cat_nn_feature_n, to_cat_prev_frame_nn_feature_n, to_cat_previous_frame), 1)
+            pred_ = _run_head(dynamic_seghead, current_frame_embedding[n], per_object)
             dic_tmp[seq_names[n]] = pred_.permute(1, 0, 2, 3)
 
         if global_map_tmp_dic is None:
@@ -418,7 +462,6 @@ class IntVOS(nn.Module):
                 local_map_dist_dic[seq_names[n]][frame_num[n]][interaction_num - 1] = 0
                 local_map_dics = (local_map_tmp_dic, local_map_dist_dic)
             # ---- head input (:741-760)
-            to_cat_current_frame_embedding = ref_frame_embedding[n].unsqueeze(0).repeat((n_ids, 1, 1, 1))
             to_cat_scribble_mask_to_cat = (seq_ref_scribble_label.float() == gt_id.float())
             to_cat_scribble_mask_to_cat = to_cat_scribble_mask_to_cat.unsqueeze(-1).permute(2, 3, 0, 1).float()
             if not first_inter:
@@ -428,9 +471,8 @@ class IntVOS(nn.Module):
             else:
                 to_cat_prev_round_to_cat = torch.zeros_like(to_cat_scribble_mask_to_cat)
                 to_cat_prev_round_to_cat[0] = 1.0
-            to_cat = torch.cat((to_cat_current_frame_embedding, to_cat_scribble_mask_to_cat,
-                                to_cat_prev_round_to_cat), 1)
-            pred_ = self.inter_seghead(to_cat)
+            per_object = torch.cat((to_cat_scribble_mask_to_cat, to_cat_prev_round_to_cat), 1)
+            pred_ = _run_head(self.inter_seghead, ref_frame_embedding[n], per_object)
             dic_tmp[seq_names[n]] = pred_.permute(1, 0, 2, 3)
         if local_map_dics is None:
             return dic_tmp

@@ -282,3 +282,40 @@ def upsample_argmax(logits, size, want_small=True):
                                        None if small is None else small.data_ptr(), _stream_ptr(lg.device))
     _lib.check(rc, "manet_upsample_argmax")
     return mask, small
+
+
+def fold_bn(bn):
+    """eval-mode BatchNorm as per-channel (scale, shift): y = x * scale + shift"""
+    inv = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+    g = bn.weight.detach().float() if bn.weight is not None else torch.ones_like(inv)
+    b = bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(inv)
+    scale = g * inv
+    return scale, b - bn.running_mean.detach().float() * scale
+
+
+def dwconv7x7_bn_relu(x, weight, bias=None, bn=None, relu=True, scale=None, shift=None):
+    """Depthwise 7x7 conv (padding 3) + bias + eval-mode BatchNorm + ReLU in one HIP kernel
+    (IntVOS.py:491-493,500-502: conv1 -> bn1 -> relu1 of _split_separable_conv2d).
+    x [B, C, h, w] fp32; weight [C, 1, 7, 7]; bn: an nn.BatchNorm2d in eval mode, or explicit per-channel
+    `scale` / `shift` (fold_bn), or neither."""
+    lib = _lib.load()
+    _need_gpu(x, "x")
+    x = x.float().contiguous()
+    B, C, h, w = x.shape
+    if tuple(weight.shape) != (C, 1, 7, 7):
+        raise ValueError("weight must be [C, 1, 7, 7]")
+    wt = weight.detach().float().contiguous()
+    if bn is not None:
+        scale, shift = fold_bn(bn)
+    if scale is not None:
+        scale, shift = scale.float().contiguous(), shift.float().contiguous()
+    bz = None if bias is None else bias.detach().float().contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.manet_dwconv7x7_bn_relu_f32(x.data_ptr(), B, C, h, w, wt.data_ptr(),
+                                             None if bz is None else bz.data_ptr(),
+                                             None if scale is None else scale.data_ptr(),
+                                             None if shift is None else shift.data_ptr(), int(bool(relu)),
+                                             out.data_ptr(), _stream_ptr(x.device))
+    _lib.check(rc, "manet_dwconv7x7_bn_relu_f32")
+    return out

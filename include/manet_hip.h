@@ -159,6 +159,15 @@ int manet_correlation_forward_f32(const float *in1, const float *in2, int B, int
 int manet_upsample_argmax(const float *logits, int n_ids, int h, int w, int H, int W, int64_t *mask_hw,
                           int32_t *label_small_hw, manet_stream_t stream);
 
+/* Depthwise 7x7 convolution (padding 3, one filter per channel) + bias + BatchNorm(eval) + ReLU, fused:
+ * the first half of the reference's _split_separable_conv2d (IntVOS.py:491-493,500-502), the building block
+ * of DynamicSegHead.  in/out [B][C][h][w] fp32 contiguous, weight [C][7][7],
+ * bias / bn_scale / bn_shift [C] or NULL (0 / 1 / 0); bn_scale = gamma / sqrt(var + eps),
+ * bn_shift = beta - mean * bn_scale.  out = relu?((conv + bias) * bn_scale + bn_shift). */
+int manet_dwconv7x7_bn_relu_f32(const float *in, int B, int C, int h, int w, const float *weight,
+                                const float *bias, const float *bn_scale, const float *bn_shift, int relu,
+                                float *out, manet_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Opt-in measurement hook (not part of the data path, used by bench.py): between _begin and _end
  * every launch of the dominant kernel (the global-match MFMA kernel) is bracketed by two HIP

@@ -267,6 +267,33 @@ def variant_mask_step():
              size=np.array([H, W]))
 
 
+def variant_seg_head():
+    """8f rank 1: the reference's own _split_separable_conv2d and DynamicSegHead (IntVOS.py:488-525) in eval
+    mode on random inputs: conv1->bn1->relu1 output (what the fused HIP kernel replaces) and the full head."""
+    torch, R = import_reference(["--TEST_MODE", "True", "--MODEL_SEMANTIC_EMBEDDING_DIM", "13",
+                                 "--MODEL_HEAD_EMBEDDING_DIM", "24"])
+    torch.manual_seed(20200619)
+    blk = R._split_separable_conv2d(6, 10)
+    head = R.DynamicSegHead()  # in_dim 16, embed 24
+    for m in list(blk.modules()) + list(head.modules()):
+        if hasattr(m, "running_mean") and m.running_mean is not None:
+            m.running_mean.uniform_(-0.3, 0.3)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.2, 0.2)
+    blk.eval()
+    head.eval()
+    x = torch.randn(2, 6, 18, 67)
+    with torch.no_grad():
+        half = blk.relu1(blk.bn1(blk.conv1(x)))
+        full = blk(x)
+        hx = torch.randn(2, 16, 11, 13)
+        hout = head(hx)
+    sd_b = {("blk::" + k): v for k, v in blk.state_dict().items()}
+    sd_h = {("head::" + k): v for k, v in head.state_dict().items()}
+    save("seg_head_tiny", x=x, half=half, full=full, hx=hx, hout=hout, eps=blk.bn1.eps, **sd_b, **sd_h)
+
+
 VARIANTS = {
     "global_tm1": lambda: variant_global(True),
     "global_tm0": lambda: variant_global(False),
@@ -276,6 +303,7 @@ VARIANTS = {
     "statedict": variant_statedict,
     "correlation": variant_correlation,
     "mask_step": variant_mask_step,
+    "seg_head": variant_seg_head,
 }
 
 if __name__ == "__main__":

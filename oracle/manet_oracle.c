@@ -440,3 +440,31 @@ void oracle_upsample_argmax(const float *logits, int n_ids, int h, int w, int H,
             small[y * w + x] = (int32_t)mask[(long)Y * W + X];
         }
 }
+
+/*
+ * Depthwise 7x7 conv (padding 3) + bias + BatchNorm(eval, folded to scale/shift) + ReLU
+ * (IntVOS.py:491-493,500-502: conv1 -> bn1 -> relu1 of _split_separable_conv2d).
+ * in/out [B][C][h][w], weight [C][7][7]; taps accumulated row-major with fmaf, as the HIP kernel.
+ */
+void oracle_dwconv7x7_bn_relu_f32(const float *in, int B, int C, int h, int w, const float *weight,
+                                  const float *bias, const float *scale, const float *shift, int relu, float *out)
+{
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < B * C; ++p) {
+        int c = p % C;
+        const float *src = in + (long)p * h * w;
+        const float *wk = weight + (long)c * 49;
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                float acc = 0.0f;
+                for (int ky = 0; ky < 7; ++ky)
+                    for (int kx = 0; kx < 7; ++kx) {
+                        int yy = y + ky - 3, xx = x + kx - 3;
+                        float v = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? src[yy * w + xx] : 0.0f;
+                        acc = fmaf(v, wk[ky * 7 + kx], acc);
+                    }
+                float v = fmaf(acc + (bias ? bias[c] : 0.0f), scale ? scale[c] : 1.0f, shift ? shift[c] : 0.0f);
+                out[(long)p * h * w + y * w + x] = relu ? (v > 0.0f ? v : 0.0f) : v;
+            }
+    }
+}

@@ -61,6 +61,8 @@ def lib():
         L.oracle_correlation_forward_f32.argtypes = [_f32p, _f32p] + [_I] * 9 + [_f32p]
         L.oracle_upsample_argmax.restype = None
         L.oracle_upsample_argmax.argtypes = [_f32p, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int64), _i32p]
+        L.oracle_dwconv7x7_bn_relu_f32.restype = None
+        L.oracle_dwconv7x7_bn_relu_f32.argtypes = [_f32p, _I, _I, _I, _I, _f32p, _f32p, _f32p, _f32p, _I, _f32p]
         L.oracle_bf16_round.restype = ctypes.c_float
         L.oracle_bf16_round.argtypes = [ctypes.c_float]
         _lib = L
@@ -239,3 +241,16 @@ def upsample_argmax(logits, size):
     lib().oracle_upsample_argmax(_ptr(lg), n_ids, h, w, H, W, mask.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
                                  small.ctypes.data_as(_i32p))
     return mask[None], small[None, None]
+
+
+def dwconv7x7_bn_relu(x, weight, bias=None, scale=None, shift=None, relu=True):
+    """IntVOS.py:491-493,500-502 (conv1 -> bn1 -> relu1), BN folded to per-channel scale/shift."""
+    x = np.ascontiguousarray(_f32(x))
+    B, C, h, w = x.shape
+    wt = np.ascontiguousarray(_f32(weight)).reshape(C, 49)
+    opt = lambda a: None if a is None else _ptr(np.ascontiguousarray(_f32(a)))
+    keep = [np.ascontiguousarray(_f32(a)) if a is not None else None for a in (bias, scale, shift)]
+    out = np.empty_like(x)
+    lib().oracle_dwconv7x7_bn_relu_f32(_ptr(x), B, C, h, w, _ptr(wt), *[None if k is None else _ptr(k) for k in keep],
+                                       int(bool(relu)), _ptr(out))
+    return out
