@@ -20,10 +20,13 @@
  *   manet_correlation_forward_f32
  *                             correlation_package/correlation_cuda.cc:10-87 (pybind `forward`)
  *                             + correlation_cuda_kernel.cu:46-147.
+ *   manet_upsample_argmax     test.py:253-255 + networks/IntVOS.py:598-599
+ *   manet_dwconv7x7_bn_relu_f32  networks/IntVOS.py:491-493,500-502
  *
  * Status codes: 0 = ok; negative = error (see MANET_E_*); manet_last_error_string() gives the
  * text of the last error raised on the calling thread.
- * Thread-safety: all functions are re-entrant and keep no state between calls.
+ * Thread-safety: the data-path functions are re-entrant and keep no state between calls (the
+ * opt-in manet_profile_* / manet_tune_* hooks at the end are process-wide and not on the data path).
  */
 #ifndef MANET_HIP_H
 #define MANET_HIP_H
