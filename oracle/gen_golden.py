@@ -294,6 +294,16 @@ def variant_seg_head():
     save("seg_head_tiny", x=x, half=half, full=full, hx=hx, hout=hout, eps=blk.bn1.eps, **sd_b, **sd_h)
 
 
+def variant_config():
+    """flag names / defaults of the reference's config.py (config.py:17-80), as a JSON fixture"""
+    import json
+    torch, R = import_reference([])
+    d = {k: v for k, v in vars(R.cfg).items() if k != "ROOT_DIR"}
+    os.makedirs(OUT, exist_ok=True)
+    json.dump(d, open(os.path.join(OUT, "config_defaults.json"), "w"), indent=1, sort_keys=True)
+    print("wrote config_defaults", len(d))
+
+
 VARIANTS = {
     "global_tm1": lambda: variant_global(True),
     "global_tm0": lambda: variant_global(False),
@@ -304,6 +314,7 @@ VARIANTS = {
     "correlation": variant_correlation,
     "mask_step": variant_mask_step,
     "seg_head": variant_seg_head,
+    "config": variant_config,
 }
 
 if __name__ == "__main__":

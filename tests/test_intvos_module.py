@@ -218,3 +218,15 @@ def test_module_functions_on_gpu_match_reference():
     dist = M.local_pairwise_distances2(dev(g["cur_chw"]).permute(1, 2, 0), dev(g["prev_chw"]).permute(1, 2, 0),
                                        max_distance=int(g["d"]))
     np.testing.assert_allclose(dist.cpu().numpy(), g["dist"], rtol=1e-5, atol=2e-6)
+
+
+def test_cfg_defaults_equal_reference():
+    """same flag names and defaults as the reference's config.py:17-80 (fixture from oracle/gen_golden.py)"""
+    import json
+    import os
+    from conftest import GOLDEN
+    from cvpr2020_manet_amd.config import make_cfg
+    ref = json.load(open(os.path.join(GOLDEN, "config_defaults.json")))
+    mine = {k: v for k, v in vars(make_cfg([])).items() if k != "ROOT_DIR"}
+    assert mine == ref
+    assert make_cfg(["--TEST_MODE", "True", "--unknown-flag", "1"]).TEST_MODE is True
