@@ -55,10 +55,12 @@ def blob_labels(n_ids, shift, device):
     return lab
 
 
-def cpu_baseline(bank_rows, bank_lab, cur, prev, prev_lab):
+def cpu_baseline(bank_rows, bank_lab, cur, prev, prev_lab, gpu_global=None, gpu_local=None):
     """The CPU oracle (a C port of the reference path, kind="port") on the host cores, on a bounded
     sample of the same frame: a subset of query pixels against the FULL bank for the global match
-    (cost is linear in query pixels), the whole frame for the local match.  ~10-30 s."""
+    (cost is linear in query pixels), the whole frame for the local match.  ~10-30 s.
+    The oracle's outputs double as the parity check of the metric ("mask max-abs-err vs ref"): when the
+    GPU results of the same frame are passed in, their max abs deviation is returned as well."""
     from oracle import oracle as orc
     cores = os.cpu_count() or 1
     qry = cur.permute(1, 2, 0).cpu().numpy()
@@ -67,10 +69,12 @@ def cpu_baseline(bank_rows, bank_lab, cur, prev, prev_lab):
     ref3 = ref.reshape(-1, 1, C)
     N = H * W
 
+    last = {}
+
     def run(nq):
         q = np.ascontiguousarray(qry.reshape(-1, C)[:nq]).reshape(nq, 1, C)
         t0 = time.perf_counter()
-        orc.global_match(ref3, q, lab, 1, n_ids=N_IDS, test_mode=True)
+        last["raw"] = orc.global_match(ref3, q, lab, 1, n_ids=N_IDS, test_mode=True)
         return time.perf_counter() - t0
 
     probe_n = 4 * cores
@@ -81,13 +85,21 @@ def cpu_baseline(bank_rows, bank_lab, cur, prev, prev_lab):
     nq = max(nq, cores)
     t_glob = run(nq)
     t0 = time.perf_counter()
-    orc.local_match(prev.permute(1, 2, 0).cpu().numpy(), qry, prev_lab.cpu().numpy(), N_IDS, LOCAL_D)
+    loc = orc.local_match(prev.permute(1, 2, 0).cpu().numpy(), qry, prev_lab.cpu().numpy(), N_IDS, LOCAL_D)
     t_loc = time.perf_counter() - t0
     frame_s = t_glob / nq * N + t_loc
-    return {"value": 1.0 / frame_s, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "global match: %d of %d query pixels x full %d-row bank (%.1f s, scaled linearly); "
-                      "local match d=%d: whole frame (%.1f s); oracle/manet_oracle.c with OpenMP on %d threads"
-                      % (nq, N, ref.shape[0], t_glob, LOCAL_D, t_loc, cores)}
+    res = {"value": 1.0 / frame_s, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "global match: %d of %d query pixels x full %d-row bank (%.1f s, scaled linearly); "
+                     "local match d=%d: whole frame (%.1f s); oracle/manet_oracle.c with OpenMP on %d threads"
+                     % (nq, N, ref.shape[0], t_glob, LOCAL_D, t_loc, cores)}
+    parity = None
+    if gpu_global is not None:
+        want, _ = orc.normalize_merge(last["raw"].reshape(-1, N_IDS), None, normalize=True)
+        got = gpu_global.cpu().numpy()[:nq]
+        parity = {"global_map_max_abs_err": float(np.abs(got - want).max()), "global_pixels_checked": int(nq),
+                  "local_map_max_abs_err": float(np.abs(gpu_local.cpu().numpy() - loc.reshape(H, W, N_IDS)).max()),
+                  "reference": "CPU oracle (pinned to reference vectors), same frame, normalised maps"}
+    return res, parity
 
 
 def main():
@@ -268,7 +280,13 @@ def main():
                          "algorithmic_flops_per_launch": flops},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(bank_rows, bank_lab, frame_emb(0), frame_emb(1), prev_labs[0])
+            # the same frame once more on the GPU (fresh map, outside the timed region) for the parity figures
+            g_chk = ops.global_match(bank_rows, frame_emb(0).permute(1, 2, 0), bank_lab, N_IDS, normalize=True,
+                                     compute=args.compute)
+            l_chk = ops.local_match(frame_emb(1).permute(1, 2, 0), frame_emb(0).permute(1, 2, 0), prev_labs[0], N_IDS,
+                                    LOCAL_D)
+            line["cpu_baseline"], line["parity"] = cpu_baseline(bank_rows, bank_lab, frame_emb(0), frame_emb(1),
+                                                                prev_labs[0], g_chk, l_chk)
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None  # measured on rank 0 at N=1 only (see the N=1 line)
         print(json.dumps(line), flush=True)
