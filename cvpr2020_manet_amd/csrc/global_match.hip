@@ -370,6 +370,21 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict_
     }
 }
 
+// Workspace initialisation as a plain kernel.  (hipMemsetAsync nodes were observed to replay with the
+// wrong fill value from the second replay of a captured HIP graph on ROCm 7.2; a kernel node has no
+// such problem, and callers may capture a frame's launch sequence.)
+__global__ void fill32_kernel(unsigned *__restrict__ p, unsigned value, long n)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = value;
+}
+void fill32(void *p, unsigned value, size_t words, hipStream_t st)
+{
+    if (!words) return;
+    unsigned blocks = (unsigned)((words + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fill32_kernel, dim3(blocks), dim3(256), 0, st, (unsigned *)p, value, (long)words);
+}
+
 // order-preserving float -> uint key (so atomicMin on keys == min on floats, negatives included:
 // d may be slightly negative from rounding and must not be clamped)
 __device__ __forceinline__ unsigned key_of(float f)
@@ -974,8 +989,8 @@ int manet_bank_prepare(const float *bank, int64_t b_stride_m, int64_t b_stride_c
     int *meta = (int *)(ws + L.off_meta);
     int *hist = (int *)(ws + L.off_hist);
     int *src_of = (int *)(ws + L.off_src);
-    (void)hipMemsetAsync(meta, 0, META_INTS * sizeof(int), st);
-    (void)hipMemsetAsync(src_of, 0xff, (size_t)L.T_max * BT * sizeof(int), st);
+    fill32(meta, 0u, META_INTS, st);
+    fill32(src_of, 0xffffffffu, (size_t)L.T_max * BT, st);
     if (M0 > 0) {
         hipLaunchKernelGGL(label_hist_kernel, dim3((unsigned)L.nblocks), dim3(RPB), 0, st, labels, (long)M0, n_ids, hist);
         hipLaunchKernelGGL(label_scan_kernel, dim3((unsigned)n_ids), dim3(64), 0, st, hist, (int)L.nblocks, n_ids, meta);
@@ -1010,7 +1025,7 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
     char *mws = (char *)match_ws;
     const int *meta = (const int *)(bws + BL.off_meta);
     unsigned *keys = (unsigned *)(mws + ML.off_keys);
-    (void)hipMemsetAsync(keys, 0xff, (size_t)n_ids * ML.N_pad * sizeof(unsigned), st);
+    fill32(keys, 0xffffffffu, (size_t)n_ids * ML.N_pad, st);
     {
         size_t lds = (size_t)QB * (ML.G.kpad + 1) * sizeof(float) + QB * sizeof(int);
         hipLaunchKernelGGL(pack_rows_kernel<QB>, dim3((unsigned)(ML.N_pad / QB)), dim3(256), lds, st, query,
@@ -1030,7 +1045,7 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
     if (k_nn > 1) {
         // splits that own no tile never write their lists: start from "no candidate"
         size_t words = (size_t)TOPK_SPLITS * n_ids * ML.N_pad * MANET_MAX_KNN;
-        (void)hipMemsetAsync(topk, 0x7f, words * sizeof(float), st);  // 0x7f7f7f7f = 3.39e38 >= 1e20: invalid
+        fill32(topk, 0x7f7f7f7fu, words, st);  // 3.39e38 >= 1e20: invalid
     }
     if (compute != MANET_COMPUTE_F32) {
         const bool x3 = (compute == MANET_COMPUTE_BF16X3);

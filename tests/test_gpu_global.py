@@ -286,3 +286,37 @@ def test_full_size_properties_cfg2(ops):
         dm = d.masked_fill((lab != o)[None], float("inf")).min(dim=1).values
         # absolute: |d| ~ 0.1 and fp32 cancellation noise ~1e-7; relative bar of north_star is 1e-3
         assert torch.allclose(out[idx, o].double(), dm, rtol=1e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16", "bf16x3"])
+def test_run_to_run_determinism(ops, mode):
+    """atomicMin across bank splits and the stable bank sort make every mode bit-reproducible"""
+    q, k, lab = _case(61, 60, 80, 120, 80, 100, 3)
+    outs = [ops.global_match(chw_view(k), chw_view(q), dev(lab), 3, compute=mode) for _ in range(4)]
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+def test_hip_graph_capture_of_a_propagated_frame(ops):
+    """the C ABI never allocates or synchronises, so a frame's launch sequence can be captured in a HIP
+    graph by the caller and replayed (same results as eager)"""
+    q, k, lab = _case(62, 40, 50, 80, 50, 100, 3)
+    qv, kv, lv = chw_view(q), chw_view(k), dev(lab)
+    prev, plab = chw_view(k[:, :40, :]), dev(lab[:40])
+    mem = torch.ones(40 * 50, 3, device="cuda")
+    eager_g = ops.global_match(kv, qv, lv, 3, normalize=True, mem=mem.clone())
+    eager_l = ops.local_match(prev, qv, plab, 3, 4)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):  # warm the per-stream workspaces outside the capture
+        ops.global_match(kv, qv, lv, 3, normalize=True, mem=mem.clone())
+        ops.local_match(prev, qv, plab, 3, 4)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    gmem = mem.clone()
+    with torch.cuda.graph(graph, stream=s):
+        g = ops.global_match(kv, qv, lv, 3, normalize=True, mem=gmem)
+        l = ops.local_match(prev, qv, plab, 3, 4)
+    for _ in range(3):
+        gmem.fill_(1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g, eager_g) and torch.equal(l, eager_l)
