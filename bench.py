@@ -124,11 +124,19 @@ def main():
     # MANET_BENCH_BACKEND=gloo: dry run of the N>1 flow on fewer GPUs than ranks (ranks share devices)
     backend = os.environ.get("MANET_BENCH_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count()
-    if world > 1:
+    # MANET_BENCH_FORCE_DIST=1: take the collective code path even with one rank (exercises RCCL on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("MANET_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(dev_index)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            except TypeError:  # older signature without device_id
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group(backend)
     if args.gpus != world:
@@ -177,7 +185,7 @@ def main():
 
     def build_bank():
         """every rank gets the full bank (+ halo): ONE all-gather over RCCL when world > 1"""
-        if world > 1:
+        if use_dist:
             # the rank's slab needs the embeddings of the bank frames it owns
             owned = torch.stack([frame_emb(i) for i in range(n_local)]) if n_local <= 8 else None
             if owned is None:
@@ -212,7 +220,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -237,7 +245,7 @@ def main():
     kern_ms = float(np.mean([ms[i] for i in range(nrec.value)])) if nrec.value else float("nan")
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -289,8 +297,12 @@ def main():
                                                                 prev_labs[0], g_chk, l_chk)
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None  # measured on rank 0 at N=1 only (see the N=1 line)
+        try:  # RCCL writes a version banner through C stdio: flush it first so the JSON line comes last
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
