@@ -297,13 +297,14 @@ def main():
                                                                 prev_labs[0], g_chk, l_chk)
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None  # measured on rank 0 at N=1 only (see the N=1 line)
+    if use_dist:
+        dist.destroy_process_group()
+    if rank == 0:
         try:  # RCCL writes a version banner through C stdio: flush it first so the JSON line comes last
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
         print(json.dumps(line), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
