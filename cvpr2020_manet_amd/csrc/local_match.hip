@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void local_dist_kernel(const float *__restr
         if (active) {
             const float *ys = smem + (long)buf * buf_floats;
             const float *xs = ys + LD_CC * yplane;
-#pragma nounroll
+#pragma unroll 2
             for (int c = 0; c < LD_CC; ++c) {  // channels beyond C were staged as x = y = 0 (adds 0) / 1e20 (already inf)
                 const float *yrow = ys + c * yplane + (ry + dy) * CW + 2 * g;
                 const float2 xv = *(const float2 *)(xs + c * xplane + ry * LD_TX + 2 * g);
