@@ -16,9 +16,11 @@
 //     object id are dropped, which is what the reference's pixel selection / 1e20 mask amounts
 //     to).  Every 64-row bank tile then belongs to one object: no per-element label compare, and
 //     work shrinks with the number of labelled pixels.
-//   * the pre-pass writes the bank in the exact LDS image the MFMA loop wants ([k-group][k-parity]
-//     [row][4 k] floats, conflict-free ds_read_b128) so a tile is staged by linear, fully
-//     coalesced global_load_lds_dwordx4 (no VGPR round trip), double buffered, one barrier/tile.
+//   * the pre-pass writes the bank in the exact LDS image the MFMA loop wants ([16-byte unit][row]
+//     [4 floats | 8 bf16], conflict-free ds_read_b128) so a tile is staged by linear, fully coalesced
+//     16-byte loads, one tile-step ahead through registers, double buffered, one barrier per tile.
+//   * three arithmetic modes: fp32 MFMA (exact), bf16 MFMA on rounded embeddings, and split-bf16
+//     (hi+lo, three MFMAs: fp32-class accuracy); top-k (k_nn 2..8) as a variant of the fp32 kernel.
 //   * the 64 queries x C operand of a wave lives in registers for the whole kernel.
 //   * grid = (256-query tiles) x (S bank splits), split index tied to blockIdx % 8 so that the
 //     workgroups of one XCD stream the same bank range through that XCD's L2.  Splits combine by

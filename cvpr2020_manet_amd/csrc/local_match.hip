@@ -4,15 +4,18 @@
 // (local_previous_frame_nearest_neighbor_features_per_object; USE_CORRELATION_COST=False,
 // MODEL_UNFOLD=True -- the live configuration, IntVOS.py:15-16).
 //
-// This stage is HBM/latency bound (arithmetic intensity ~16 flop/B): the point is
-// to read each embedding once, coalesced along x out of the caller's C-major planes, and never
-// to build the reference's [1,C,h',w',(2d+1)^2] unfold tensor (1.6 GB at d=12).
+// HBM-bound at small windows (d=4: ~7 flop/B), VALU-bound at the reference's default d=12 (SURVEY.md
+// 8d): the point is to read each embedding once, coalesced along x out of the caller's C-major
+// planes, and never to build the reference's [1,C,h',w',(2d+1)^2] unfold tensor (1.6 GB at d=12).
 //   pool2x2_kernel      both frames -> [C][h'][w'] planes (2x2 mean; floor sizes)
-//   local_dist_kernel   thread = (pixel, window row): (2d+1) running sums over C of (x - y)^2,
-//                       direct form as the reference (no |x|^2+|y|^2-2xy cancellation);
-//                       out-of-image neighbours are the reference's 1e20 padding -> inf -> 1.0
-//   local_min_kernel    thread = full-resolution pixel: bilinear (align_corners) sample of the
-//                       pooled, normalised volume + stride-2 label gather + masked min per object
+//   local_dist_kernel<D> workgroup = rows x 16 columns of the (pooled) grid; the previous frame's halo
+//                       tile goes through LDS in channel stages, a thread slides a 2-column window over
+//                       one window row: 2 x (2d+1) running sums over C of (x - y)^2, direct form as the
+//                       reference (no |x|^2+|y|^2-2xy cancellation); out-of-image neighbours are the
+//                       reference's 1e20 padding -> inf -> 1.0 after normalisation
+//   local_min_kernel    64 full-resolution pixels x 8 waves: bilinear (align_corners) sample of the
+//                       pooled, normalised volume + stride-2 label gather + masked min per object;
+//                       waves split the window rows, partial minima meet in LDS
 //   local_upsample_kernel  only for the stand-alone local_pairwise_distances2 API
 #include "manet_common.h"
 

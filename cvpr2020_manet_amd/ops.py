@@ -50,11 +50,6 @@ def _labels(t, name):
     return t.reshape(-1).to(torch.int32).contiguous()
 
 
-def _size_t():
-    import ctypes
-    return ctypes.c_size_t(0)
-
-
 def global_match(reference_embeddings, query_embeddings, reference_labels, n_ids, k_nearest_neighbors=1,
                  compute="f32", normalize=False, mem=None):
     """nearest_neighbor_features_per_object on the HIP path (IntVOS.py:160-210), optionally with the
