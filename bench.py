@@ -21,6 +21,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -102,6 +104,22 @@ def cpu_baseline(bank_rows, bank_lab, cur, prev, prev_lab, gpu_global=None, gpu_
     return res, parity
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU,
+    torch.distributed.run, rendezvous on 127.0.0.1) and relay rank 0's JSON line.  Called BEFORE anything
+    in this process touches the GPU -- a process that has initialised HIP must never exec or be the
+    parent that matters; this parent only waits and passes the exit code on."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,13 +134,24 @@ def main():
                          "5 = 720p T=10 6 ids d=4")
     args = ap.parse_args()
 
+    # MANET_BENCH_BACKEND=gloo: dry run of the N>1 flow on fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("MANET_BENCH_BACKEND", "nccl")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: become the launcher (no GPU call has happened in this process)
+        n_dev = torch.cuda.device_count()  # counting devices does not initialise HIP
+        if backend == "nccl" and n_dev < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (one rank per GPU over RCCL)"
+                             % (args.gpus, n_dev))
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the matching path has no CPU fallback")
-    # MANET_BENCH_BACKEND=gloo: dry run of the N>1 flow on fewer GPUs than ranks (ranks share devices)
-    backend = os.environ.get("MANET_BENCH_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count()
     # MANET_BENCH_FORCE_DIST=1: take the collective code path even with one rank (exercises RCCL on a 1-GPU box)
     use_dist = world > 1 or os.environ.get("MANET_BENCH_FORCE_DIST") == "1"
@@ -139,9 +168,6 @@ def main():
                 dist.init_process_group("nccl")
         else:
             dist.init_process_group(backend)
-    if args.gpus != world:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
 

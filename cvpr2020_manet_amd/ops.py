@@ -21,6 +21,21 @@ def _need_gpu(t, name):
                            "(the matching path has no CPU fallback)" % name)
 
 
+def _refuse_autograd(what, *tensors):
+    """The HIP ops below hand raw pointers to the C ABI and return tensors without a grad_fn.  The
+    reference's functions are differentiable (train_stage1.py:126-156 back-propagates through them), so
+    silently detaching would train the heads with zero gradient through the match maps: raise instead.
+    Ops that do have a backward (`global_match`, `local_match`, `correlation_forward`) route through their
+    torch.autograd.Function in cvpr2020_manet_amd.autograd before they get here."""
+    if not torch.is_grad_enabled():
+        return
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.requires_grad:
+            raise RuntimeError("cvpr2020_manet_amd.ops.%s: an input requires grad, but this op has no "
+                               "backward -- call it under torch.no_grad() or detach the input "
+                               "(gradients would otherwise be dropped silently)" % what)
+
+
 def _stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -58,6 +73,7 @@ def global_match(reference_embeddings, query_embeddings, reference_labels, n_ids
     Returns float32 [N, n_ids] (N = number of query pixels), raw or normalised distances.
     """
     import ctypes
+    _refuse_autograd("global_match", reference_embeddings, query_embeddings, mem)
     lib = _lib.load()
     ref, M0, C = _flat(reference_embeddings, "reference_embeddings")
     qry, N, C2 = _flat(query_embeddings, "query_embeddings")
@@ -98,6 +114,7 @@ class PreparedBank:
 
     def __init__(self, reference_embeddings, reference_labels, n_ids, compute="f32"):
         import ctypes
+        _refuse_autograd("PreparedBank", reference_embeddings)
         lib = _lib.load()
         ref, M0, C = _flat(reference_embeddings, "reference_embeddings")
         lab = _labels(reference_labels, "reference_labels")
@@ -118,6 +135,7 @@ class PreparedBank:
 
     def match(self, query_embeddings, k_nearest_neighbors=1, normalize=False, mem=None, out=None):
         import ctypes
+        _refuse_autograd("PreparedBank.match", query_embeddings, mem)
         lib = _lib.load()
         qry, N, C = _flat(query_embeddings, "query_embeddings")
         if C != self.C:
@@ -151,6 +169,7 @@ class PreparedBank:
 def normalize_merge_(x, mem=None, normalize=True):
     """In place: x = (sigmoid(x)-0.5)*2 if normalize; if mem: x = mem = min(x, mem)
     (IntVOS.py:611-612, :620-622, :718-723)."""
+    _refuse_autograd("normalize_merge_", x, mem)
     lib = _lib.load()
     _need_gpu(x, "x")
     if x.dtype != torch.float32 or not x.is_contiguous():
@@ -179,6 +198,7 @@ def local_dist(x, y, max_distance, downsample=True):
     """local_pairwise_distances2(x=query, y=prev) (IntVOS.py:266-315) -> [h, w, (2d+1)^2]."""
     import ctypes
     lib = _lib.load()
+    _refuse_autograd("local_dist", x, y)
     x = _hwc(x, "x")
     y = _hwc(y, "y")
     h, w, C = x.shape
@@ -205,6 +225,7 @@ def local_match(prev_frame_embedding, query_embedding, prev_frame_labels, n_ids,
     """local_previous_frame_nearest_neighbor_features_per_object (IntVOS.py:345-434) -> [h, w, n_ids]."""
     import ctypes
     lib = _lib.load()
+    _refuse_autograd("local_match", prev_frame_embedding, query_embedding)
     prev = _hwc(prev_frame_embedding, "prev_frame_embedding")
     cur = _hwc(query_embedding, "query_embedding")
     h, w, C = cur.shape
@@ -241,6 +262,7 @@ def correlation_out_dims(H, W, pad_size, kernel_size, max_displacement, stride1,
 def correlation_forward(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2):
     """correlation_cuda.forward (correlation_cuda.cc:10-87) -> [B, (2r+1)^2, outH, outW] fp32."""
     lib = _lib.load()
+    _refuse_autograd("correlation_forward", input1, input2)
     _need_gpu(input1, "input1")
     _need_gpu(input2, "input2")
     a = input1.float().contiguous()
@@ -265,6 +287,7 @@ def upsample_argmax(logits, size, want_small=True):
     frame's previous-frame label (IntVOS.py:598-599) -> int32 [1, 1, h, w] (None if not wanted)."""
     lib = _lib.load()
     _need_gpu(logits, "logits")
+    # integer outputs (argmax): nothing to differentiate, same as the reference's torch.argmax
     if logits.dim() != 4 or logits.shape[0] != 1:
         raise ValueError("logits must be [1, n_ids, h, w]")
     lg = logits.float().contiguous()
@@ -293,6 +316,7 @@ def dwconv7x7_bn_relu(x, weight, bias=None, bn=None, relu=True, scale=None, shif
     (IntVOS.py:491-493,500-502: conv1 -> bn1 -> relu1 of _split_separable_conv2d).
     x [B, C, h, w] fp32; weight [C, 1, 7, 7]; bn: an nn.BatchNorm2d in eval mode, or explicit per-channel
     `scale` / `shift` (fold_bn), or neither."""
+    _refuse_autograd("dwconv7x7_bn_relu", x, weight, bias, scale, shift)  # callers use it under no_grad only
     lib = _lib.load()
     _need_gpu(x, "x")
     x = x.float().contiguous()
