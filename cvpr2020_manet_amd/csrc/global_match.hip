@@ -41,18 +41,30 @@ constexpr int META_T = 0;          // [0]        number of bank tiles actually u
 constexpr int META_SEG = 1;        // [1..65]    first tile of object o (entry n_ids = T)
 constexpr int META_CNT = 130;      // [130..193] rows per object
 
-// Packed operand image of one row block: `units` 16-byte units per row, stored [unit][row][16 B],
-// then the rows' squared norms (fp32).
+// Packed operand image of one row block: `units` 16-byte units per row, stored [unit][row][16 B].
 //   f32    unit u = 2g+h holds k = 8g + 2j + h, j = 0..3 (4 floats)      -> v_mfma_f32_32x32x2_f32
+//          followed by the rows' squared norms (fp32)
 //   bf16   unit u = 2s+h holds k = 16s + 8h + e, e = 0..7 (8 bf16)        -> v_mfma_f32_32x32x16_bf16
+//          no norm block: the norms ride in the spare k slots C..C+5 of the image itself (below)
 //   bf16x3 the bf16 image of hi = bf16(x), then the image of lo = bf16(x - hi)
-__host__ __device__ constexpr size_t bank_tile_bytes_u(int units)
+//
+// bf16 images: d(n,m) = |q|^2 + |k|^2 - 2 q.k comes out of the MFMA chain itself, accumulator
+// starting at 0, no per-element epilogue arithmetic:
+//   query rows hold  -2*bf16(q)  (exact: a power of two)          bank rows hold  bf16(k)
+//   query k = C+0..2 : 1, 1, 1                                      bank k = C+0..2 : |k|^2 as hi+mid+lo
+//   query k = C+3..5 : |q|^2 as hi+mid+lo (three bf16 = 24 bits)    bank k = C+3..5 : 1, 1, 1
+// (three bf16 pieces carry an fp32 value exactly; the products with 1 are exact, the sum is fp32.)
+constexpr int BF16_SPECIAL = 6;  // spare k slots needed behind the C channels
+__host__ __device__ constexpr size_t bank_tile_bytes_u(int units, bool norms)
 {
-    return ((size_t)units * BT * 16 + BT * 4 + 1023) / 1024 * 1024;  // whole 1 KiB global_load_lds pieces
+    return ((size_t)units * BT * 16 + (norms ? BT * 4 : 0) + 1023) / 1024 * 1024;  // whole 1 KiB LDS-DMA pieces
 }
-__host__ __device__ constexpr size_t query_block_bytes_u(int units) { return (size_t)units * QB * 16 + QB * 4; }
-__host__ __device__ constexpr size_t bank_tile_bytes(int NG) { return bank_tile_bytes_u(2 * NG); }
-__host__ __device__ constexpr size_t query_block_bytes(int NG) { return query_block_bytes_u(2 * NG); }
+__host__ __device__ constexpr size_t query_block_bytes_u(int units, bool norms)
+{
+    return (size_t)units * QB * 16 + (norms ? QB * 4 : 0);
+}
+__host__ __device__ constexpr size_t bank_tile_bytes(int NG) { return bank_tile_bytes_u(2 * NG, true); }
+__host__ __device__ constexpr size_t query_block_bytes(int NG) { return query_block_bytes_u(2 * NG, true); }
 
 // number of v_mfma_f32_32x32x2 k-steps (2 k each) the f32 kernel is instantiated for
 int pick_ks(int C)
@@ -62,13 +74,15 @@ int pick_ks(int C)
     if (C <= 104) return 52;
     return 64;
 }
-// number of v_mfma_f32_32x32x16_bf16 k-steps (16 k each) the bf16 kernels are instantiated for
+// number of v_mfma_f32_32x32x16_bf16 k-steps (16 k each) the bf16 kernels are instantiated for:
+// C channels + BF16_SPECIAL norm slots
 int pick_ksb(int C)
 {
-    if (C <= 32) return 2;
-    if (C <= 112) return 7;
-    return 8;
+    if (C + BF16_SPECIAL <= 32) return 2;
+    if (C + BF16_SPECIAL <= 112) return 7;   // C = 100: 7 MFMAs per 32x32 block
+    return 9;
 }
+constexpr int QT_BF16 = 512;  // queries per workgroup of the bf16 kernels (8 waves x 64)
 
 struct Geom {
     int compute;
@@ -94,10 +108,11 @@ Geom geom_of(int C, int compute)
         G.units = 2 * G.steps * (compute == MANET_COMPUTE_BF16X3 ? 2 : 1);
         G.kpad = 16 * G.steps;
         // 8 waves: the bf16 MFMA eats a bank tile 14x faster, so share it between more queries
-        G.qt = (manet_tune_get(MANET_TUNE_BF16_VARIANT, 0) == 1) ? 256 : 512;
+        G.qt = QT_BF16;
     }
-    G.tile_bytes = bank_tile_bytes_u(G.units);
-    G.qblk_bytes = query_block_bytes_u(G.units);
+    const bool norms = (compute == MANET_COMPUTE_F32);
+    G.tile_bytes = bank_tile_bytes_u(G.units, norms);
+    G.qblk_bytes = query_block_bytes_u(G.units, norms);
     return G;
 }
 
@@ -282,25 +297,43 @@ __device__ __forceinline__ unsigned f2bf(float x)
 }
 __device__ __forceinline__ float bf2f(unsigned b) { return __uint_as_float(b << 16); }
 
-// bank (ROWS = 64) and query (ROWS = 32) pack: rows -> MFMA operand image (see Geom), then |row|^2.
+// an fp32 value as three bf16 pieces, p0 + p1 + p2 == x exactly (3 x 8 significand bits)
+__device__ __forceinline__ void split3_bf16(float x, unsigned (&p)[3])
+{
+    p[0] = f2bf(x);
+    float r = x - bf2f(p[0]);
+    p[1] = f2bf(r);
+    r = r - bf2f(p[1]);
+    p[2] = f2bf(r);
+}
+
+// embedding element types the pack kernels read (the producer's storage):
+// float, or bf16 as raw 16-bit words
+__device__ __forceinline__ float emb_load(const float *p, long i) { return p[i]; }
+__device__ __forceinline__ float emb_load(const unsigned short *p, long i) { return bf2f(p[i]); }
+
+// bank (ROWS = 64) and query (ROWS = 32) pack: rows -> MFMA operand image (see Geom).
 // Rows are staged through LDS so that both the global reads (along k for row-major sources, along
 // rows for C-major sources) and the 16-byte image writes are coalesced.  |row|^2 is the k-ascending
 // fmaf chain of the oracle (IntVOS.py:32,35) -- over the bf16-rounded values in MANET_COMPUTE_BF16
 // (the path then IS the reference formula on rounded embeddings), over the fp32 values otherwise.
-template <int ROWS>
-__global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict__ src, long s_row,
+// f32 images carry the norms in a trailing block; bf16 images carry them in the spare k slots (Geom).
+template <int ROWS, typename SRC>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const SRC *__restrict__ src, long s_row,
                                                         long s_c, const int *__restrict__ src_of,
                                                         const int *__restrict__ meta, long n_rows,
                                                         int C, int compute, int units, int kpad,
                                                         char *__restrict__ dst, long tile_bytes,
                                                         float pad_norm)
 {
+    constexpr bool IS_QUERY = (ROWS == QB);
     const long tile = blockIdx.x;
     if (meta && tile >= meta[META_T]) return;
     extern __shared__ __attribute__((aligned(16))) char pack_smem[];
     const int KP = kpad + 1;  // odd row stride: column reads are conflict-free
     float *rows = (float *)pack_smem;                  // [ROWS][KP]
     int *s_src = (int *)(rows + (long)ROWS * KP);      // [ROWS]
+    float *s_norm = (float *)(s_src + ROWS);           // [ROWS]
     const int tid = threadIdx.x;
     if (tid < ROWS) {
         long slot = tile * ROWS + tid;
@@ -311,13 +344,13 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict_
         for (int idx = tid; idx < ROWS * C; idx += 256) {
             int r = idx / C, k = idx - r * C;
             int sr = s_src[r];
-            rows[r * KP + k] = (sr >= 0) ? src[(long)sr * s_row + k] : 0.0f;
+            rows[r * KP + k] = (sr >= 0) ? emb_load(src, (long)sr * s_row + k) : 0.0f;
         }
     } else {  // C-major (or generic) source: lanes along rows
         for (int idx = tid; idx < ROWS * C; idx += 256) {
             int k = idx / ROWS, r = idx - k * ROWS;
             int sr = s_src[r];
-            rows[r * KP + k] = (sr >= 0) ? src[(long)sr * s_row + (long)k * s_c] : 0.0f;
+            rows[r * KP + k] = (sr >= 0) ? emb_load(src, (long)sr * s_row + (long)k * s_c) : 0.0f;
         }
     }
     for (int idx = tid; idx < ROWS * (kpad - C); idx += 256) {
@@ -325,35 +358,6 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict_
         rows[r * KP + k] = 0.0f;
     }
     __syncthreads();
-    char *out = dst + tile * tile_bytes;
-    if (compute == MANET_COMPUTE_F32) {
-        for (int item = tid; item < units * ROWS; item += 256) {
-            int r = item % ROWS, u = item / ROWS;
-            const float *row = rows + r * KP + 8 * (u >> 1) + (u & 1);
-            f32x4 v = {row[0], row[2], row[4], row[6]};
-            *(f32x4 *)(out + ((long)u * ROWS + r) * 16) = v;
-        }
-    } else {
-        const int hi_units = (compute == MANET_COMPUTE_BF16X3) ? units / 2 : units;
-        for (int item = tid; item < units * ROWS; item += 256) {
-            int r = item % ROWS, u = item / ROWS;
-            const bool lo = u >= hi_units;
-            const int uu = lo ? u - hi_units : u;
-            const float *row = rows + r * KP + 16 * (uu >> 1) + 8 * (uu & 1);
-            unsigned w[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x0 = row[2 * e], x1 = row[2 * e + 1];
-                unsigned b0 = f2bf(x0), b1 = f2bf(x1);
-                if (lo) {
-                    b0 = f2bf(x0 - bf2f(b0));
-                    b1 = f2bf(x1 - bf2f(b1));
-                }
-                w[e] = b0 | (b1 << 16);
-            }
-            *(uint4 *)(out + ((long)u * ROWS + r) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-    }
     if (tid < ROWS) {
         float n = pad_norm;
         if (s_src[tid] >= 0) {
@@ -368,7 +372,50 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict_
                 for (int k = 0; k < C; ++k) n = fmaf(row[k], row[k], n);
             }
         }
-        *(float *)(out + (long)units * ROWS * 16 + tid * 4) = n;
+        s_norm[tid] = n;
+    }
+    __syncthreads();
+    char *out = dst + tile * tile_bytes;
+    if (compute == MANET_COMPUTE_F32) {
+        for (int item = tid; item < units * ROWS; item += 256) {
+            int r = item % ROWS, u = item / ROWS;
+            const float *row = rows + r * KP + 8 * (u >> 1) + (u & 1);
+            f32x4 v = {row[0], row[2], row[4], row[6]};
+            *(f32x4 *)(out + ((long)u * ROWS + r) * 16) = v;
+        }
+        if (tid < ROWS) *(float *)(out + (long)units * ROWS * 16 + tid * 4) = s_norm[tid];
+    } else {
+        const int hi_units = (compute == MANET_COMPUTE_BF16X3) ? units / 2 : units;
+        const float scale = IS_QUERY ? -2.0f : 1.0f;  // the query operand is -2q (exact in bf16)
+        for (int item = tid; item < units * ROWS; item += 256) {
+            int r = item % ROWS, u = item / ROWS;
+            const bool lo = u >= hi_units;
+            const int uu = lo ? u - hi_units : u;
+            const int k0 = 16 * (uu >> 1) + 8 * (uu & 1);
+            const float *row = rows + r * KP + k0;
+            unsigned e8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = row[e];
+                unsigned b = f2bf(x);
+                if (lo) b = f2bf(x - bf2f(b));
+                e8[e] = f2bf(scale * bf2f(b));
+            }
+            if (k0 + 8 > C && k0 < C + BF16_SPECIAL) {  // this unit holds norm slots (see Geom)
+                unsigned piece[3];
+                split3_bf16(s_norm[r], piece);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int j = k0 + e - C;  // 0..2: bank norm / query ones, 3..5: bank ones / query norm
+                    if (j >= 0 && j < BF16_SPECIAL) {
+                        const bool norm_slot = IS_QUERY ? (j >= 3) : (j < 3);
+                        e8[e] = lo ? 0u : (norm_slot ? piece[j % 3] : 0x3f80u);
+                    }
+                }
+            }
+            *(uint4 *)(out + ((long)u * ROWS + r) * 16) =
+                make_uint4(e8[0] | (e8[1] << 16), e8[2] | (e8[3] << 16), e8[4] | (e8[5] << 16), e8[6] | (e8[7] << 16));
+        }
     }
 }
 
@@ -389,15 +436,40 @@ void fill32(void *p, unsigned value, size_t words, hipStream_t st)
 
 // order-preserving float -> uint key (so atomicMin on keys == min on floats, negatives included:
 // d may be slightly negative from rounding and must not be clamped)
+// NaN -> key 0: it wins every atomicMin and float_of(0) is a NaN again, so a NaN distance propagates
+// to the output like torch.min does (IntVOS.py:84).
 __device__ __forceinline__ unsigned key_of(float f)
 {
     unsigned u = __float_as_uint(f);
+    if (f != f) return 0u;
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ float float_of(unsigned k)
 {
     unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
     return __uint_as_float(u);
+}
+
+// LDS-DMA of one 1 KiB piece: lane l's 16 bytes at `gsrc` land at LDS byte address lds_dst + 16 l.
+// Issued from inline asm on purpose: hipcc cannot tell the DMA's LDS destination from the ds_reads of the
+// OTHER staging buffer and would drain vmcnt(0) in front of them, which serialises the prefetch (r1).
+// Hidden in asm, the compiler does not count these loads; the kernel does (one s_waitcnt vmcnt(0) per
+// step, right before the barrier that publishes the buffer).  M0 (the DMA's LDS base) is saved/restored
+// inside the statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// NaN-propagating minimum (v_minimum3_f32 on gfx950): torch.min semantics, and -- unlike fminf on an MFMA
+// result -- needs no canonicalising v_max in front of it.
+__device__ __forceinline__ float min3p(float m, float a, float b)
+{
+    return __builtin_elementwise_minimum(__builtin_elementwise_minimum(m, a), b);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -512,8 +584,8 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
 
     auto flush = [&](int obj) {
         if (KNN == 1) {
-            float a = fminf(m0[0], __shfl_xor(m0[0], 32));
-            float c = fminf(m1[0], __shfl_xor(m1[0], 32));
+            float a = min3p(m0[0], m0[0], __shfl_xor(m0[0], 32));
+            float c = min3p(m1[0], m1[0], __shfl_xor(m1[0], 32));
             if (h == 0) {
                 atomicMin(keys + (size_t)obj * N_pad + qbase, key_of(a));
                 atomicMin(keys + (size_t)obj * N_pad + qbase + 32, key_of(c));
@@ -587,9 +659,9 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
                 const float d01 = fmaf(-2.0f, c01[r], xs1 + y0[i]);
                 const float d10 = fmaf(-2.0f, c10[r], xs0 + y1[i]);
                 const float d11 = fmaf(-2.0f, c11[r], xs1 + y1[i]);
-                if (KNN == 1) {
-                    m0[0] = fminf(m0[0], fminf(d00, d10));
-                    m1[0] = fminf(m1[0], fminf(d01, d11));
+                if (KNN == 1) {  // NaN-propagating, like torch.min (IntVOS.py:84)
+                    m0[0] = min3p(m0[0], d00, d10);
+                    m1[0] = min3p(m1[0], d01, d11);
                 } else {
                     topk_insert<KNN>(m0, d00);
                     topk_insert<KNN>(m0, d10);
@@ -604,26 +676,35 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
 
 // ---------------------------------------------------------------------------------------------
 // main kernel, bf16 operands (MANET_COMPUTE_BF16 / _BF16X3): one workgroup = 512 queries x one bank
-// split, 8 waves.  Same structure as the f32 kernel (swapped operands, object-pure 64-row tiles,
-// lane-local running min, double-buffered global_load_lds staging, atomicMin across splits); the
-// contraction is v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+// split, 8 waves.  Same decomposition as the f32 kernel (swapped operands, object-pure 64-row tiles,
+// lane-local running min, atomicMin across splits); the contraction is v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation:
 //   X3 = false: one MFMA per 16 k on embeddings rounded to bf16 (7 instead of 50 MFMAs per block at C=100)
 //   X3 = true : hi*hi + hi*lo + lo*hi with x = hi + lo, hi = bf16(x), lo = bf16(x - hi): the dropped
 //               lo*lo term is <= 2^-16 relative, i.e. fp32-class distances at 3/16 of the f32 MFMA cost.
-template <int KSB, bool X3, int NW, int TPS>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void global_match_bf16_kernel(const char *__restrict__ qpack,
-                                                                const char *__restrict__ bpack,
-                                                                const int *__restrict__ meta, int n_ids,
-                                                                int nQT, int S, long N_pad,
-                                                                unsigned *__restrict__ keys, int block_map)
+// The operand images carry -2q and both squared norms (see Geom), so an accumulator element IS
+// d(n, m) = |q|^2 + |k|^2 - 2 q.k when the k loop ends: the epilogue is ONE v_minimum3_f32 per two
+// elements (r1: add + fma + min per element = 6x the VALU work, 0.32 of 0.68 ms).
+// Staging: TPS tiles per step, double buffered in LDS; DMA = true: asm LDS-DMA (no VGPR round trip, no
+// ds_write pass, the loads of step s+1 fly during the whole of step s); DMA = false: r1's register staging.
+template <int KSB, bool X3, int TPS, bool DMA>
+__global__ __launch_bounds__(512, 1) void global_match_bf16_kernel(const char *__restrict__ qpack,
+                                                                   const char *__restrict__ bpack,
+                                                                   const int *__restrict__ meta, int n_ids,
+                                                                   int nQT, int S, long N_pad,
+                                                                   unsigned *__restrict__ keys, int block_map,
+                                                                   int young_prio)
 {
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    constexpr int NW = 8;
     constexpr int UNITS = 2 * KSB * (X3 ? 2 : 1);
     constexpr int LO = 2 * KSB;  // first unit of the lo image
-    constexpr size_t TILE_BYTES = bank_tile_bytes_u(UNITS);
-    constexpr size_t QBLK_BYTES = query_block_bytes_u(UNITS);
+    constexpr size_t TILE_BYTES = bank_tile_bytes_u(UNITS, false);  // = UNITS KiB
+    constexpr size_t QBLK_BYTES = query_block_bytes_u(UNITS, false);
+    constexpr size_t STEP_BYTES = TILE_BYTES * TPS;
     constexpr int QTB = NW * 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x TPS x TILE_BYTES
+    static_assert(TILE_BYTES == (size_t)UNITS * 1024, "a bf16 tile is a whole number of 1 KiB DMA pieces");
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x STEP_BYTES
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -647,71 +728,86 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void global_match_bf16_ke
     const int t1 = (int)((long)(s + 1) * T / S);
     if (t0 >= t1) return;
 
-    // register staging (see the f32 kernel) of one STEP = TPS consecutive tiles: one barrier per step
+    // ---- staging of one STEP = TPS consecutive tiles ------------------------------------------------
+    constexpr int PIECES = UNITS * TPS;  // 1 KiB pieces per step
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+    auto stage_dma = [&](int t, int slot) __attribute__((always_inline)) {
+        const int np = ((t1 - t) < TPS ? (t1 - t) : TPS) * UNITS;  // the split's last step may be short
+        const char *g = bpack + (size_t)t * TILE_BYTES + (size_t)lane * 16;
+        const unsigned l = smem_base + (unsigned)slot * (unsigned)STEP_BYTES;
+#pragma unroll
+        for (int i = 0; i < (PIECES + NW - 1) / NW; ++i) {
+            const int pc = wave + i * NW;  // wave-uniform
+            if (pc < np) lds_dma16(g + (size_t)pc * 1024, l + (unsigned)pc * 1024u);
+        }
+    };
     constexpr int NV = (int)(TILE_BYTES / 16) * TPS;
-    constexpr int NLD = (NV + NW * 64 - 1) / (NW * 64);
+    constexpr int NLD = DMA ? 1 : (NV + NW * 64 - 1) / (NW * 64);
     constexpr int NTHR = NW * 64;
-    constexpr size_t STEP_BYTES = TILE_BYTES * TPS;
     u32x4 Ra[NLD];
-    // loads of a step's last partial tile group are clamped into the split's own range
-#define MANET_GLOAD_STEP(R_, t_)                                                                    \
-    {                                                                                               \
-        const u32x4 *g_ = (const u32x4 *)(bpack + (size_t)(t_) * TILE_BYTES);                       \
-        const int lim_ = ((t1 - (t_)) < TPS ? (t1 - (t_)) : TPS) * (int)(TILE_BYTES / 16);          \
-        _Pragma("unroll") for (int i_ = 0; i_ < NLD; ++i_)                                          \
-        {                                                                                           \
-            const int idx_ = i_ * NTHR + tid;                                                       \
-            R_[i_] = g_[idx_ < lim_ ? idx_ : lim_ - 1];                                             \
-        }                                                                                           \
-    }
-#define MANET_LSTORE_STEP(R_, slot_)                                                                \
-    {                                                                                               \
-        u32x4 *l_ = (u32x4 *)(smem + (size_t)(slot_) * STEP_BYTES);                                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < NLD; ++i_)                                          \
-            if (i_ * NTHR + tid < NV) l_[i_ * NTHR + tid] = R_[i_];                                 \
-    }
-    MANET_GLOAD_STEP(Ra, t0);
+    auto gload = [&](int t) __attribute__((always_inline)) {
+        const u32x4 *g_ = (const u32x4 *)(bpack + (size_t)t * TILE_BYTES);
+        const int lim_ = ((t1 - t) < TPS ? (t1 - t) : TPS) * (int)(TILE_BYTES / 16);
+#pragma unroll
+        for (int i_ = 0; i_ < NLD; ++i_) {
+            const int idx_ = i_ * NTHR + tid;
+            Ra[i_] = g_[idx_ < lim_ ? idx_ : lim_ - 1];  // clamped into the split's own range
+        }
+    };
+    auto lstore = [&](int slot) __attribute__((always_inline)) {
+        u32x4 *l_ = (u32x4 *)(smem + (size_t)slot * STEP_BYTES);
+#pragma unroll
+        for (int i_ = 0; i_ < NLD; ++i_)
+            if (i_ * NTHR + tid < NV) l_[i_ * NTHR + tid] = Ra[i_];
+    };
+    if (DMA) stage_dma(t0, 0);
+    else gload(t0);
 
-    // B operand: lane holds q[j = lane&31][k = 16s + 8*(lane>>5) + 0..7] for its two query blocks
-    uint4 q0[KSB], q1[KSB], q0l[X3 ? KSB : 1], q1l[X3 ? KSB : 1];
-    float xs0, xs1;
+    // B operand: lane holds (-2q | norm slots)[j = lane&31][k = 16s + 8*(lane>>5) + 0..7] for its two blocks
+    u32x4 q0[KSB], q1[KSB], q0l[X3 ? KSB : 1], q1l[X3 ? KSB : 1];
     {
         const char *qb0 = qpack + (size_t)(qt * (QTB / QB) + wave * 2) * QBLK_BYTES;
         const char *qb1 = qb0 + QBLK_BYTES;
 #pragma unroll
         for (int k = 0; k < KSB; ++k) {
-            q0[k] = *(const uint4 *)(qb0 + ((size_t)(k * 2 + h) * QB + l31) * 16);
-            q1[k] = *(const uint4 *)(qb1 + ((size_t)(k * 2 + h) * QB + l31) * 16);
+            q0[k] = *(const u32x4 *)(qb0 + ((size_t)(k * 2 + h) * QB + l31) * 16);
+            q1[k] = *(const u32x4 *)(qb1 + ((size_t)(k * 2 + h) * QB + l31) * 16);
             if (X3) {
-                q0l[k] = *(const uint4 *)(qb0 + ((size_t)(LO + k * 2 + h) * QB + l31) * 16);
-                q1l[k] = *(const uint4 *)(qb1 + ((size_t)(LO + k * 2 + h) * QB + l31) * 16);
+                q0l[k] = *(const u32x4 *)(qb0 + ((size_t)(LO + k * 2 + h) * QB + l31) * 16);
+                q1l[k] = *(const u32x4 *)(qb1 + ((size_t)(LO + k * 2 + h) * QB + l31) * 16);
             }
         }
-        xs0 = *(const float *)(qb0 + (size_t)UNITS * QB * 16 + l31 * 4);
-        xs1 = *(const float *)(qb1 + (size_t)UNITS * QB * 16 + l31 * 4);
     }
     const long qbase = (long)qt * QTB + wave * 64 + l31;
+    // Make the compiler wait for the query operand HERE.  Otherwise its counted vmcnt waits for these
+    // loads sink into the tile loop (down to vmcnt(0)), where they would also drain the asm LDS-DMA of the
+    // next step that the compiler does not know about.
+#pragma unroll
+    for (int k = 0; k < KSB; ++k) {
+        asm volatile("" : "+v"(q0[k]), "+v"(q1[k]));
+        if (X3) asm volatile("" : "+v"(q0l[k]), "+v"(q1l[k]));
+    }
 
     int o = 0;
     while (meta[META_SEG + o + 1] <= t0) ++o;
     int seg_end = meta[META_SEG + o + 1];
-    float m0 = MANET_WRONG_LABEL_PADDING_DISTANCE, m1 = MANET_WRONG_LABEL_PADDING_DISTANCE;
+    // two running minima per query block (even / odd accumulator registers): short dependency chains
+    float m0a, m0b, m1a, m1b;
+    m0a = m0b = m1a = m1b = MANET_WRONG_LABEL_PADDING_DISTANCE;
     auto flush = [&](int obj) {
-        float a = fminf(m0, __shfl_xor(m0, 32));
-        float c = fminf(m1, __shfl_xor(m1, 32));
+        float a = min3p(m0a, m0b, __shfl_xor(min3p(m0a, m0b, m0b), 32));
+        float c = min3p(m1a, m1b, __shfl_xor(min3p(m1a, m1b, m1b), 32));
         if (h == 0) {
             atomicMin(keys + (size_t)obj * N_pad + qbase, key_of(a));
             atomicMin(keys + (size_t)obj * N_pad + qbase + 32, key_of(c));
         }
     };
 #define MANET_BF(x) __builtin_bit_cast(bf16x8_t, x)
-    struct Acc {
-        f32x16 c00, c01, c10, c11;
-    };
-    // the 4 x KSB (x3) MFMAs of one 64 x 64 tile block
-    auto mfma_tile = [&](const char *tb, Acc &c) __attribute__((always_inline)) {
+#define MANET_MFMA(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a_), MANET_BF(b_), c_, 0, 0, 0)
+    // one 64-row tile: 4 x KSB (x3) MFMAs from zero accumulators, then the running minimum
+    auto tile = [&](const char *tb) __attribute__((always_inline)) {
         const u32x4 *A = (const u32x4 *)tb;
-        c.c00 = c.c01 = c.c10 = c.c11 = f32x16{0};
+        f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
         if (!X3) {
             // all A fragments of the tile first (2 x KSB ds_read_b128 in flight), then the MFMAs back to
             // back behind counted lgkmcnt waits: the matrix pipe never waits for an LDS round trip
@@ -723,10 +819,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void global_match_bf16_ke
             }
 #pragma unroll
             for (int k = 0; k < KSB; ++k) {
-                c.c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0[k]), MANET_BF(q0[k]), c.c00, 0, 0, 0);
-                c.c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0[k]), MANET_BF(q1[k]), c.c01, 0, 0, 0);
-                c.c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1[k]), MANET_BF(q0[k]), c.c10, 0, 0, 0);
-                c.c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1[k]), MANET_BF(q1[k]), c.c11, 0, 0, 0);
+                MANET_MFMA(a0[k], q0[k], c00);
+                MANET_MFMA(a1[k], q0[k], c10);
+                MANET_MFMA(a0[k], q1[k], c01);
+                MANET_MFMA(a1[k], q1[k], c11);
             }
         } else {
 #pragma unroll
@@ -735,72 +831,440 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void global_match_bf16_ke
                 u32x4 a1 = A[(k * 2 + h) * BT + 32 + l31];
                 u32x4 a0l = A[(LO + k * 2 + h) * BT + l31];
                 u32x4 a1l = A[(LO + k * 2 + h) * BT + 32 + l31];
-                c.c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q0[k]), c.c00, 0, 0, 0);
-                c.c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q1[k]), c.c01, 0, 0, 0);
-                c.c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q0[k]), c.c10, 0, 0, 0);
-                c.c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q1[k]), c.c11, 0, 0, 0);
-                c.c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q0l[k]), c.c00, 0, 0, 0);
-                c.c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0), MANET_BF(q1l[k]), c.c01, 0, 0, 0);
-                c.c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q0l[k]), c.c10, 0, 0, 0);
-                c.c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1), MANET_BF(q1l[k]), c.c11, 0, 0, 0);
-                c.c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0l), MANET_BF(q0[k]), c.c00, 0, 0, 0);
-                c.c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a0l), MANET_BF(q1[k]), c.c01, 0, 0, 0);
-                c.c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1l), MANET_BF(q0[k]), c.c10, 0, 0, 0);
-                c.c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a1l), MANET_BF(q1[k]), c.c11, 0, 0, 0);
+                MANET_MFMA(a0, q0[k], c00);
+                MANET_MFMA(a1, q0[k], c10);
+                MANET_MFMA(a0, q1[k], c01);
+                MANET_MFMA(a1, q1[k], c11);
+                MANET_MFMA(a0, q0l[k], c00);
+                MANET_MFMA(a1, q0l[k], c10);
+                MANET_MFMA(a0, q1l[k], c01);
+                MANET_MFMA(a1, q1l[k], c11);
+                MANET_MFMA(a0l, q0[k], c00);
+                MANET_MFMA(a1l, q0[k], c10);
+                MANET_MFMA(a0l, q1[k], c01);
+                MANET_MFMA(a1l, q1[k], c11);
             }
         }
-    };
-    // running min over the 64 x 64 distances of a finished tile block
-    auto epilogue = [&](const char *tb, const Acc &c) __attribute__((always_inline)) {
-        const float *ysl = (const float *)(tb + (size_t)UNITS * BT * 16);
+        // accumulator register r of block rb = bank row rb*32 + (r&3) + 8*(r>>2) + 4*h; all of them belong
+        // to the same object, so the reduction over rows is register-wise
 #pragma unroll
-        for (int tq = 0; tq < 4; ++tq) {
-            f32x4 y0 = *(const f32x4 *)(ysl + 8 * tq + 4 * h);
-            f32x4 y1 = *(const f32x4 *)(ysl + 32 + 8 * tq + 4 * h);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * tq + i;
-                m0 = fminf(m0, fminf(fmaf(-2.0f, c.c00[r], xs0 + y0[i]), fmaf(-2.0f, c.c10[r], xs0 + y1[i])));
-                m1 = fminf(m1, fminf(fmaf(-2.0f, c.c01[r], xs1 + y0[i]), fmaf(-2.0f, c.c11[r], xs1 + y1[i])));
-            }
+        for (int r = 0; r < 16; r += 2) {
+            m0a = min3p(m0a, c00[r], c10[r]);
+            m0b = min3p(m0b, c00[r + 1], c10[r + 1]);
+            m1a = min3p(m1a, c01[r], c11[r]);
+            m1b = min3p(m1b, c01[r + 1], c11[r + 1]);
         }
     };
     auto next_object = [&](int t) __attribute__((always_inline)) {
         if (t >= seg_end) {  // wave-uniform: tile t starts another object's rows
             flush(o);
-            m0 = m1 = MANET_WRONG_LABEL_PADDING_DISTANCE;
+            m0a = m0b = m1a = m1b = MANET_WRONG_LABEL_PADDING_DISTANCE;
             do { ++o; seg_end = meta[META_SEG + o + 1]; } while (t >= seg_end);
         }
     };
-    {
-        // double-buffered LDS (2 x TPS tiles), register-staged prefetch one step ahead, ONE barrier per
-        // step of TPS tiles.  With the bf16 MFMA a 64-row tile is only ~0.4 us of matrix work per wave, so
-        // the fixed cost of a step (barrier skew, LDS write, first-fragment latency) is amortised over
-        // TPS tiles.  (A ping-pong schedule of the two waves of a SIMD and a dual-accumulator software
-        // pipeline were both measured: within noise of this simpler loop, see DESIGN.md.)
-        Acc c;
-        MANET_LSTORE_STEP(Ra, 0);
-        if (t0 + TPS < t1) MANET_GLOAD_STEP(Ra, t0 + TPS);
-        int buf = 0;
-        for (int t = t0; t < t1; t += TPS, buf ^= 1) {
+    // static priority for the younger half of the workgroup (waves 4-7 lose every VALU arbitration against
+    // their SIMD partner otherwise; MI355X_MICROARCH.md "two waves per SIMD", item 4)
+    if (young_prio && wave >= 4) __builtin_amdgcn_s_setprio(1);
+
+    if (!DMA) {
+        lstore(0);
+        if (t0 + TPS < t1) gload(t0 + TPS);
+    }
+    int buf = 0;
+    for (int t = t0; t < t1; t += TPS, buf ^= 1) {
+        if (DMA) {
+            // this wave's pieces of the step have landed; the barrier then publishes everybody's pieces
+            // and tells us that every wave is done reading the other buffer (the previous step)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + TPS < t1) stage_dma(t + TPS, buf ^ 1);  // in flight during the whole step
+        } else {
             __syncthreads();  // step's tiles visible in `buf`; the other buffer is free
             if (t + TPS < t1) {
-                MANET_LSTORE_STEP(Ra, buf ^ 1);
-                if (t + 2 * TPS < t1) MANET_GLOAD_STEP(Ra, t + 2 * TPS);
+                lstore(buf ^ 1);
+                if (t + 2 * TPS < t1) gload(t + 2 * TPS);
             }
+        }
 #pragma unroll
-            for (int u = 0; u < TPS; ++u) {
-                if (t + u < t1) {
-                    const char *tb = smem + (size_t)buf * STEP_BYTES + (size_t)u * TILE_BYTES;
-                    next_object(t + u);
-                    mfma_tile(tb, c);
-                    epilogue(tb, c);
-                }
+        for (int u = 0; u < TPS; ++u) {
+            if (t + u < t1) {
+                next_object(t + u);
+                tile(smem + (size_t)buf * STEP_BYTES + (size_t)u * TILE_BYTES);
             }
         }
     }
-#undef MANET_GLOAD_STEP
-#undef MANET_LSTORE_STEP
+#undef MANET_MFMA
+#undef MANET_BF
+    flush(o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined form of the plain-bf16 kernel (the shipped one for MANET_COMPUTE_BF16).
+// Same decomposition and arithmetic as global_match_bf16_kernel<KSB, false, 2, true>; what changes is WHEN
+// things are issued, so that the matrix pipe never waits for LDS (r2 PMC of the kernel above: pipe 67 %
+// busy, waves parked 37 % of their cycles on s_waitcnt -- the A-fragment reads right behind every barrier):
+//   * a step = 2 tiles (A, B); fragment registers F[k] are bound to k-step k: as soon as the four MFMAs of
+//     (tile, k) have been issued, F[k] is refilled with the NEXT tile's k-step -- every ds_read_b128 is in
+//     flight for a whole tile (~7 x 128 matrix cycles) before its MFMA needs it;
+//   * the step's barrier sits BETWEEN tile A and tile B.  By then tile B's fragments are already in
+//     registers, so the barrier (a) publishes the next step's buffer, whose first fragments tile B's k-steps
+//     prefetch, and (b) frees the current buffer for the LDS-DMA of the step after next.  No fragment read
+//     ever follows a barrier directly; two LDS buffers suffice.
+// NBUF = LDS ring depth (2: a step's DMA has one step of lead; 3: two).  ABL: timing ablations only (results are
+// garbage): 1 = no DMA / no vmcnt wait, 2 = no barrier, 4 = epilogue reduced to one min3, 8 = no fragment refills.
+template <int KSB, int NBUF, int ABL>
+__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void global_match_bf16_pipe_kernel(const char *__restrict__ qpack, const char *__restrict__ bpack,
+                                   const int *__restrict__ meta, int n_ids, int nQT, int S, long N_pad,
+                                   unsigned *__restrict__ keys, int block_map, int young_prio)
+{
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    constexpr int NW = 8, TPS = 2;
+    constexpr int UNITS = 2 * KSB;
+    constexpr size_t TILE_BYTES = bank_tile_bytes_u(UNITS, false);  // = UNITS KiB
+    constexpr size_t QBLK_BYTES = query_block_bytes_u(UNITS, false);
+    constexpr size_t STEP_BYTES = TILE_BYTES * TPS;
+    constexpr int QTB = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // NBUF x STEP_BYTES
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    const int b = blockIdx.x;
+    int qt, s;
+    if (block_map == 0) {
+        const int xcd = b & 7;
+        const int idx = b >> 3;
+        qt = idx % nQT;
+        s = xcd + 8 * (idx / nQT);
+    } else {
+        qt = b % nQT;
+        s = b / nQT;
+    }
+    const int T = meta[META_T];
+    const int t0 = (int)((long)s * T / S);
+    const int t1 = (int)((long)(s + 1) * T / S);
+    if (t0 >= t1) return;
+
+    constexpr int PIECES = UNITS * TPS;  // 1 KiB pieces per step
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+    auto stage_dma = [&](int t, int slot, bool prologue = false) __attribute__((always_inline)) {
+        if ((ABL & 1) && !prologue) return;  // ablation: only the first steps are staged (real data in LDS)
+        const int np = ((t1 - t) < TPS ? (t1 - t) : TPS) * UNITS;  // the split's last step may be short
+        const char *g = bpack + (size_t)t * TILE_BYTES + (size_t)lane * 16;
+        const unsigned l = smem_base + (unsigned)slot * (unsigned)STEP_BYTES;
+#pragma unroll
+        for (int i = 0; i < (PIECES + NW - 1) / NW; ++i) {
+            const int pc = wave + i * NW;  // wave-uniform
+            if (pc < np) lds_dma16(g + (size_t)pc * 1024, l + (unsigned)pc * 1024u);
+        }
+    };
+    // s_waitcnt vmcnt(n) with n = this wave's pieces of the `keep` youngest FULL steps: waits for everything
+    // older (VMEM loads return in order).  A full step is PIECES pieces dealt round-robin to the 8 waves.
+    constexpr int P_HI = (PIECES + NW - 1) / NW, P_LO = PIECES / NW;
+    const bool many = (PIECES % NW) != 0 && wave < (PIECES % NW);  // wave-uniform
+    auto wait_dma_keep = [&](int keep) __attribute__((always_inline)) {
+        if (ABL & 1) keep = 0;
+        if (keep == 2) {
+            if (many) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P_HI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P_LO) : "memory");
+        } else if (keep == 1) {
+            if (many) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_HI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_LO) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    auto full_step = [&](int t) { return t + TPS <= t1; };  // both tiles exist
+    stage_dma(t0, 0, true);
+    if (t0 + TPS < t1) stage_dma(t0 + TPS, 1, true);
+    if (NBUF == 3 && t0 + 2 * TPS < t1) stage_dma(t0 + 2 * TPS, 2, true);
+
+    u32x4 q0[KSB], q1[KSB];
+    {
+        const char *qb0 = qpack + (size_t)(qt * (QTB / QB) + wave * 2) * QBLK_BYTES;
+        const char *qb1 = qb0 + QBLK_BYTES;
+#pragma unroll
+        for (int k = 0; k < KSB; ++k) {
+            q0[k] = *(const u32x4 *)(qb0 + ((size_t)(k * 2 + h) * QB + l31) * 16);
+            q1[k] = *(const u32x4 *)(qb1 + ((size_t)(k * 2 + h) * QB + l31) * 16);
+        }
+    }
+    const long qbase = (long)qt * QTB + wave * 64 + l31;
+#pragma unroll
+    for (int k = 0; k < KSB; ++k) asm volatile("" : "+v"(q0[k]), "+v"(q1[k]));  // compiler waits for q here
+
+    int o = 0;
+    while (meta[META_SEG + o + 1] <= t0) ++o;
+    int seg_end = meta[META_SEG + o + 1];
+    float m0a, m0b, m1a, m1b;
+    m0a = m0b = m1a = m1b = MANET_WRONG_LABEL_PADDING_DISTANCE;
+    auto flush = [&](int obj) {
+        float a = min3p(m0a, m0b, __shfl_xor(min3p(m0a, m0b, m0b), 32));
+        float c = min3p(m1a, m1b, __shfl_xor(min3p(m1a, m1b, m1b), 32));
+        if (h == 0) {
+            atomicMin(keys + (size_t)obj * N_pad + qbase, key_of(a));
+            atomicMin(keys + (size_t)obj * N_pad + qbase + 32, key_of(c));
+        }
+    };
+    auto next_object = [&](int t) __attribute__((always_inline)) {
+        if (t >= seg_end) {  // wave-uniform: tile t starts another object's rows
+            flush(o);
+            m0a = m0b = m1a = m1b = MANET_WRONG_LABEL_PADDING_DISTANCE;
+            do { ++o; seg_end = meta[META_SEG + o + 1]; } while (t >= seg_end);
+        }
+    };
+    if (young_prio && wave >= 4) __builtin_amdgcn_s_setprio(1);
+
+    // this lane's fragment offset inside a tile image: unit (2k + h), rows l31 and 32 + l31
+    const unsigned frag_off = (unsigned)((h * BT + l31) * 16);
+    u32x4 F0[KSB], F1[KSB];
+#define MANET_BF(x) __builtin_bit_cast(bf16x8_t, x)
+#define MANET_MFMA(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a_), MANET_BF(b_), c_, 0, 0, 0)
+#define MANET_LOADF(k_, tile_base_)                                                                \
+    {                                                                                              \
+        const char *f_ = (tile_base_) + frag_off + (size_t)(k_) * (2 * BT * 16);                   \
+        F0[k_] = *(const u32x4 *)f_;                                                               \
+        F1[k_] = *(const u32x4 *)(f_ + 32 * 16);                                                   \
+    }
+    // one tile: MFMAs of k-step k from F[k], then F[k] <- k-step k of the tile at `next_base`
+#define MANET_TILE(next_base_)                                                                     \
+    {                                                                                              \
+        f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};                                         \
+        _Pragma("unroll") for (int k = 0; k < KSB; ++k)                                            \
+        {                                                                                          \
+            MANET_MFMA(F0[k], q0[k], c00);                                                         \
+            MANET_MFMA(F1[k], q0[k], c10);                                                         \
+            MANET_MFMA(F0[k], q1[k], c01);                                                         \
+            MANET_MFMA(F1[k], q1[k], c11);                                                         \
+            if (!(ABL & 8)) MANET_LOADF(k, next_base_);                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); /* 4 MFMA  */                       \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); /* 2 DS read: the refill, right behind them */ \
+        }                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < ((ABL & 4) ? 2 : 16); r += 2)                        \
+        {                                                                                          \
+            m0a = min3p(m0a, c00[r], c10[r]);                                                      \
+            m0b = min3p(m0b, c00[r + 1], c10[r + 1]);                                              \
+            m1a = min3p(m1a, c01[r], c11[r]);                                                      \
+            m1b = min3p(m1b, c01[r + 1], c11[r + 1]);                                              \
+        }                                                                                          \
+    }
+
+    // prologue: steps 0, 1, 2 in flight; publish step 0 (1 and 2 keep flying if they are full steps),
+    // fetch tile A's fragments
+    wait_dma_keep(NBUF == 3 ? (full_step(t0 + 2 * TPS) ? 2 : 0) : (full_step(t0 + TPS) ? 1 : 0));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < KSB; ++k) MANET_LOADF(k, smem);
+
+    int buf = 0;
+    for (int t = t0; t < t1; t += TPS, buf = (buf == NBUF - 1 ? 0 : buf + 1)) {
+        const char *cur = smem + (size_t)buf * STEP_BYTES;
+        const char *nxt = smem + (size_t)(buf == NBUF - 1 ? 0 : buf + 1) * STEP_BYTES;
+        // ---- tile A (its fragments are in F; refill F with tile B of the same buffer)
+        next_object(t);
+        MANET_TILE(cur + TILE_BYTES);
+        // ---- mid-step: everything of this buffer is in registers now.  Wait for this wave's pieces of the
+        // NEXT step (issued two steps ago; the step after next keeps flying), then the barrier publishes the
+        // next step's buffer and frees this one for step + 3.  (An LDS-DMA piece takes ~1 us from issue to
+        // landed at ~25 GB/s per CU -- about one step of matrix work, so one step of lead is not enough.)
+        wait_dma_keep(NBUF == 3 && full_step(t + 2 * TPS) ? 1 : 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of `cur` have returned
+        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NBUF * TPS < t1) stage_dma(t + NBUF * TPS, buf);
+        // ---- tile B (refill F with tile A of the next step's buffer; a stale read if there is none)
+        if (t + 1 < t1) {
+            next_object(t + 1);
+            MANET_TILE(nxt);
+        }
+    }
+#undef MANET_TILE
+#undef MANET_LOADF
+#undef MANET_MFMA
+#undef MANET_BF
+    flush(o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// "Wide" form of the pipelined plain-bf16 kernel: 4 waves per workgroup, each wave owns 128 queries (four
+// 32-query blocks, 112 VGPRs of -2q operand) and walks the bank in PASSES of 32 rows: 4 x KSB MFMAs per pass,
+// four independent accumulators, one A fragment per k-step (7 ds_read_b128 per 28 MFMAs -- half the LDS
+// fragment traffic of the 64 x 64 wave tile).  Same 512 queries per workgroup and the same packed images as
+// the other bf16 kernels, but TWO workgroups per CU (256 threads, <= 256 VGPRs): their barriers are
+// independent, and the prologue / flush of one overlaps the matrix work of the other.
+//   step = 2 tiles = 4 passes; fragments F[k] bound to k, refilled with the next pass's k-step right behind
+//   the MFMAs that consumed them; the step's barrier sits before the LAST pass (its fragments are already in
+//   registers): it publishes the next step's buffer and frees the current one for the LDS-DMA of step + 2.
+template <int KSB, int ABL>
+__global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const char *__restrict__ qpack,
+                                                                        const char *__restrict__ bpack,
+                                                                        const int *__restrict__ meta, int n_ids,
+                                                                        int nQT, int S, long N_pad,
+                                                                        unsigned *__restrict__ keys, int block_map,
+                                                                        int young_prio)
+{
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    constexpr int NW = 4, TPS = 2, NQB = 4;  // waves, tiles per step, query blocks per wave
+    constexpr int UNITS = 2 * KSB;
+    constexpr size_t TILE_BYTES = bank_tile_bytes_u(UNITS, false);  // = UNITS KiB
+    constexpr size_t QBLK_BYTES = query_block_bytes_u(UNITS, false);
+    constexpr size_t STEP_BYTES = TILE_BYTES * TPS;
+    constexpr int QTB = QT_BF16;
+    static_assert(NW * NQB * QB == QTB, "4 waves x 4 blocks x 32 queries");
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x STEP_BYTES
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    const int b = blockIdx.x;
+    int qt, s;
+    if (block_map == 0) {
+        const int xcd = b & 7;
+        const int idx = b >> 3;
+        qt = idx % nQT;
+        s = xcd + 8 * (idx / nQT);
+    } else {
+        qt = b % nQT;
+        s = b / nQT;
+    }
+    const int T = meta[META_T];
+    const int t0 = (int)((long)s * T / S);
+    const int t1 = (int)((long)(s + 1) * T / S);
+    if (t0 >= t1) return;
+
+    constexpr int PIECES = UNITS * TPS;  // 1 KiB pieces per step
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+    auto stage_dma = [&](int t, int slot, bool prologue = false) __attribute__((always_inline)) {
+        if ((ABL & 1) && !prologue) return;
+        const int np = ((t1 - t) < TPS ? (t1 - t) : TPS) * UNITS;  // the split's last step may be short
+        const char *g = bpack + (size_t)t * TILE_BYTES + (size_t)lane * 16;
+        const unsigned l = smem_base + (unsigned)slot * (unsigned)STEP_BYTES;
+#pragma unroll
+        for (int i = 0; i < (PIECES + NW - 1) / NW; ++i) {
+            const int pc = wave + i * NW;  // wave-uniform
+            if (pc < np) lds_dma16(g + (size_t)pc * 1024, l + (unsigned)pc * 1024u);
+        }
+    };
+    stage_dma(t0, 0, true);
+    if (t0 + TPS < t1) stage_dma(t0 + TPS, 1, true);
+
+    u32x4 q[NQB][KSB];
+    {
+        const char *qb = qpack + (size_t)(qt * (QTB / QB) + wave * NQB) * QBLK_BYTES;
+#pragma unroll
+        for (int j = 0; j < NQB; ++j)
+#pragma unroll
+            for (int k = 0; k < KSB; ++k)
+                q[j][k] = *(const u32x4 *)(qb + (size_t)j * QBLK_BYTES + ((size_t)(k * 2 + h) * QB + l31) * 16);
+    }
+    const long qbase = (long)qt * QTB + wave * (NQB * QB) + l31;
+#pragma unroll
+    for (int j = 0; j < NQB; ++j)
+#pragma unroll
+        for (int k = 0; k < KSB; ++k) asm volatile("" : "+v"(q[j][k]));  // compiler waits for q here
+
+    int o = 0;
+    while (meta[META_SEG + o + 1] <= t0) ++o;
+    int seg_end = meta[META_SEG + o + 1];
+    float ma[NQB], mb[NQB];  // two running minima per query block (even / odd accumulator registers)
+#pragma unroll
+    for (int j = 0; j < NQB; ++j) ma[j] = mb[j] = MANET_WRONG_LABEL_PADDING_DISTANCE;
+    auto flush = [&](int obj) {
+#pragma unroll
+        for (int j = 0; j < NQB; ++j) {
+            const float v = min3p(ma[j], mb[j], mb[j]);
+            const float a = min3p(v, v, __shfl_xor(v, 32));
+            if (h == 0) atomicMin(keys + (size_t)obj * N_pad + qbase + 32 * j, key_of(a));
+        }
+    };
+    auto next_object = [&](int t) __attribute__((always_inline)) {
+        if (t >= seg_end) {  // wave-uniform: tile t starts another object's rows
+            flush(o);
+#pragma unroll
+            for (int j = 0; j < NQB; ++j) ma[j] = mb[j] = MANET_WRONG_LABEL_PADDING_DISTANCE;
+            do { ++o; seg_end = meta[META_SEG + o + 1]; } while (t >= seg_end);
+        }
+    };
+    (void)young_prio;
+
+    // this lane's fragment offset inside a tile image: unit (2k + h), row rb * 32 + l31
+    const unsigned frag_off = (unsigned)((h * BT + l31) * 16);
+    u32x4 F[KSB];
+#define MANET_BF(x) __builtin_bit_cast(bf16x8_t, x)
+#define MANET_MFMA(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a_), MANET_BF(b_), c_, 0, 0, 0)
+#define MANET_LOADF(k_, pass_base_) F[k_] = *(const u32x4 *)((pass_base_) + frag_off + (size_t)(k_) * (2 * BT * 16));
+    // one pass = 32 bank rows x 128 queries: MFMAs of k-step k from F[k], then F[k] <- k-step k of the pass
+    // at `next_base` (a tile's second row block is 32 * 16 bytes behind its first inside every unit)
+#define MANET_PASS(next_base_)                                                                     \
+    {                                                                                              \
+        f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};                                             \
+        _Pragma("unroll") for (int k = 0; k < KSB; ++k)                                            \
+        {                                                                                          \
+            MANET_MFMA(F[k], q[0][k], c0);                                                         \
+            MANET_MFMA(F[k], q[1][k], c1);                                                         \
+            MANET_MFMA(F[k], q[2][k], c2);                                                         \
+            MANET_MFMA(F[k], q[3][k], c3);                                                         \
+            if (!(ABL & 8)) MANET_LOADF(k, next_base_);                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); /* 4 MFMA */                        \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* the refill right behind them */  \
+        }                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < ((ABL & 4) ? 2 : 16); r += 4)                        \
+        {                                                                                          \
+            ma[0] = min3p(ma[0], c0[r], c0[r + 2]);                                                \
+            mb[0] = min3p(mb[0], c0[r + 1], c0[r + 3]);                                            \
+            ma[1] = min3p(ma[1], c1[r], c1[r + 2]);                                                \
+            mb[1] = min3p(mb[1], c1[r + 1], c1[r + 3]);                                            \
+            ma[2] = min3p(ma[2], c2[r], c2[r + 2]);                                                \
+            mb[2] = min3p(mb[2], c2[r + 1], c2[r + 3]);                                            \
+            ma[3] = min3p(ma[3], c3[r], c3[r + 2]);                                                \
+            mb[3] = min3p(mb[3], c3[r + 1], c3[r + 3]);                                            \
+        }                                                                                          \
+    }
+
+    // prologue: steps 0 and 1 in flight; publish step 0, fetch the first pass's fragments
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < KSB; ++k) MANET_LOADF(k, smem);
+
+    int buf = 0;
+    for (int t = t0; t < t1; t += TPS, buf ^= 1) {
+        const char *cur = smem + (size_t)buf * STEP_BYTES;
+        const char *nxt = smem + (size_t)(buf ^ 1) * STEP_BYTES;
+        const bool has_b = (t + 1 < t1);
+        // ---- tile A: rows 0-31 (refill: A rows 32-63), rows 32-63 (refill: B rows 0-31)
+        next_object(t);
+        MANET_PASS(cur + 32 * 16);
+        MANET_PASS(cur + TILE_BYTES);
+        // ---- tile B rows 0-31 (refill: B rows 32-63).  After this pass every fragment of `cur` is in
+        // registers.
+        if (has_b) {
+            next_object(t + 1);
+            MANET_PASS(cur + TILE_BYTES + 32 * 16);
+        }
+        // ---- this wave's pieces of the next step have landed (issued one step ago) and its reads of `cur`
+        // have returned; the barrier publishes the next buffer and frees `cur` for step + 2
+        if (!(ABL & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 * TPS < t1) stage_dma(t + 2 * TPS, buf);
+        // ---- tile B rows 32-63 (refill: first pass of the next step; a stale read if there is none)
+        if (has_b) MANET_PASS(nxt);
+    }
+#undef MANET_PASS
+#undef MANET_LOADF
+#undef MANET_MFMA
 #undef MANET_BF
     flush(o);
 }
@@ -914,33 +1378,71 @@ void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int 
     manet_profile_record(st, false);
 }
 
-template <int KSB, bool X3, int NW, int TPS>
+template <int KSB, bool X3, int TPS, bool DMA>
 void launch_main_bf16_v(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S, long N_pad,
-                        unsigned *keys, hipStream_t st)
+                        unsigned *keys, int young_prio, hipStream_t st)
 {
-    size_t lds = 2 * TPS * bank_tile_bytes_u(2 * KSB * (X3 ? 2 : 1));
-    (void)hipFuncSetAttribute((const void *)global_match_bf16_kernel<KSB, X3, NW, TPS>,
+    size_t lds = 2 * TPS * bank_tile_bytes_u(2 * KSB * (X3 ? 2 : 1), false);
+    (void)hipFuncSetAttribute((const void *)global_match_bf16_kernel<KSB, X3, TPS, DMA>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     manet_profile_record(st, true);
-    hipLaunchKernelGGL((global_match_bf16_kernel<KSB, X3, NW, TPS>), dim3((unsigned)(nQT * S)), dim3(NW * 64), lds, st,
-                       qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, manet_tune_get(MANET_TUNE_BLOCK_MAP, 0));
+    hipLaunchKernelGGL((global_match_bf16_kernel<KSB, X3, TPS, DMA>), dim3((unsigned)(nQT * S)), dim3(512), lds, st,
+                       qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, manet_tune_get(MANET_TUNE_BLOCK_MAP, 0),
+                       young_prio);
     manet_profile_record(st, false);
 }
 
-// workgroup shape of the bf16 kernels: 0 (default) = 8 waves, 2 tiles per barrier for plain bf16;
-// tuning: 1 = 4 waves x 2 workgroups per CU, 2 = 8 waves, 1 tile per barrier, 3 = 8 waves, 4 tiles
-int bf16_variant() { return manet_tune_get(MANET_TUNE_BF16_VARIANT, 0); }
-
+// Shipped shape of the bf16 kernels: 2 tiles per step (1 for split-bf16), asm LDS-DMA staging.
+// MANET_TUNE_BF16_VARIANT (experiments; bit field): bits 0-1: tiles per step 0 = default, 1 = one,
+// 2 = four (two for split-bf16); bit 2: register staging instead of LDS-DMA; bit 3: static s_setprio 1
+// for waves 4-7; bit 4: plain bf16 on the un-pipelined kernel (the split-bf16 structure).  None of it changes
+// a workspace layout.
 template <int KSB, bool X3>
 void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S, long N_pad,
                       unsigned *keys, hipStream_t st)
 {
-    switch (bf16_variant()) {
-    case 1: launch_main_bf16_v<KSB, X3, 4, X3 ? 1 : 2>(qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, st); break;
-    case 2: launch_main_bf16_v<KSB, X3, 8, 1>(qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, st); break;
-    case 3: launch_main_bf16_v<KSB, X3, 8, X3 ? 2 : 4>(qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, st); break;
-    default: launch_main_bf16_v<KSB, X3, 8, X3 ? 1 : 2>(qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, st); break;
+    const int v = manet_tune_get(MANET_TUNE_BF16_VARIANT, 0);
+    const int tps = v & 3, reg = (v >> 2) & 1, flat = (v >> 4) & 1;
+    int prio = (v >> 3) & 1;
+    if (!X3 && !flat) {  // plain-bf16 kernels: software-pipelined fragments, barrier in front of the step's last pass
+        const int nbuf = (v >> 5) & 1 ? 3 : 2;
+        // the 8-wave 64x64-wave-tile form: tuning, and KSB = 9 (C > 106), whose 144 operand VGPRs do not fit the wide form
+        const int narrow = ((v >> 6) & 1) || KSB == 9;
+        const int abl = KSB == 7 ? manet_tune_get(MANET_TUNE_ABLATION, 0) : 0;  // timing experiments only
+        const void *fn = nullptr;
+        unsigned threads = 512;
+        size_t lds = (size_t)nbuf * 2 * bank_tile_bytes_u(2 * KSB, false);
+        if (narrow) {
+#define MANET_PK(NB_, AB_)                                                                         \
+    if (nbuf == NB_ && abl == AB_) fn = (const void *)global_match_bf16_pipe_kernel<KSB, NB_, (KSB == 7 ? AB_ : 0)>;
+            MANET_PK(2, 0) MANET_PK(3, 0) MANET_PK(2, 1) MANET_PK(2, 2) MANET_PK(2, 4) MANET_PK(2, 8) MANET_PK(2, 15)
+#undef MANET_PK
+            if (!fn) fn = (const void *)global_match_bf16_pipe_kernel<KSB, 2, 0>;
+        } else {
+            threads = 256;
+            lds = (size_t)2 * 2 * bank_tile_bytes_u(2 * KSB, false);
+#define MANET_WK(AB_) \
+    if (abl == AB_) fn = (const void *)global_match_bf16_wide_kernel<KSB, (KSB == 7 ? AB_ : 0)>;
+            MANET_WK(0) MANET_WK(1) MANET_WK(2) MANET_WK(4) MANET_WK(8) MANET_WK(15)
+#undef MANET_WK
+            if (!fn) fn = (const void *)global_match_bf16_wide_kernel<KSB, 0>;
+        }
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int bm = manet_tune_get(MANET_TUNE_BLOCK_MAP, 0);
+        void *args[] = {(void *)&qpack, (void *)&bpack, (void *)&meta, (void *)&n_ids, (void *)&nQT, (void *)&S,
+                        (void *)&N_pad, (void *)&keys, (void *)&bm, (void *)&prio};
+        manet_profile_record(st, true);
+        (void)hipLaunchKernel(fn, dim3((unsigned)(nQT * S)), dim3(threads), args, lds, st);
+        manet_profile_record(st, false);
+        return;
     }
+#define MANET_BV(TPS_)                                                                                         \
+    if (reg) launch_main_bf16_v<KSB, X3, TPS_, false>(qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, prio, st); \
+    else launch_main_bf16_v<KSB, X3, TPS_, true>(qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, prio, st);
+    if (tps == 1) { MANET_BV(1) }
+    else if (tps == 2) { MANET_BV((X3 ? 2 : 4)) }
+    else { MANET_BV((X3 ? 1 : 2)) }
+#undef MANET_BV
 }
 
 }  // namespace
@@ -1002,8 +1504,8 @@ int manet_bank_prepare(const float *bank, int64_t b_stride_m, int64_t b_stride_c
         hipLaunchKernelGGL(label_scatter_kernel, dim3((unsigned)L.nblocks), dim3(RPB), 0, st, labels, (long)M0, n_ids,
                            (const int *)hist, (const int *)meta, src_of);
     {
-        size_t lds = (size_t)BT * (L.G.kpad + 1) * sizeof(float) + BT * sizeof(int);
-        hipLaunchKernelGGL(pack_rows_kernel<BT>, dim3((unsigned)L.T_max), dim3(256), lds, st, bank, (long)b_stride_m,
+        size_t lds = (size_t)BT * (L.G.kpad + 1) * sizeof(float) + 2 * BT * sizeof(int);
+        hipLaunchKernelGGL((pack_rows_kernel<BT, float>), dim3((unsigned)L.T_max), dim3(256), lds, st, bank, (long)b_stride_m,
                            (long)b_stride_c, (const int *)src_of, (const int *)meta, (long)M0, C, compute, L.G.units,
                            L.G.kpad, ws + L.off_pack, (long)L.tile_bytes, MANET_WRONG_LABEL_PADDING_DISTANCE);
     }
@@ -1029,13 +1531,18 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
     unsigned *keys = (unsigned *)(mws + ML.off_keys);
     fill32(keys, 0xffffffffu, (size_t)n_ids * ML.N_pad, st);
     {
-        size_t lds = (size_t)QB * (ML.G.kpad + 1) * sizeof(float) + QB * sizeof(int);
-        hipLaunchKernelGGL(pack_rows_kernel<QB>, dim3((unsigned)(ML.N_pad / QB)), dim3(256), lds, st, query,
+        size_t lds = (size_t)QB * (ML.G.kpad + 1) * sizeof(float) + 2 * QB * sizeof(int);
+        hipLaunchKernelGGL((pack_rows_kernel<QB, float>), dim3((unsigned)(ML.N_pad / QB)), dim3(256), lds, st, query,
                            (long)q_stride_n, (long)q_stride_c, (const int *)nullptr, (const int *)nullptr, (long)N,
                            C, compute, ML.G.units, ML.G.kpad, mws + ML.off_q, (long)ML.qblk_bytes, 0.0f);
     }
     // resident workgroup slots: f32 = 2 x 256-thread workgroups per CU, bf16 = 1 x 512-thread workgroup per CU
-    int S = pick_splits(ML.nQT, BL.T_max, (compute == MANET_COMPUTE_F32 || ML.G.qt == 256) ? 512 : 256);
+    // resident workgroup slots: f32 and plain bf16 (wide kernel) = 2 x 256-thread workgroups per CU,
+    // split-bf16 (and the tuning-only narrow/flat bf16 forms) = 1 x 512-thread workgroup per CU
+    const int bv = manet_tune_get(MANET_TUNE_BF16_VARIANT, 0);
+    const bool two_per_cu = compute == MANET_COMPUTE_F32 ||
+                            (compute == MANET_COMPUTE_BF16 && !(bv & (16 | 64)) && ML.G.steps != 9);
+    int S = pick_splits(ML.nQT, BL.T_max, two_per_cu ? 512 : 256);
     {
         int forced = manet_tune_get(MANET_TUNE_SPLITS, 0);  // tuning only
         if (forced > 0) S = (forced + 7) / 8 * 8;
@@ -1059,8 +1566,8 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
         switch (ML.G.steps) {
             MANET_GB_CASE(2) MANET_GB_CASE(7)
         default:
-            if (x3) launch_main_bf16<8, true>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st);
-            else launch_main_bf16<8, false>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st);
+            if (x3) launch_main_bf16<9, true>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st);
+            else launch_main_bf16<9, false>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st);
             break;
         }
 #undef MANET_GB_CASE

@@ -49,7 +49,10 @@ def test_gpu_kernel_vs_reference_and_oracle(oracle):
     g = load_golden("seg_head_tiny")
     blk, head = make_block(g, "cuda")
     x = torch.from_numpy(g["x"]).cuda()
-    half = ops.dwconv7x7_bn_relu(x, blk.conv1.weight, blk.conv1.bias, blk.bn1).cpu().numpy()
+    with pytest.raises(RuntimeError, match="requires grad"):  # Parameters + grad mode: would drop their gradient
+        ops.dwconv7x7_bn_relu(x, blk.conv1.weight, blk.conv1.bias, blk.bn1)
+    with torch.no_grad():
+        half = ops.dwconv7x7_bn_relu(x, blk.conv1.weight, blk.conv1.bias, blk.bn1).cpu().numpy()
     np.testing.assert_allclose(half, g["half"], rtol=RTOL, atol=ATOL)
     scale, shift = folded_bn(g, "blk::bn1.")
     want = oracle.dwconv7x7_bn_relu(g["x"], g["blk::conv1.weight"], g["blk::conv1.bias"], scale, shift)
