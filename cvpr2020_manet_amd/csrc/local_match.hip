@@ -336,6 +336,356 @@ __global__ void local_upsample_kernel(const float *__restrict__ dvol, int h, int
     out[i] = bilin_sample(dvol + (long)l * hp * wp, wp, cy, cx);
 }
 
+// ---------------------------------------------------------------------------------------------
+// FUSED local match (the live configuration: downsample on): window distances -> normalise -> bilinear ->
+// stride-2 label gather -> masked min in ONE kernel behind the pooling pass; the (2d+1)^2 volume never touches
+// memory (r1: pooled volume written and re-read by a third launch, 47 us at d=4 / 125 us at d=12).
+//
+// Decomposition.  A full-resolution pixel (y, x) reads the pooled volume at rows {i0, i1}, columns {j0, j1}
+// (bilinear, align_corners).  A workgroup owns the pixels whose (i0, j0) falls into a TY x 15 block of the
+// pooled grid; they need the volume on a (TY+1) x 16 block S (a one-sided apron), for every window offset.
+//   phase 1  distances on S: thread = (row of S, window row dy, group of COLS columns), COLS x P running sums
+//            over C; channels staged through LDS in double-buffered chunks; a thread slides its COLS+2d wide
+//            window over the P offsets out of registers.  Same arithmetic and order as local_dist_kernel / the
+//            oracle (ascending fmaf chain of (x - y)^2).
+//   phase 2  the normalised volume of S goes to LDS ([dy][dx][SY][16]), the previous frame's labels around the
+//            tile too (one byte each), and every pixel takes its masked minimum over the window -- the same
+//            expressions in the same order as local_min_kernel / the oracle: bit-identical to r1's path.
+// The pooling pass writes PADDED planes (lf_pool_pad_kernel): a border of the reference's padding value (1e20 for
+// the previous frame, IntVOS.py:287) wide enough that no tile ever leaves the plane, rows a multiple of 16 bytes.
+// Staging is then branch-free: float4 global loads -> ds_write_b128, a handful per thread per stage (r2, first
+// version: one exec-masked scalar load + store per element cost as much as the window arithmetic itself).
+// Wide windows (d >= 7) use COLS = 4: window reads are aligned ds_read_b128 and feed 4 x P fma pairs.
+// For d >= 11 the window rows are dealt to NDG workgroups per tile (d=11: 2, d=12: 5); their partial minima meet
+// by atomicMin on the float bits (all candidates lie in [0, 1]; `out` is pre-set to 1.0, the reference's
+// "no match" value, IntVOS.py:429-430).
+__host__ __device__ constexpr int lf_cols(int d) { return d <= 6 ? 2 : 4; }                       // columns per thread
+// d >= 10: a thread owns one HALF of the window columns (dx 0..11 | 12..2d): 4 x 13 instead of 4 x 25 running sums,
+// twice the threads -- two waves per SIMD for the arithmetic and twice the lanes for the per-pixel phase
+__host__ __device__ constexpr int lf_dxs(int d) { return d >= 10 ? 2 : 1; }
+constexpr int LF_PH = 12;  // window columns of the first half (a multiple of 4: the second half's reads stay 16-byte aligned)
+__host__ __device__ constexpr int lf_pa(int d)  // running sums per column per thread
+{
+    return lf_dxs(d) == 1 ? 2 * d + 1 : ((2 * d + 1 - LF_PH) > LF_PH ? (2 * d + 1 - LF_PH) : LF_PH);
+}
+__host__ __device__ constexpr int lf_nt(int d) { return d <= 4 ? 256 : (d <= 6 ? 512 : (d <= 9 ? 256 : 512)); }  // threads
+__host__ __device__ constexpr int lf_slots(int d) { return lf_nt(d) / ((16 / lf_cols(d)) * lf_dxs(d)); }  // (row, dy) slots
+__host__ __device__ constexpr int lf_nd(int d) { return d <= 10 ? 2 * d + 1 : (d == 11 ? 12 : 5); }  // dy per workgroup
+__host__ __device__ constexpr int lf_ndg(int d) { return (2 * d + 1 + lf_nd(d) - 1) / lf_nd(d); }
+__host__ __device__ constexpr int lf_sy(int d) { return lf_slots(d) / lf_nd(d) > 12 ? 12 : lf_slots(d) / lf_nd(d); }
+constexpr int LF_SX = 16;  // columns of S
+__host__ __device__ constexpr int lf_cw(int d)  // halo row stride (every thread reads whole vectors: room for the over-read)
+{
+    return lf_dxs(d) == 2 ? 40 : ((LF_SX + 2 * d + 3) & ~3);
+}
+__host__ __device__ constexpr int lf_yr(int d) { return lf_sy(d) + lf_nd(d) - 1; }                // halo rows
+__host__ __device__ constexpr int lf_yplane(int d) { return lf_yr(d) * lf_cw(d); }
+__host__ __device__ constexpr int lf_xplane(int d) { return lf_sy(d) * LF_SX; }
+// channels per LDS stage: two stages <= 64 KiB, <= 12 float4 in flight per thread
+__host__ __device__ constexpr int lf_cc(int d)
+{
+    int by_lds = 65536 / (8 * (lf_yplane(d) + lf_xplane(d)));
+    int by_regs = 12 * lf_nt(d) / ((lf_yplane(d) + lf_xplane(d)) / 4);
+    int cc = by_lds < by_regs ? by_lds : by_regs;
+    return cc < 2 ? 2 : (cc > 25 ? 25 : cc);
+}
+__host__ __device__ constexpr int lf_lab_rows(int d) { return 2 * (lf_sy(d) - 1) + 4 + 2 * (lf_nd(d) - 1); }
+__host__ __device__ constexpr int lf_lab_cols(int d) { return 2 * (LF_SX - 1) + 4 + 4 * d; }
+__host__ __device__ constexpr size_t lf_lds_bytes(int d)
+{
+    size_t stage = 2 * (size_t)lf_cc(d) * (lf_yplane(d) + lf_xplane(d)) * 4;
+    size_t vol = (size_t)lf_nd(d) * (2 * d + 1) * lf_sy(d) * LF_SX * 4 + (((size_t)lf_lab_rows(d) * lf_lab_cols(d) + 15) & ~(size_t)15);
+    return stage > vol ? stage : vol;
+}
+// padded pooled plane [HPAD][WS]: image pixel (py, px) at (d + py, d + px)
+struct PoolPad {
+    int hp, wp, HPAD, WS;
+    long plane;  // HPAD * WS
+};
+static PoolPad lf_pool_pad(int h, int w, int d)
+{
+    PoolPad G;
+    G.hp = h / 2;
+    G.wp = w / 2;
+    G.HPAD = G.hp + lf_sy(d) + lf_ndg(d) * lf_nd(d) - 1;  // last tile row + halo rows of the last dy group
+    G.WS = (G.wp + lf_cw(d) + 3) & ~3;                     // last tile column + halo columns
+    G.plane = (long)G.HPAD * G.WS;
+    return G;
+}
+
+// IntVOS.py:282-284 F.avg_pool2d(x, (2,2), (2,2)) of both frames into padded planes: window summed row-major,
+// times 1/4 (exact) -- the arithmetic of pool2x2_kernel; border = 0 for the current frame (never used), 1e20 for
+// the previous frame (IntVOS.py:287: (x - 1e20)^2 = inf -> 1.0 after normalisation, no bounds logic downstream)
+__global__ void lf_pool_pad_kernel(const float *__restrict__ a, long a_sy, long a_sx, long a_sc,
+                                   const float *__restrict__ b, long b_sy, long b_sx, long b_sc, int C, int hp, int wp,
+                                   int d, int HPAD, int WS, float *__restrict__ ap, float *__restrict__ bp)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long plane = (long)HPAD * WS;
+    if (i >= plane * C) return;
+    int c = (int)(i / plane);
+    int rem = (int)(i - (long)c * plane);
+    int r = rem / WS, col = rem - r * WS;
+    int py = r - d, px = col - d;
+    float va = 0.0f, vb = 1e20f;
+    if (py >= 0 && py < hp && px >= 0 && px < wp) {
+        const float *p = a + (2L * py) * a_sy + (2L * px) * a_sx + (long)c * a_sc;
+        const float *q = b + (2L * py) * b_sy + (2L * px) * b_sx + (long)c * b_sc;
+        va = (((p[0] + p[a_sx]) + p[a_sy]) + p[a_sy + a_sx]) * 0.25f;
+        vb = (((q[0] + q[b_sx]) + q[b_sy]) + q[b_sy + b_sx]) * 0.25f;
+    }
+    ap[i] = va;
+    bp[i] = vb;
+}
+
+template <int D>
+__global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__restrict__ curp,
+                                                               const float *__restrict__ prevp, int WS, long PS,
+                                                               const int *__restrict__ labels, int h, int w, int C,
+                                                               int n_ids, float *__restrict__ out, int abl)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int P = 2 * D + 1, NT = lf_nt(D), ND = lf_nd(D), NDG = lf_ndg(D), SY = lf_sy(D), TY = SY - 1;
+    constexpr int TX = LF_SX - 1, CW = lf_cw(D), YR = lf_yr(D), CC = lf_cc(D), COLS = lf_cols(D), NG = LF_SX / COLS;
+    constexpr int DXS = lf_dxs(D), PA = lf_pa(D);
+    constexpr int yplane = YR * CW, xplane = SY * LF_SX;
+    constexpr int buf_floats = CC * (yplane + xplane);
+    constexpr int NVY = yplane / 4, NVX = xplane / 4;          // float4 per channel
+    constexpr int KY = (CC * NVY + NT - 1) / NT, KX = (CC * NVX + NT - 1) / NT;  // float4 per thread per stage
+    float *smem = (float *)smem_raw;
+    const int tid = threadIdx.x;
+    const int hp = h / 2, wp = w / 2;
+    const int a = blockIdx.y * TY, b0 = blockIdx.x * TX;  // pooled origin of S
+    const int dy0 = blockIdx.z * ND;                       // first window row of this workgroup
+
+    // ---- phase 1: distances on S for window rows dy0 .. dy0+ND-1 ---------------------------------
+    // staging map (fixed for the whole kernel): this thread's float4 items of a stage -- channel offset inside
+    // the stage, element offset inside a padded plane, float offset inside the LDS stage
+    int ych[KY], ygo[KY], ylo[KY], xch[KX], xgo[KX], xlo[KX];
+#pragma unroll
+    for (int k = 0; k < KY; ++k) {
+        const int i = tid + NT * k;
+        const int c = i / NVY, v = i - c * NVY;
+        const int r = v / (CW / 4), q = v - r * (CW / 4);
+        ych[k] = (i < CC * NVY) ? c : -1;
+        ygo[k] = (a + dy0 + r) * WS + b0 + 4 * q;  // padded coordinates: image row a - D + dy0 + r sits at row a + dy0 + r
+        ylo[k] = c * yplane + r * CW + 4 * q;
+    }
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        const int i = tid + NT * k;
+        const int c = i / NVX, v = i - c * NVX;
+        const int r = v / 4, q = v - r * 4;
+        xch[k] = (i < CC * NVX) ? c : -1;
+        xgo[k] = (D + a + r) * WS + D + b0 + 4 * q;
+        xlo[k] = CC * yplane + c * xplane + r * LF_SX + 4 * q;
+    }
+    f32x4 ry_[KY], rx_[KX];
+    auto load_regs = [&](int c0) __attribute__((always_inline)) {  // unconditional, clamped: no branches
+#pragma unroll
+        for (int k = 0; k < KY; ++k) {
+            int ch = c0 + (ych[k] < 0 ? 0 : ych[k]);
+            ch = ch < C ? ch : C - 1;
+            ry_[k] = *(const f32x4 *)(prevp + (long)ch * PS + ygo[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < KX; ++k) {
+            int ch = c0 + (xch[k] < 0 ? 0 : xch[k]);
+            ch = ch < C ? ch : C - 1;
+            rx_[k] = *(const f32x4 *)(curp + (long)ch * PS + xgo[k]);
+        }
+    };
+    auto store_lds = [&](int buf, int c0) __attribute__((always_inline)) {  // channels beyond C: x = y = 0 (add 0)
+        float *st = smem + (long)buf * buf_floats;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KY; ++k)
+            if (ych[k] >= 0) *(f32x4 *)(st + ylo[k]) = (c0 + ych[k] < C) ? ry_[k] : zero;
+#pragma unroll
+        for (int k = 0; k < KX; ++k)
+            if (xch[k] >= 0) *(f32x4 *)(st + xlo[k]) = (c0 + xch[k] < C) ? rx_[k] : zero;
+    };
+
+    const int g = tid % NG;
+    const int xh = (tid / NG) % DXS;                 // which half of the window columns
+    const int dyi = (tid / (NG * DXS)) % ND;
+    const int ry = (tid / (NG * DXS)) / ND;
+    const bool active = ry < SY;
+    const int dx_lo = xh * LF_PH;
+    const int ndx = (xh == DXS - 1) ? P - dx_lo : LF_PH;  // window columns this thread really owns (<= PA)
+    constexpr int WN = (COLS + PA - 1 + COLS - 1) / COLS * COLS;  // window floats read per channel (whole vectors)
+    float acc[COLS][PA];  // sums beyond ndx accumulate whatever follows in the row and are never stored
+#pragma unroll
+    for (int j = 0; j < COLS; ++j)
+#pragma unroll
+        for (int i = 0; i < PA; ++i) acc[j][i] = 0.0f;
+
+    load_regs(0);
+    store_lds(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = 0; c0 < C; c0 += CC, buf ^= 1) {
+        const bool more = (c0 + CC) < C;
+        if (more) load_regs(c0 + CC);  // next stage's global loads fly under this stage's math
+        if (active && !(abl & 1)) {
+            const float *ys = smem + (long)buf * buf_floats;
+            const float *xs = ys + CC * yplane;
+#pragma unroll 2
+            for (int c = 0; c < CC; ++c) {
+                const float *yrow = ys + c * yplane + (ry + dyi) * CW + COLS * g + dx_lo;
+                const float *xrow = xs + c * xplane + ry * LF_SX + COLS * g;
+                float win[WN], xv[COLS];
+                if constexpr (COLS == 2) {
+                    const float2 t = *(const float2 *)xrow;
+                    xv[0] = t.x;
+                    xv[1] = t.y;
+#pragma unroll
+                    for (int i = 0; i < WN / 2; ++i) {
+                        const float2 u = *(const float2 *)(yrow + 2 * i);
+                        win[2 * i] = u.x;
+                        win[2 * i + 1] = u.y;
+                    }
+                } else {
+                    const f32x4 t = *(const f32x4 *)xrow;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[j] = t[j];
+#pragma unroll
+                    for (int i = 0; i < WN / 4; ++i) {
+                        const f32x4 u = *(const f32x4 *)(yrow + 4 * i);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) win[4 * i + j] = u[j];
+                    }
+                }
+#pragma unroll
+                for (int dx = 0; dx < PA; ++dx) {
+#pragma unroll
+                    for (int j = 0; j < COLS; ++j) {
+                        const float dd = xv[j] - win[dx + j];
+                        acc[j][dx] = fmaf(dd, dd, acc[j][dx]);
+                    }
+                }
+            }
+        }
+        if (more) store_lds(buf ^ 1, c0 + CC);
+        __syncthreads();
+    }
+
+    // ---- phase 2: normalised volume of S and the labels around the tile into LDS -----------------
+    float *V = smem;                                           // [ND][P][SY][16]
+    unsigned char *L = (unsigned char *)(V + ND * P * SY * LF_SX);  // [lab_rows][lab_cols], 255 = matches no id
+    if (active) {
+#pragma unroll
+        for (int dx = 0; dx < PA; ++dx) {
+            if (dx < ndx) {
+                float *vp = V + ((dyi * P + dx_lo + dx) * SY + ry) * LF_SX + COLS * g;
+#pragma unroll
+                for (int j = 0; j < COLS; ++j) vp[j] = manet_normalize_dist(acc[j][dx]);
+            }
+        }
+    }
+    // full-resolution pixels of this tile: rows with i0(y) in [a, a+TY), columns with j0(x) in [b0, b0+TX).
+    // i0(y) <= y/2, so the rows start at 2a or a little later (wave-uniform scans, a few iterations)
+    int ya = 2 * a, yb;
+    while (ya < h && bilin_coeff(ya, hp, h).i0 < a) ++ya;
+    yb = ya;
+    while (yb < h && bilin_coeff(yb, hp, h).i0 < a + TY) ++yb;
+    int xa = 2 * b0, xb;
+    while (xa < w && bilin_coeff(xa, wp, w).i0 < b0) ++xa;
+    xb = xa;
+    while (xb < w && bilin_coeff(xb, wp, w).i0 < b0 + TX) ++xb;
+    const int ny = yb - ya, nx = xb - xa;
+    if (ny > 2 * TY + 4 || nx > 2 * TX + 4) __builtin_trap();  // cannot happen (ratio (hp-1)/(h-1) < 1/2): fail loudly, never overrun L
+    // labels: rows ya + 2(dy0 - D) .. , columns xa - 2D .. ; outside the image = 0 (zero padding, IntVOS.py:400)
+    const int lrows = ny + 2 * (ND - 1), lcols = nx + 4 * D;
+    const int ly0 = ya + 2 * (dy0 - D), lx0 = xa - 2 * D;
+    for (int e = tid; e < lrows * lcols; e += NT) {
+        const int r = e / lcols, c = e - r * lcols;
+        const int yy = ly0 + r, xx = lx0 + c;
+        int lab = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? labels[(long)yy * w + xx] : 0;
+        L[r * lcols + c] = (lab >= 0 && lab < MANET_MAX_IDS) ? (unsigned char)lab : (unsigned char)255;
+    }
+    __syncthreads();
+    const int nd_here = (P - dy0) < ND ? (P - dy0) : ND;  // window rows this workgroup really owns
+    for (int pix = tid; pix < ny * nx; pix += NT) {
+        const int py = pix / nx, pxx = pix - py * nx;
+        const int y = ya + py, x = xa + pxx;
+        const Bilin cy = bilin_coeff(y, hp, h), cx = bilin_coeff(x, wp, w);
+        const int r0 = (cy.i0 - a) * LF_SX, r1 = (cy.i1 - a) * LF_SX, q0 = cx.i0 - b0, q1 = cx.i1 - b0;
+        for (int o0 = 0; o0 < n_ids; o0 += NI) {
+            float m[NI];
+#pragma unroll
+            for (int k = 0; k < NI; ++k) m[k] = INFINITY;
+            for (int by = 0; by < ((abl & 2) ? 0 : nd_here); ++by) {
+                const unsigned char *lrow = L + (py + 2 * by) * lcols + pxx;
+                const float *vp = V + (by * P) * SY * LF_SX;
+#pragma unroll 5
+                for (int bx = 0; bx < P; ++bx) {
+                    const int lab = lrow[2 * bx];
+                    const float *pl = vp + bx * SY * LF_SX;
+                    const float v = cy.l0 * (cx.l0 * pl[r0 + q0] + cx.l1 * pl[r0 + q1]) +
+                                    cy.l1 * (cx.l0 * pl[r1 + q0] + cx.l1 * pl[r1 + q1]);
+#pragma unroll
+                    for (int k = 0; k < NI; ++k) m[k] = fminf(m[k], (lab == o0 + k) ? v : 1.0f);
+                }
+            }
+            float *o = out + ((long)y * w + x) * n_ids + o0;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                if (o0 + k < n_ids) {
+                    if (NDG == 1) o[k] = m[k];
+                    else atomicMin((unsigned *)(o + k), __float_as_uint(m[k]));  // values in [0, 1]: uint order = float order
+                }
+            }
+        }
+    }
+}
+
+template <int D>
+static void launch_fused_d(hipStream_t st, const float *ap, const float *bp, const PoolPad &G, const int *labels, int h,
+                           int w, int C, int n_ids, float *out)
+{
+    constexpr int TY = lf_sy(D) - 1, TX = LF_SX - 1;
+    // i0 runs over 0..hp-1 (the last value only for the last row); tiles cover all of them
+    dim3 grid((unsigned)((G.wp + TX - 1) / TX), (unsigned)((G.hp + TY - 1) / TY), (unsigned)lf_ndg(D));
+    const size_t lds = lf_lds_bytes(D);
+    (void)hipFuncSetAttribute((const void *)local_fused_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(local_fused_kernel<D>, grid, dim3(lf_nt(D)), lds, st, ap, bp, G.WS, G.plane, labels, h, w, C, n_ids,
+                       out, manet_tune_get(MANET_TUNE_ABLATION, 0));
+}
+
+__global__ void fill_f32_kernel(float *__restrict__ p, float v, long n)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// `pooled`: room for the two padded pooled frames (2 * C * lf_pool_pad().plane floats)
+static void launch_fused(int d, hipStream_t st, const float *cur, long c_sy, long c_sx, long c_sc, const float *prev,
+                         long p_sy, long p_sx, long p_sc, const int *labels, int h, int w, int C, int n_ids, float *out,
+                         float *pooled)
+{
+    const PoolPad G = lf_pool_pad(h, w, d);
+    float *ap = pooled, *bp = pooled + G.plane * C;
+    {
+        long n = G.plane * C;
+        hipLaunchKernelGGL(lf_pool_pad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cur, c_sy, c_sx, c_sc,
+                           prev, p_sy, p_sx, p_sc, C, G.hp, G.wp, d, G.HPAD, G.WS, ap, bp);
+    }
+    if (lf_ndg(d) > 1) {  // partial minima meet by atomicMin: start from the "no match" value
+        long n = (long)h * w * n_ids;
+        unsigned blocks = (unsigned)((n + 255) / 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(fill_f32_kernel, dim3(blocks), dim3(256), 0, st, out, 1.0f, n);
+    }
+#define MANET_LF_CASE(D_) case D_: launch_fused_d<D_>(st, ap, bp, G, labels, h, w, C, n_ids, out); break;
+    switch (d) {
+        MANET_LF_CASE(0) MANET_LF_CASE(1) MANET_LF_CASE(2) MANET_LF_CASE(3) MANET_LF_CASE(4) MANET_LF_CASE(5)
+        MANET_LF_CASE(6) MANET_LF_CASE(7) MANET_LF_CASE(8) MANET_LF_CASE(9) MANET_LF_CASE(10) MANET_LF_CASE(11)
+        MANET_LF_CASE(12)
+    default: break;
+    }
+#undef MANET_LF_CASE
+}
+
 struct LocalLayout {
     int hp, wp, PP;
     size_t off_ap, off_bp, off_vol, total;
@@ -348,9 +698,11 @@ LocalLayout local_layout(int h, int w, int C, int d, int downsample)
     L.hp = downsample ? h / 2 : h;
     L.wp = downsample ? w / 2 : w;
     size_t plane = (size_t)L.hp * L.wp;
+    // pooled frames: the padded planes of the fused path (the unpadded ones of the other paths fit inside)
+    size_t pooled = downsample ? (size_t)lf_pool_pad(h, w, d).plane * C * sizeof(float) : 0;
     L.off_ap = 0;
-    L.off_bp = manet_align_up(downsample ? plane * C * sizeof(float) : 0, 256);
-    L.off_vol = L.off_bp + manet_align_up(downsample ? plane * C * sizeof(float) : 0, 256);
+    L.off_bp = manet_align_up(pooled, 256);
+    L.off_vol = L.off_bp + manet_align_up(pooled, 256);
     L.total = manet_align_up(L.off_vol + plane * L.PP * sizeof(float), 256);
     return L;
 }
@@ -439,6 +791,11 @@ int manet_local_match_f32(const float *prev, int64_t p_sy, int64_t p_sx, int64_t
     if (!workspace || workspace_bytes < L.total)
         return manet_set_error(MANET_E_WORKSPACE, "local workspace %zu < %zu bytes", workspace_bytes, L.total);
     hipStream_t st = (hipStream_t)stream;
+    if (downsample && !manet_tune_get(MANET_TUNE_LOCAL_UNFUSED, 0)) {  // the live configuration: pooling pass + fused kernel
+        launch_fused(max_distance, st, cur, (long)c_sy, (long)c_sx, (long)c_sc, prev, (long)p_sy, (long)p_sx, (long)p_sc,
+                     prev_labels, h, w, C, n_ids, out, (float *)((char *)workspace + L.off_ap));
+        return manet_check_launch("manet_local_match_f32");
+    }
     // IntVOS.py:370: local_pairwise_distances2(query_embedding, prev_frame_embedding)
     float *vol = enqueue_volume(cur, c_sy, c_sx, c_sc, prev, p_sy, p_sx, p_sc, h, w, C, max_distance, downsample,
                                 (char *)workspace, L, st);
