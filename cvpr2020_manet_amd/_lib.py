@@ -40,6 +40,18 @@ SIGNATURES = {
     "manet_tune_set": (_i, [_i, _i]),
     "manet_profile_end": (_i, [ctypes.POINTER(ctypes.c_float), _i, _ip]),
     "manet_correlation_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "manet_global_match_arg_workspace_bytes": (_i, [_i64, _i64, _i, _i, _szp]),
+    "manet_global_match_arg_f32": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp, _sz,
+                                        _vp]),
+    "manet_global_match_backward_f32": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i, _i, _vp,
+                                             _i64, _i64, _vp, _i64, _i64, _vp]),
+    "manet_local_match_arg_workspace_bytes": (_i, [_i, _i, _i, _i, _szp]),
+    "manet_local_match_arg_f32": (_i, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _vp,
+                                       _vp, _vp, _vp, _sz, _vp]),
+    "manet_local_match_backward_workspace_bytes": (_i, [_i, _i, _i, _i, _szp]),
+    "manet_local_match_backward_f32": (_i, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i, _i, _i,
+                                            _i, _i, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "manet_correlation_backward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
 }
 
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2

@@ -1,0 +1,179 @@
+"""torch.autograd.Function wrappers of the matching path's training entry points.
+
+The reference's matching functions are plain PyTorch, so autograd differentiates them for free and
+train_stage1.py:126-156 / train_stage2.py back-propagate through IntVOS.forward.  The HIP path takes raw
+pointers, so the backward is explicit:
+
+  GlobalMatchFn   nearest_neighbor_features_per_object, k = 1 (reference IntVOS.py:160-210): torch.min sends the
+                  gradient to ONE bank row per (query pixel, object) -- the forward kernel records it
+                  (manet_global_match_arg_f32), the backward is a gather / scatter-add
+                  (manet_global_match_backward_f32).
+  LocalMatchFn    local_previous_frame_nearest_neighbor_features_per_object, downsample on (:345-434): the
+                  forward records the winning window offset and keeps the normalised pooled volume; the
+                  backward walks min -> where -> bilinear -> sigmoid -> (x - y)^2 -> avg_pool2d in reverse.
+  CorrelationFn   correlation_package (correlation.py:7-45): forward + manet_correlation_backward_f32.
+
+`ops.global_match` / `ops.local_match` / `ops.correlation_forward` route here when grad mode is on and an
+embedding requires grad; normalisation and the min-merge with the stored map stay ordinary torch ops on the
+result (they are element-wise and torch differentiates them).  fp32 only; anything else raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _scratch(device, nbytes):
+    return torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+
+
+class GlobalMatchFn(torch.autograd.Function):
+    """out [N, n_ids] raw distances; differentiable w.r.t. reference [M0, C] and query [N, C] (any strides)."""
+
+    @staticmethod
+    def forward(ctx, ref, qry, labels, n_ids):
+        lib = _lib.load()
+        M0, C = ref.shape
+        N = qry.shape[0]
+        dev = qry.device
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(lib.manet_global_match_arg_workspace_bytes(N, M0, C, n_ids, ctypes.byref(nbytes)),
+                   "manet_global_match_arg_workspace_bytes")
+        ws = _scratch(dev, nbytes.value)
+        out = torch.empty((N, n_ids), dtype=torch.float32, device=dev)
+        arg = torch.empty((N, n_ids), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.manet_global_match_arg_f32(qry.data_ptr(), qry.stride(0), qry.stride(1), ref.data_ptr(),
+                                                ref.stride(0) if M0 > 0 else C, ref.stride(1) if M0 > 0 else 1,
+                                                labels.data_ptr(), N, M0, C, n_ids, out.data_ptr(), arg.data_ptr(),
+                                                ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "manet_global_match_arg_f32")
+        ctx.save_for_backward(ref, qry, arg)
+        ctx.n_ids = n_ids
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_arg):
+        lib = _lib.load()
+        ref, qry, arg = ctx.saved_tensors
+        M0, C = ref.shape
+        N = qry.shape[0]
+        dev = qry.device
+        g = grad_out.contiguous().float()
+        # gradients in the inputs' own memory order (C-major embeddings stay C-major)
+        gq = torch.empty_strided(qry.shape, qry.stride(), dtype=torch.float32, device=dev) \
+            if _dense(qry) else torch.empty(qry.shape, dtype=torch.float32, device=dev)
+        gr = torch.empty_strided(ref.shape, ref.stride(), dtype=torch.float32, device=dev) \
+            if _dense(ref) else torch.empty(ref.shape, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.manet_global_match_backward_f32(qry.data_ptr(), qry.stride(0), qry.stride(1), ref.data_ptr(),
+                                                     ref.stride(0) if M0 > 0 else C, ref.stride(1) if M0 > 0 else 1,
+                                                     arg.data_ptr(), g.data_ptr(), N, M0, C, ctx.n_ids,
+                                                     gq.data_ptr(), gq.stride(0), gq.stride(1), gr.data_ptr(),
+                                                     gr.stride(0) if M0 > 0 else C, gr.stride(1) if M0 > 0 else 1,
+                                                     _stream_ptr(dev))
+        _lib.check(rc, "manet_global_match_backward_f32")
+        return gr, gq, None, None
+
+
+def _dense(t):
+    """non-overlapping and dense (a permuted contiguous tensor): empty_strided can mirror its layout"""
+    if t.numel() == 0:
+        return False
+    sizes_strides = sorted(zip(t.stride(), t.shape))
+    expect = 1
+    for st, sz in sizes_strides:
+        if sz == 1:
+            continue
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
+class LocalMatchFn(torch.autograd.Function):
+    """out [h, w, n_ids]; differentiable w.r.t. prev and cur [h, w, C] (any strides); downsample configuration."""
+
+    @staticmethod
+    def forward(ctx, prev, cur, labels, n_ids, max_distance):
+        lib = _lib.load()
+        h, w, C = cur.shape
+        dev = cur.device
+        P = 2 * max_distance + 1
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(lib.manet_local_match_arg_workspace_bytes(h, w, C, max_distance, ctypes.byref(nbytes)),
+                   "manet_local_match_arg_workspace_bytes")
+        ws = _scratch(dev, nbytes.value)
+        out = torch.empty((h, w, n_ids), dtype=torch.float32, device=dev)
+        arg = torch.empty((h, w, n_ids), dtype=torch.int32, device=dev)
+        vol = torch.empty((P * P, h // 2, w // 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.manet_local_match_arg_f32(prev.data_ptr(), prev.stride(0), prev.stride(1), prev.stride(2),
+                                               cur.data_ptr(), cur.stride(0), cur.stride(1), cur.stride(2),
+                                               labels.data_ptr(), h, w, C, n_ids, max_distance, out.data_ptr(),
+                                               arg.data_ptr(), vol.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               _stream_ptr(dev))
+        _lib.check(rc, "manet_local_match_arg_f32")
+        ctx.save_for_backward(prev, cur, vol, arg)
+        ctx.n_ids, ctx.max_distance = n_ids, max_distance
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        prev, cur, vol, arg = ctx.saved_tensors
+        h, w, C = cur.shape
+        dev = cur.device
+        g = grad_out.contiguous().float()
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(lib.manet_local_match_backward_workspace_bytes(h, w, C, ctx.max_distance, ctypes.byref(nbytes)),
+                   "manet_local_match_backward_workspace_bytes")
+        ws = _scratch(dev, nbytes.value)
+        gp = torch.empty_strided(prev.shape, prev.stride(), dtype=torch.float32, device=dev) \
+            if _dense(prev) else torch.empty(prev.shape, dtype=torch.float32, device=dev)
+        gc = torch.empty_strided(cur.shape, cur.stride(), dtype=torch.float32, device=dev) \
+            if _dense(cur) else torch.empty(cur.shape, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.manet_local_match_backward_f32(prev.data_ptr(), prev.stride(0), prev.stride(1), prev.stride(2),
+                                                    cur.data_ptr(), cur.stride(0), cur.stride(1), cur.stride(2),
+                                                    vol.data_ptr(), arg.data_ptr(), g.data_ptr(), h, w, C, ctx.n_ids,
+                                                    ctx.max_distance, gp.data_ptr(), gp.stride(0), gp.stride(1),
+                                                    gp.stride(2), gc.data_ptr(), gc.stride(0), gc.stride(1),
+                                                    gc.stride(2), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "manet_local_match_backward_f32")
+        return gp, gc, None, None, None
+
+
+class CorrelationFn(torch.autograd.Function):
+    """correlation_package's CorrelationFunction (correlation.py:7-45) on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2):
+        from . import ops
+        a = input1.float().contiguous()
+        b = input2.float().contiguous()
+        ctx.save_for_backward(a, b)
+        ctx.params = (pad_size, kernel_size, max_displacement, stride1, stride2)
+        with torch.no_grad():
+            return ops.correlation_forward(a, b, pad_size, kernel_size, max_displacement, stride1, stride2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        a, b = ctx.saved_tensors
+        B, C, H, W = a.shape
+        pad_size, kernel_size, max_displacement, stride1, stride2 = ctx.params
+        g = grad_out.contiguous().float()
+        ga, gb = torch.empty_like(a), torch.empty_like(b)
+        with torch.cuda.device(a.device):
+            rc = lib.manet_correlation_backward_f32(a.data_ptr(), b.data_ptr(), g.data_ptr(), B, C, H, W, pad_size,
+                                                    kernel_size, max_displacement, stride1, stride2, ga.data_ptr(),
+                                                    gb.data_ptr(), _stream_ptr(a.device))
+        _lib.check(rc, "manet_correlation_backward_f32")
+        return ga, gb, None, None, None, None, None

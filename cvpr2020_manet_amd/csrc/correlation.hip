@@ -53,6 +53,59 @@ __global__ __launch_bounds__(256) void correlation_forward_kernel(
     out[i] = acc / nelems;
 }
 
+// Backward (reference: correlation_cuda_kernel.cu:150-241 grad wrt input1, :243-334 grad wrt input2; host wrapper
+// correlation_cuda.cc:89-167).  The reference gathers with one 32-thread block per input element and a serial
+// final reduce; here one thread owns one input element (lanes along x) and walks the kernel window and the
+// displacement grid: no atomics, no scratch, no padded copies.
+//   gin1[n][c][ya][xa] = 1/(K*K*C) * sum_{j,i} sum_{tj,ti} gout[n][tc][oy][ox] * in2[n][c][ya + tj*s2][xa + ti*s2]
+//      with oy*s1 = ya + pad - max_disp - j,  ox*s1 = xa + pad - max_disp - i   (integral, inside the output)
+//   gin2[n][c][yb][xb] = the same with in1 sampled at (yb - tj*s2, xb - ti*s2) and
+//      oy*s1 = yb + pad - max_disp - j - tj*s2
+template <bool SECOND>
+__global__ __launch_bounds__(256) void correlation_backward_kernel(
+    const float *__restrict__ other, const float *__restrict__ gout, int B, int C, int H, int W, int pad, int kr,
+    int max_disp, int s1, int s2, int r, int oh, int ow, float nelems, float *__restrict__ gin)
+{
+    const int D = 2 * r + 1;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long plane = (long)H * W;
+    if (idx >= (long)B * C * plane) return;
+    const int x = (int)(idx % W);
+    const int y = (int)((idx / W) % H);
+    const int c = (int)((idx / plane) % C);
+    const int n = (int)(idx / (plane * C));
+    const float *oth = other + ((long)n * C + c) * plane;
+    const float *go = gout + (long)n * D * D * oh * ow;
+    float acc = 0.0f;
+    for (int tj = -r; tj <= r; ++tj)
+        for (int ti = -r; ti <= r; ++ti) {
+            const int tc = (tj + r) * D + (ti + r);
+            // the other input's sample that multiplies this element at displacement (tj, ti)
+            const int yo = SECOND ? y - tj * s2 : y + tj * s2;
+            const int xo = SECOND ? x - ti * s2 : x + ti * s2;
+            if (yo < 0 || yo >= H || xo < 0 || xo >= W) continue;
+            const float ov = oth[(long)yo * W + xo];
+            // first-input position of the product: (y, x) itself, or (yo, xo) when this is the second input
+            const int y1p = (SECOND ? yo : y) + pad - max_disp, x1p = (SECOND ? xo : x) + pad - max_disp;
+            float gs = 0.0f;
+            for (int j = -kr; j <= kr; ++j) {
+                const int ys = y1p - j;
+                if (ys < 0 || ys % s1) continue;
+                const int oy = ys / s1;
+                if (oy >= oh) continue;
+                for (int i = -kr; i <= kr; ++i) {
+                    const int xs = x1p - i;
+                    if (xs < 0 || xs % s1) continue;
+                    const int ox = xs / s1;
+                    if (ox >= ow) continue;
+                    gs += go[((long)tc * oh + oy) * ow + ox];
+                }
+            }
+            acc = fmaf(gs, ov, acc);
+        }
+    gin[idx] = acc / nelems;
+}
+
 }  // namespace
 
 extern "C" {
@@ -91,6 +144,27 @@ int manet_correlation_forward_f32(const float *in1, const float *in2, int B, int
                        (hipStream_t)stream, in1, in2, B, C, H, W, pad_size, kr, max_displacement, stride1, stride2, r,
                        oh, ow, nelems, out);
     return manet_check_launch("manet_correlation_forward_f32");
+}
+
+int manet_correlation_backward_f32(const float *in1, const float *in2, const float *grad_out, int B, int C, int H, int W,
+                                   int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                   float *grad_in1, float *grad_in2, manet_stream_t stream)
+{
+    int oc, oh, ow;
+    int rc = manet_correlation_out_dims(H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &oc, &oh, &ow);
+    if (rc) return rc;
+    if (!in1 || !in2 || !grad_out || !grad_in1 || !grad_in2 || B <= 0 || C <= 0)
+        return manet_set_error(MANET_E_INVALID, "bad arguments");
+    int kr = (kernel_size - 1) / 2;
+    int r = max_displacement / stride2;
+    long total = (long)B * C * H * W;
+    float nelems = (float)(kernel_size * kernel_size * C);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(correlation_backward_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in2,
+                       grad_out, B, C, H, W, pad_size, kr, max_displacement, stride1, stride2, r, oh, ow, nelems, grad_in1);
+    hipLaunchKernelGGL(correlation_backward_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in1,
+                       grad_out, B, C, H, W, pad_size, kr, max_displacement, stride1, stride2, r, oh, ow, nelems, grad_in2);
+    return manet_check_launch("manet_correlation_backward_f32");
 }
 
 }  // extern "C"

@@ -148,7 +148,7 @@ struct MatchLayout {
 
 constexpr int TOPK_SPLITS = 16;  // the top-k path trades a little tail balance for a bounded workspace
 
-MatchLayout match_layout(int64_t N, int C, int n_ids, int compute, int k_nn = 1)
+MatchLayout match_layout(int64_t N, int C, int n_ids, int compute, int k_nn = 1, bool arg = false)
 {
     MatchLayout L;
     L.G = geom_of(C, compute);
@@ -161,6 +161,8 @@ MatchLayout match_layout(int64_t N, int C, int n_ids, int compute, int k_nn = 1)
     L.total = L.off_topk;
     if (k_nn > 1)
         L.total = manet_align_up(L.off_topk + (size_t)TOPK_SPLITS * n_ids * L.N_pad * MANET_MAX_KNN * sizeof(float), 1024);
+    if (arg)  // 64-bit (distance key, bank slot) pairs of the arg-min form live where the top-k lists would
+        L.total = manet_align_up(L.off_topk + (size_t)n_ids * L.N_pad * sizeof(unsigned long long), 1024);
     return L;
 }
 
@@ -489,7 +491,10 @@ __device__ __forceinline__ void topk_insert(float (&m)[K], float d)
 // KNN = 1: masked minimum (IntVOS.py:84-85), splits meet through atomicMin on `keys`.
 // KNN = 8: the MANET_MAX_KNN smallest distances per (query, object) for the top-k path
 //          (IntVOS.py:87-94); every split writes its sorted list to `topk` [S][n_ids][N_pad][8].
-template <int KS, int KNN>
+// ARG (with KNN = 1): also track WHICH bank row attains the minimum (training: the gradient of torch.min flows to
+//          that row only, IntVOS.py:84); splits meet through a 64-bit atomicMin on (distance key << 32 | bank slot)
+//          in `keys64` -- equal distances resolve to the smallest slot, i.e. the first row in the sorted bank.
+template <int KS, int KNN, bool ARG = false>
 __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__restrict__ qpack,
                                                                   const char *__restrict__ bpack,
                                                                   const int *__restrict__ meta,
@@ -498,6 +503,8 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
                                                                   unsigned *__restrict__ keys,
                                                                   float *__restrict__ topk, int block_map)
 {
+    static_assert(!ARG || KNN == 1, "arg-min tracking is the k = 1 path");
+    unsigned long long *keys64 = (unsigned long long *)topk;  // ARG: the top-k region holds the 64-bit pairs
     constexpr int NG = (KS + 3) / 4;
     constexpr size_t TILE_BYTES = bank_tile_bytes(NG);
     constexpr size_t QBLK_BYTES = query_block_bytes(NG);
@@ -576,14 +583,26 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
     while (meta[META_SEG + o + 1] <= t0) ++o;  // object owning tile t0
     int seg_end = meta[META_SEG + o + 1];
     float m0[KNN], m1[KNN];
+    int a0 = -1, a1 = -1;  // ARG: bank slot (without the lane's +4h) of the running minimum, -1 = none yet
     auto reset = [&]() {
 #pragma unroll
         for (int j = 0; j < KNN; ++j) m0[j] = m1[j] = (KNN == 1) ? MANET_WRONG_LABEL_PADDING_DISTANCE : INFINITY;
+        a0 = a1 = -1;
     };
     reset();
 
     auto flush = [&](int obj) {
-        if (KNN == 1) {
+        if (ARG) {
+            unsigned long long k0 = ((unsigned long long)key_of(m0[0]) << 32) | (unsigned)(a0 < 0 ? -1 : a0 + 4 * h);
+            unsigned long long k1 = ((unsigned long long)key_of(m1[0]) << 32) | (unsigned)(a1 < 0 ? -1 : a1 + 4 * h);
+            const unsigned long long o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32);
+            k0 = k0 < o0 ? k0 : o0;
+            k1 = k1 < o1 ? k1 : o1;
+            if (h == 0) {
+                atomicMin(keys64 + (size_t)obj * N_pad + qbase, k0);
+                atomicMin(keys64 + (size_t)obj * N_pad + qbase + 32, k1);
+            }
+        } else if (KNN == 1) {
             float a = min3p(m0[0], m0[0], __shfl_xor(m0[0], 32));
             float c = min3p(m1[0], m1[0], __shfl_xor(m1[0], 32));
             if (h == 0) {
@@ -659,7 +678,13 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
                 const float d01 = fmaf(-2.0f, c01[r], xs1 + y0[i]);
                 const float d10 = fmaf(-2.0f, c10[r], xs0 + y1[i]);
                 const float d11 = fmaf(-2.0f, c11[r], xs1 + y1[i]);
-                if (KNN == 1) {  // NaN-propagating, like torch.min (IntVOS.py:84)
+                if (ARG) {  // strict <: the first row in bank order wins a tie; a NaN never wins
+                    const int slot = t * BT + (r & 3) + 8 * (r >> 2);
+                    if (d00 < m0[0]) { m0[0] = d00; a0 = slot; }
+                    if (d10 < m0[0]) { m0[0] = d10; a0 = slot + 32; }
+                    if (d01 < m1[0]) { m1[0] = d01; a1 = slot; }
+                    if (d11 < m1[0]) { m1[0] = d11; a1 = slot + 32; }
+                } else if (KNN == 1) {  // NaN-propagating, like torch.min (IntVOS.py:84)
                     m0[0] = min3p(m0[0], d00, d10);
                     m1[0] = min3p(m1[0], d01, d11);
                 } else {
@@ -1347,6 +1372,56 @@ __global__ void normalize_merge_kernel(float *__restrict__ x, float *__restrict_
     x[i] = g;
 }
 
+// arg-min form: decode (distance key, bank slot) -> raw distance + source row of the caller's bank (-1: no row)
+__global__ void global_finish_arg_kernel(const unsigned long long *__restrict__ keys64, const int *__restrict__ src_of,
+                                         const int *__restrict__ meta, long N, long N_pad, int n_ids,
+                                         float *__restrict__ out, int *__restrict__ arg)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * n_ids) return;
+    long n = i / n_ids;
+    int o = (int)(i - n * n_ids);
+    const unsigned long long k = keys64[(size_t)o * N_pad + n];
+    const unsigned hi = (unsigned)(k >> 32), slot = (unsigned)k;
+    out[i] = (k == ~0ull) ? MANET_WRONG_LABEL_PADDING_DISTANCE : float_of(hi);
+    arg[i] = (slot != 0xffffffffu && (long)slot < (long)meta[META_T] * BT) ? src_of[slot] : -1;
+}
+
+// Backward of the k = 1 global match w.r.t. both embeddings (reference: autograd through IntVOS.py:32-39 and the
+// torch.min of :84): with m* = arg[n][o] and g = grad_out[n][o],
+//   d/dq_n += 2 g (q_n - k_m*),   d/dk_m* += 2 g (k_m* - q_n)       (d = |q|^2 + |k|^2 - 2 q.k)
+// thread = (query n, channel c), lanes along n; grad_bank is accumulated with atomicAdd (zeroed by the caller side
+// of this entry point).  Element strides for every tensor.
+__global__ void global_match_backward_kernel(const float *__restrict__ q, long q_sn, long q_sc,
+                                             const float *__restrict__ k, long k_sm, long k_sc,
+                                             const int *__restrict__ arg, const float *__restrict__ gout, long N,
+                                             int C, int n_ids, float *__restrict__ gq, long gq_sn, long gq_sc,
+                                             float *__restrict__ gk, long gk_sm, long gk_sc)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const long n = i % N;
+    const int c = (int)(i / N);
+    const float qv = q[n * q_sn + (long)c * q_sc];
+    float acc = 0.0f;
+    for (int o = 0; o < n_ids; ++o) {
+        const int m = arg[n * n_ids + o];
+        const float g = gout[n * n_ids + o];
+        if (m < 0 || g == 0.0f) continue;
+        const float t = 2.0f * g * (qv - k[(long)m * k_sm + (long)c * k_sc]);
+        acc += t;
+        atomicAdd(gk + (long)m * gk_sm + (long)c * gk_sc, -t);
+    }
+    gq[n * gq_sn + (long)c * gq_sc] = acc;
+}
+
+__global__ void zero_strided_kernel(float *__restrict__ p, long n0, long n1, long s0, long s1)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n0 * n1) return;
+    p[(i % n0) * s0 + (i / n0) * s1] = 0.0f;
+}
+
 int check_common(int64_t N, int64_t M0, int C, int n_ids, int k_nn, int compute)
 {
     if (N <= 0 || M0 < 0) return manet_set_error(MANET_E_INVALID, "N=%lld M0=%lld", (long long)N, (long long)M0);
@@ -1364,16 +1439,16 @@ int check_common(int64_t N, int64_t M0, int C, int n_ids, int k_nn, int compute)
     return MANET_OK;
 }
 
-template <int KS, int KNN>
+template <int KS, int KNN, bool ARG = false>
 void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S,
                      long N_pad, unsigned *keys, float *topk, hipStream_t st)
 {
     size_t lds = 2 * bank_tile_bytes((KS + 3) / 4);
     // per call (cheap, host side): the attribute is per device and the library keeps no state
-    (void)hipFuncSetAttribute((const void *)global_match_f32_kernel<KS, KNN>,
+    (void)hipFuncSetAttribute((const void *)global_match_f32_kernel<KS, KNN, ARG>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     manet_profile_record(st, true);
-    hipLaunchKernelGGL((global_match_f32_kernel<KS, KNN>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack,
+    hipLaunchKernelGGL((global_match_f32_kernel<KS, KNN, ARG>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack,
                        bpack, meta, n_ids, nQT, S, N_pad, keys, topk, manet_tune_get(MANET_TUNE_BLOCK_MAP, 0));
     manet_profile_record(st, false);
 }
@@ -1613,6 +1688,81 @@ int manet_global_match(const float *query, int64_t q_stride_n, int64_t q_stride_
     if (rc) return rc;
     return manet_global_match_prepared(query, q_stride_n, q_stride_c, ws, N, M0, C, n_ids, k_nn, compute, out,
                                        mem_inout, epilogue_flags, ws + bbytes, mbytes, stream);
+}
+
+int manet_global_match_arg_workspace_bytes(int64_t N, int64_t M0, int C, int n_ids, size_t *bytes)
+{
+    if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
+    int rc = check_common(N, M0, C, n_ids, 1, MANET_COMPUTE_F32);
+    if (rc) return rc;
+    *bytes = bank_layout(M0, C, n_ids, MANET_COMPUTE_F32).total + match_layout(N, C, n_ids, MANET_COMPUTE_F32, 1, true).total;
+    return MANET_OK;
+}
+
+int manet_global_match_arg_f32(const float *query, int64_t q_stride_n, int64_t q_stride_c, const float *bank,
+                               int64_t b_stride_m, int64_t b_stride_c, const int32_t *labels, int64_t N, int64_t M0,
+                               int C, int n_ids, float *out, int32_t *arg_out, void *workspace, size_t workspace_bytes,
+                               manet_stream_t stream)
+{
+    const int compute = MANET_COMPUTE_F32;
+    int rc = check_common(N, M0, C, n_ids, 1, compute);
+    if (rc) return rc;
+    if (!query || !out || !arg_out || !workspace) return manet_set_error(MANET_E_INVALID, "null pointer");
+    BankLayout BL = bank_layout(M0, C, n_ids, compute);
+    MatchLayout ML = match_layout(N, C, n_ids, compute, 1, true);
+    if (workspace_bytes < BL.total + ML.total)
+        return manet_set_error(MANET_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, BL.total + ML.total);
+    char *bws = (char *)workspace, *mws = bws + BL.total;
+    rc = manet_bank_prepare(bank, b_stride_m, b_stride_c, labels, M0, C, n_ids, compute, bws, BL.total, stream);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int *meta = (const int *)(bws + BL.off_meta);
+    unsigned long long *keys64 = (unsigned long long *)(mws + ML.off_topk);
+    fill32(keys64, 0xffffffffu, (size_t)2 * n_ids * ML.N_pad, st);
+    {
+        size_t lds = (size_t)QB * (ML.G.kpad + 1) * sizeof(float) + 2 * QB * sizeof(int);
+        hipLaunchKernelGGL((pack_rows_kernel<QB, float>), dim3((unsigned)(ML.N_pad / QB)), dim3(256), lds, st, query,
+                           (long)q_stride_n, (long)q_stride_c, (const int *)nullptr, (const int *)nullptr, (long)N,
+                           C, compute, ML.G.units, ML.G.kpad, mws + ML.off_q, (long)ML.qblk_bytes, 0.0f);
+    }
+    int S = pick_splits(ML.nQT, BL.T_max, 512);
+    const char *qpack = mws + ML.off_q, *bpack = bws + BL.off_pack;
+    unsigned *keys = (unsigned *)(mws + ML.off_keys);
+    switch (pick_ks(C)) {
+    case 16: launch_main_f32<16, 1, true>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, (float *)keys64, st); break;
+    case 50: launch_main_f32<50, 1, true>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, (float *)keys64, st); break;
+    case 52: launch_main_f32<52, 1, true>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, (float *)keys64, st); break;
+    default: launch_main_f32<64, 1, true>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, (float *)keys64, st); break;
+    }
+    long total = (long)N * n_ids;
+    hipLaunchKernelGGL(global_finish_arg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const unsigned long long *)keys64, (const int *)(bws + BL.off_src), meta, (long)N, ML.N_pad, n_ids,
+                       out, arg_out);
+    return manet_check_launch("manet_global_match_arg_f32");
+}
+
+int manet_global_match_backward_f32(const float *query, int64_t q_stride_n, int64_t q_stride_c, const float *bank,
+                                    int64_t b_stride_m, int64_t b_stride_c, const int32_t *arg, const float *grad_out,
+                                    int64_t N, int64_t M0, int C, int n_ids, float *grad_query, int64_t gq_stride_n,
+                                    int64_t gq_stride_c, float *grad_bank, int64_t gb_stride_m, int64_t gb_stride_c,
+                                    manet_stream_t stream)
+{
+    int rc = check_common(N, M0, C, n_ids, 1, MANET_COMPUTE_F32);
+    if (rc) return rc;
+    if (!query || !arg || !grad_out || !grad_query || (M0 > 0 && (!bank || !grad_bank)))
+        return manet_set_error(MANET_E_INVALID, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (M0 > 0) {
+        long tb = (long)M0 * C;
+        hipLaunchKernelGGL(zero_strided_kernel, dim3((unsigned)((tb + 255) / 256)), dim3(256), 0, st, grad_bank, (long)M0,
+                           (long)C, (long)gb_stride_m, (long)gb_stride_c);
+    }
+    long tq = (long)N * C;
+    hipLaunchKernelGGL(global_match_backward_kernel, dim3((unsigned)((tq + 255) / 256)), dim3(256), 0, st, query,
+                       (long)q_stride_n, (long)q_stride_c, bank, (long)b_stride_m, (long)b_stride_c, arg, grad_out, (long)N, C,
+                       n_ids, grad_query, (long)gq_stride_n, (long)gq_stride_c, grad_bank, (long)gb_stride_m,
+                       (long)gb_stride_c);
+    return manet_check_launch("manet_global_match_backward_f32");
 }
 
 int manet_normalize_merge_f32(float *x, float *mem_inout, int64_t n, int normalize, manet_stream_t stream)

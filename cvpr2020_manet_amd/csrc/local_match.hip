@@ -739,6 +739,126 @@ float *enqueue_volume(const float *cur, int64_t c_sy, int64_t c_sx, int64_t c_sc
     return vol;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Training path: the local match with the winning window offset recorded, and its backward.
+// The reference differentiates IntVOS.py:266-296 + :398-432 by autograd: avg_pool2d -> sum_c (x - y_off)^2 ->
+// (sigmoid - 0.5) * 2 -> bilinear(align_corners) -> where(label mask, ., 1.0) -> min over the window.
+// The gradient of the min flows to ONE window offset per (pixel, object) (none if the constant 1.0 wins).
+
+// local_min_kernel with arg-min: arg[y][x][o] = window offset l = dy*P + dx whose masked value attains the
+// minimum (strict <: the first offset wins a tie), -1 if no matching offset beats the constant 1.0
+__global__ void local_min_arg_kernel(const float *__restrict__ dvol, const int *__restrict__ labels, int h, int w,
+                                     int hp, int wp, int d, int n_ids, float *__restrict__ out, int *__restrict__ arg)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)h * w * n_ids) return;
+    const int o = (int)(i % n_ids);
+    const long pix = i / n_ids;
+    const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+    const int P = 2 * d + 1;
+    const Bilin cy = bilin_coeff(y, hp, h), cx = bilin_coeff(x, wp, w);
+    const long plane = (long)hp * wp;
+    float m = INFINITY;
+    int am = -1;
+    for (int by = 0; by < P; ++by) {
+        const int yy = y + 2 * (by - d);
+        const bool yin = (yy >= 0 && yy < h);
+        for (int bx = 0; bx < P; ++bx) {
+            const int xx = x + 2 * (bx - d);
+            const int lab = (yin && xx >= 0 && xx < w) ? labels[(long)yy * w + xx] : 0;
+            const int l = by * P + bx;
+            const bool hit = (lab == o);
+            const float v = hit ? bilin_sample(dvol + (long)l * plane, wp, cy, cx) : 1.0f;
+            if (v < m) {
+                m = v;
+                am = hit ? l : -1;
+            }
+        }
+    }
+    out[i] = m;
+    arg[i] = am;
+}
+
+// dVn[l][i][j] += g * bilinear weight, for the winning offset of every (pixel, object)  (backward of
+// F.interpolate(..., 'bilinear', align_corners=True) restricted to the offsets the min selected)
+__global__ void local_bwd_scatter_kernel(const int *__restrict__ arg, const float *__restrict__ gout, int h, int w,
+                                         int hp, int wp, int n_ids, float *__restrict__ dvn)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)h * w * n_ids) return;
+    const int l = arg[i];
+    const float g = gout[i];
+    if (l < 0 || g == 0.0f) return;
+    const long pix = i / n_ids;
+    const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+    const Bilin cy = bilin_coeff(y, hp, h), cx = bilin_coeff(x, wp, w);
+    float *pl = dvn + (long)l * hp * wp;
+    atomicAdd(pl + cy.i0 * wp + cx.i0, g * cy.l0 * cx.l0);
+    atomicAdd(pl + cy.i0 * wp + cx.i1, g * cy.l0 * cx.l1);
+    atomicAdd(pl + cy.i1 * wp + cx.i0, g * cy.l1 * cx.l0);
+    atomicAdd(pl + cy.i1 * wp + cx.i1, g * cy.l1 * cx.l1);
+}
+
+// dV = dVn * d/dV[(sigmoid(V) - 0.5) * 2] = dVn * (1 - Vn^2) / 2   (in place; Vn = 1 where V = inf: gradient 0)
+__global__ void local_bwd_dnorm_kernel(const float *__restrict__ vn, float *__restrict__ dvn, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = vn[i];
+    dvn[i] = dvn[i] * (1.0f - v * v) * 0.5f;
+}
+
+// gradients w.r.t. the POOLED frames: V[l][p] = sum_c (x[c][p] - y[c][p + l])^2  =>
+//   gx[c][p] =  sum_l 2 (x[c][p] - y[c][p + l]) dV[l][p]            (p + l inside the image)
+//   gy[c][q] = -sum_l 2 (x[c][q - l] - y[c][q]) dV[l][q - l]        (q - l inside the image)
+__global__ void local_bwd_dist_kernel(const float *__restrict__ xp, const float *__restrict__ yp,
+                                      const float *__restrict__ dv, int C, int hp, int wp, int d,
+                                      float *__restrict__ gxp, float *__restrict__ gyp)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long plane = (long)hp * wp;
+    if (i >= plane * C) return;
+    const int c = (int)(i / plane);
+    const int rem = (int)(i - (long)c * plane);
+    const int py = rem / wp, px = rem - py * wp;
+    const int P = 2 * d + 1;
+    const float *xc = xp + (long)c * plane, *yc = yp + (long)c * plane;
+    const float xv = xc[rem], yv = yc[rem];
+    float gx = 0.0f, gy = 0.0f;
+    for (int dy = 0; dy < P; ++dy) {
+        for (int dx = 0; dx < P; ++dx) {
+            const long l = (long)(dy * P + dx) * plane;
+            const int qy = py + dy - d, qx = px + dx - d;  // neighbour this pixel looked at
+            if (qy >= 0 && qy < hp && qx >= 0 && qx < wp) gx += 2.0f * (xv - yc[qy * wp + qx]) * dv[l + rem];
+            const int sy = py - (dy - d), sx = px - (dx - d);  // pixel that looked at this one
+            if (sy >= 0 && sy < hp && sx >= 0 && sx < wp) gy -= 2.0f * (xc[sy * wp + sx] - yv) * dv[l + sy * wp + sx];
+        }
+    }
+    gxp[i] = gx;
+    gyp[i] = gy;
+}
+
+// backward of the 2x2 average pooling into the caller's (strided) gradient tensors
+__global__ void local_bwd_unpool_kernel(const float *__restrict__ gxp, const float *__restrict__ gyp, int C, int h, int w,
+                                        int hp, int wp, float *__restrict__ gcur, long c_sy, long c_sx, long c_sc,
+                                        float *__restrict__ gprev, long p_sy, long p_sx, long p_sc)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long plane = (long)h * w;
+    if (i >= plane * C) return;
+    const int c = (int)(i / plane);
+    const int rem = (int)(i - (long)c * plane);
+    const int y = rem / w, x = rem - y * w;
+    float a = 0.0f, b = 0.0f;
+    if (y < 2 * hp && x < 2 * wp) {
+        const long j = (long)c * hp * wp + (long)(y / 2) * wp + (x / 2);
+        a = 0.25f * gxp[j];
+        b = 0.25f * gyp[j];
+    }
+    gcur[(long)y * c_sy + (long)x * c_sx + (long)c * c_sc] = a;
+    gprev[(long)y * p_sy + (long)x * p_sx + (long)c * p_sc] = b;
+}
+
 }  // namespace
 
 extern "C" {
@@ -803,6 +923,92 @@ int manet_local_match_f32(const float *prev, int64_t p_sy, int64_t p_sx, int64_t
     hipLaunchKernelGGL(local_min_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * LM_WAVES), 0, st,
                        (const float *)vol, downsample ? 1 : 0, prev_labels, h, w, L.hp, L.wp, max_distance, n_ids, out);
     return manet_check_launch("manet_local_match_f32");
+}
+
+/* training path: downsample configuration only (the reference's live default, config.py:49) */
+int manet_local_match_arg_workspace_bytes(int h, int w, int C, int max_distance, size_t *bytes)
+{
+    return manet_local_workspace_bytes(h, w, C, max_distance, 1, bytes);
+}
+
+int manet_local_match_arg_f32(const float *prev, int64_t p_sy, int64_t p_sx, int64_t p_sc, const float *cur,
+                              int64_t c_sy, int64_t c_sx, int64_t c_sc, const int32_t *prev_labels, int h, int w, int C,
+                              int n_ids, int max_distance, float *out, int32_t *arg_out, float *vol_out, void *workspace,
+                              size_t workspace_bytes, manet_stream_t stream)
+{
+    int rc = check_local(h, w, C, max_distance, 1);
+    if (rc) return rc;
+    if (n_ids <= 0 || n_ids > MANET_MAX_IDS)
+        return manet_set_error(MANET_E_INVALID, "n_ids=%d (supported 1..%d)", n_ids, MANET_MAX_IDS);
+    if (!cur || !prev || !prev_labels || !out || !arg_out || !vol_out) return manet_set_error(MANET_E_INVALID, "null pointer");
+    LocalLayout L = local_layout(h, w, C, max_distance, 1);
+    if (!workspace || workspace_bytes < L.total)
+        return manet_set_error(MANET_E_WORKSPACE, "local workspace %zu < %zu bytes", workspace_bytes, L.total);
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    float *ap = (float *)(ws + L.off_ap), *bp = (float *)(ws + L.off_bp);
+    long n = (long)C * L.hp * L.wp;
+    hipLaunchKernelGGL(pool2x2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cur, (long)c_sy, (long)c_sx,
+                       (long)c_sc, prev, (long)p_sy, (long)p_sx, (long)p_sc, C, L.hp, L.wp, ap, bp);
+    long plane = (long)L.hp * L.wp;
+    launch_dist(max_distance, st, (const float *)ap, (long)L.wp, 1L, plane, (const float *)bp, (long)L.wp, 1L, plane, L.hp,
+                L.wp, C, 1, vol_out);  // normalised pooled volume [P*P][hp][wp]: kept for the backward
+    long tot = (long)h * w * n_ids;
+    hipLaunchKernelGGL(local_min_arg_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float *)vol_out,
+                       prev_labels, h, w, L.hp, L.wp, max_distance, n_ids, out, arg_out);
+    return manet_check_launch("manet_local_match_arg_f32");
+}
+
+int manet_local_match_backward_workspace_bytes(int h, int w, int C, int max_distance, size_t *bytes)
+{
+    if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
+    int rc = check_local(h, w, C, max_distance, 1);
+    if (rc) return rc;
+    size_t plane = (size_t)(h / 2) * (w / 2);
+    size_t PP = (size_t)(2 * max_distance + 1) * (2 * max_distance + 1);
+    *bytes = manet_align_up(4 * plane * C * sizeof(float), 256) + manet_align_up(plane * PP * sizeof(float), 256);
+    return MANET_OK;
+}
+
+int manet_local_match_backward_f32(const float *prev, int64_t p_sy, int64_t p_sx, int64_t p_sc, const float *cur,
+                                   int64_t c_sy, int64_t c_sx, int64_t c_sc, const float *vol, const int32_t *arg,
+                                   const float *grad_out, int h, int w, int C, int n_ids, int max_distance,
+                                   float *grad_prev, int64_t gp_sy, int64_t gp_sx, int64_t gp_sc, float *grad_cur,
+                                   int64_t gc_sy, int64_t gc_sx, int64_t gc_sc, void *workspace, size_t workspace_bytes,
+                                   manet_stream_t stream)
+{
+    int rc = check_local(h, w, C, max_distance, 1);
+    if (rc) return rc;
+    if (!cur || !prev || !vol || !arg || !grad_out || !grad_prev || !grad_cur || !workspace)
+        return manet_set_error(MANET_E_INVALID, "null pointer");
+    size_t need = 0;
+    (void)manet_local_match_backward_workspace_bytes(h, w, C, max_distance, &need);
+    if (workspace_bytes < need) return manet_set_error(MANET_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
+    const int hp = h / 2, wp = w / 2, P = 2 * max_distance + 1;
+    const long plane = (long)hp * wp;
+    hipStream_t st = (hipStream_t)stream;
+    float *ap = (float *)workspace, *bp = ap + plane * C, *gxp = bp + plane * C, *gyp = gxp + plane * C;
+    float *dvn = (float *)((char *)workspace + manet_align_up(4 * (size_t)plane * C * sizeof(float), 256));
+    long n = plane * C;
+    hipLaunchKernelGGL(pool2x2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cur, (long)c_sy, (long)c_sx,
+                       (long)c_sc, prev, (long)p_sy, (long)p_sx, (long)p_sc, C, hp, wp, ap, bp);
+    long nv = plane * P * P;
+    {
+        unsigned blocks = (unsigned)((nv + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(fill_f32_kernel, dim3(blocks), dim3(256), 0, st, dvn, 0.0f, nv);
+    }
+    long tot = (long)h * w * n_ids;
+    hipLaunchKernelGGL(local_bwd_scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, arg, grad_out, h, w,
+                       hp, wp, n_ids, dvn);
+    hipLaunchKernelGGL(local_bwd_dnorm_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, vol, dvn, nv);
+    hipLaunchKernelGGL(local_bwd_dist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float *)ap,
+                       (const float *)bp, (const float *)dvn, C, hp, wp, max_distance, gxp, gyp);
+    long nf = (long)h * w * C;
+    hipLaunchKernelGGL(local_bwd_unpool_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, (const float *)gxp,
+                       (const float *)gyp, C, h, w, hp, wp, grad_cur, (long)gc_sy, (long)gc_sx, (long)gc_sc, grad_prev,
+                       (long)gp_sy, (long)gp_sx, (long)gp_sc);
+    return manet_check_launch("manet_local_match_backward_f32");
 }
 
 }  // extern "C"

@@ -19,7 +19,10 @@ What differs, deliberately:
     IntVOS.py:102,200); CPU tensors raise -- there is no CPU fallback;
   * normalisation + min-aggregation with the stored global map (:611-622) is fused into the
     matching kernel's epilogue;
-  * segmentation heads and the encoder are stock PyTorch-ROCm modules (out of scope).
+  * segmentation heads and the encoder are stock PyTorch-ROCm modules (out of scope, SURVEY.md 8);
+  * training: when grad mode is on and an embedding requires grad, the matching ops route through explicit
+    torch.autograd.Functions (cvpr2020_manet_amd/autograd.py) so that ``loss.backward()`` of
+    train_stage1.py:126-156 reaches the encoder exactly as it does through the reference's pure-PyTorch path.
 """
 import torch
 import torch.nn as nn
@@ -448,7 +451,8 @@ class IntVOS(nn.Module):
             # ---- global map update (:716-723): min-merge of THIS map into the stored one
             if seq_names[n] not in global_map_tmp_dic:
                 global_map_tmp_dic[seq_names[n]] = torch.ones_like(nn_features_n).repeat(MAX_CLIP_FRAMES, 1, 1, 1, 1)
-            merged = nn_features_n.clone()
+            # (the reference stores the merged map detached and never feeds it to the head: IntVOS.py:718-723)
+            merged = nn_features_n.detach().clone()
             ops.normalize_merge_(merged, global_map_tmp_dic[seq_names[n]][frame_num[n]], normalize=False)
             # ---- local map memory (:725-736)
             if local_map_dics is not None:

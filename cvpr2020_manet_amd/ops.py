@@ -26,7 +26,7 @@ def _refuse_autograd(what, *tensors):
     reference's functions are differentiable (train_stage1.py:126-156 back-propagates through them), so
     silently detaching would train the heads with zero gradient through the match maps: raise instead.
     Ops that do have a backward (`global_match`, `local_match`, `correlation_forward`) route through their
-    torch.autograd.Function in cvpr2020_manet_amd.autograd before they get here."""
+    torch.autograd.Function in cvpr2020_manet_amd.autograd instead of coming here."""
     if not torch.is_grad_enabled():
         return
     for t in tensors:
@@ -34,6 +34,37 @@ def _refuse_autograd(what, *tensors):
             raise RuntimeError("cvpr2020_manet_amd.ops.%s: an input requires grad, but this op has no "
                                "backward -- call it under torch.no_grad() or detach the input "
                                "(gradients would otherwise be dropped silently)" % what)
+
+
+def _wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
+def _global_match_autograd(reference_embeddings, query_embeddings, reference_labels, n_ids, k_nearest_neighbors,
+                           compute, normalize, mem):
+    """Training route of global_match (train_stage1.py:126-156 back-propagates through it): the arg-min forward +
+    explicit backward of autograd.GlobalMatchFn; normalisation (IntVOS.py:611-612) and the min-merge with the
+    stored map (:620-622, the stored copy detached as in the reference) are ordinary differentiable torch ops."""
+    from .autograd import GlobalMatchFn
+    if k_nearest_neighbors != 1 or COMPUTE[compute] != _lib.COMPUTE_F32:
+        raise RuntimeError("cvpr2020_manet_amd.ops.global_match: the backward exists for k_nearest_neighbors=1, "
+                           "compute='f32' only (got k=%d, compute=%r)" % (k_nearest_neighbors, compute))
+    ref, M0, C = _flat(reference_embeddings, "reference_embeddings")
+    qry, N, C2 = _flat(query_embeddings, "query_embeddings")
+    if C != C2:
+        raise ValueError("embedding_dim mismatch: %d vs %d" % (C, C2))
+    lab = _labels(reference_labels, "reference_labels")
+    if lab.numel() != M0:
+        raise ValueError("reference_labels has %d entries for %d reference pixels" % (lab.numel(), M0))
+    out, _ = GlobalMatchFn.apply(ref, qry, lab, n_ids)
+    if normalize:
+        out = (torch.sigmoid(out) - 0.5) * 2
+    if mem is not None:
+        m = mem.view_as(out)
+        out = torch.where(out <= m, out, m)
+        with torch.no_grad():
+            m.copy_(out)
+    return out
 
 
 def _stream_ptr(device):
@@ -73,7 +104,9 @@ def global_match(reference_embeddings, query_embeddings, reference_labels, n_ids
     Returns float32 [N, n_ids] (N = number of query pixels), raw or normalised distances.
     """
     import ctypes
-    _refuse_autograd("global_match", reference_embeddings, query_embeddings, mem)
+    if _wants_grad(reference_embeddings, query_embeddings, mem):
+        return _global_match_autograd(reference_embeddings, query_embeddings, reference_labels, n_ids,
+                                      k_nearest_neighbors, compute, normalize, mem)
     lib = _lib.load()
     ref, M0, C = _flat(reference_embeddings, "reference_embeddings")
     qry, N, C2 = _flat(query_embeddings, "query_embeddings")
@@ -225,7 +258,19 @@ def local_match(prev_frame_embedding, query_embedding, prev_frame_labels, n_ids,
     """local_previous_frame_nearest_neighbor_features_per_object (IntVOS.py:345-434) -> [h, w, n_ids]."""
     import ctypes
     lib = _lib.load()
-    _refuse_autograd("local_match", prev_frame_embedding, query_embedding)
+    if _wants_grad(prev_frame_embedding, query_embedding):
+        from .autograd import LocalMatchFn
+        if not downsample:
+            raise RuntimeError("cvpr2020_manet_amd.ops.local_match: the backward exists for the downsample "
+                               "configuration (MODEL_LOCAL_DOWNSAMPLE=True, the reference's default) only")
+        prev = _hwc(prev_frame_embedding, "prev_frame_embedding")
+        cur = _hwc(query_embedding, "query_embedding")
+        if tuple(prev.shape) != tuple(cur.shape):
+            raise ValueError("prev_frame_embedding and query_embedding must have the same shape")
+        lab = _labels(prev_frame_labels, "prev_frame_labels")
+        if lab.numel() != cur.shape[0] * cur.shape[1]:
+            raise ValueError("prev_frame_labels must have height*width entries")
+        return LocalMatchFn.apply(prev, cur, lab, n_ids, max_distance)
     prev = _hwc(prev_frame_embedding, "prev_frame_embedding")
     cur = _hwc(query_embedding, "query_embedding")
     h, w, C = cur.shape
@@ -262,7 +307,11 @@ def correlation_out_dims(H, W, pad_size, kernel_size, max_displacement, stride1,
 def correlation_forward(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2):
     """correlation_cuda.forward (correlation_cuda.cc:10-87) -> [B, (2r+1)^2, outH, outW] fp32."""
     lib = _lib.load()
-    _refuse_autograd("correlation_forward", input1, input2)
+    if _wants_grad(input1, input2):
+        from .autograd import CorrelationFn
+        _need_gpu(input1, "input1")
+        _need_gpu(input2, "input2")
+        return CorrelationFn.apply(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2)
     _need_gpu(input1, "input1")
     _need_gpu(input2, "input2")
     a = input1.float().contiguous()

@@ -20,6 +20,9 @@
  *   manet_correlation_forward_f32
  *                             correlation_package/correlation_cuda.cc:10-87 (pybind `forward`)
  *                             + correlation_cuda_kernel.cu:46-147.
+ *   manet_*_arg_f32 / manet_*_backward_f32
+ *                             torch.autograd through the two functions above (train_stage1.py:126-156)
+ *                             and correlation_cuda.backward (correlation_cuda.cc:89-167)
  *   manet_upsample_argmax     test.py:253-255 + networks/IntVOS.py:598-599
  *   manet_dwconv7x7_bn_relu_f32  networks/IntVOS.py:491-493,500-502
  *
@@ -172,6 +175,65 @@ int manet_dwconv7x7_bn_relu_f32(const float *in, int B, int C, int h, int w, con
                                 float *out, manet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Training path: what torch.autograd does for the reference's pure-PyTorch path
+ * (train_stage1.py:126-156 back-propagates through IntVOS.forward) and what
+ * correlation_cuda.backward does for the native op (correlation_cuda.cc:89-167,
+ * correlation_cuda_kernel.cu:150-334).  The Python side wraps these in torch.autograd.Function
+ * (cvpr2020_manet_amd/autograd.py).  fp32, k_nearest_neighbors = 1, downsample configuration.
+ *
+ * manet_global_match_arg_f32: manet_global_match (MANET_COMPUTE_F32, k_nn = 1, no epilogue; `out` is
+ *   bit-identical to it) that also returns arg_out [N][n_ids] int32 = the row of the caller's bank
+ *   whose distance is the minimum (the element torch.min differentiates through, IntVOS.py:84);
+ *   equal distances resolve to the first such row of the object-sorted bank, -1 if the object has no row.
+ * manet_global_match_backward_f32: with m* = arg[n][o], g = grad_out[n][o]:
+ *   grad_query[n] = sum_o 2 g (q_n - k_m*),  grad_bank[m] = sum over (n,o) with m* = m of 2 g (k_m - q_n)
+ *   (d = |q|^2 + |k|^2 - 2 q.k, IntVOS.py:32-39).  Both gradient tensors take element strides and are
+ *   fully overwritten (grad_bank is zeroed, then accumulated with atomicAdd: summation order is not
+ *   deterministic, like torch's own scatter-add backward). */
+int manet_global_match_arg_workspace_bytes(int64_t N, int64_t M0, int C, int n_ids, size_t *bytes);
+int manet_global_match_arg_f32(const float *query, int64_t q_stride_n, int64_t q_stride_c,
+                               const float *bank, int64_t b_stride_m, int64_t b_stride_c,
+                               const int32_t *labels, int64_t N, int64_t M0, int C, int n_ids,
+                               float *out, int32_t *arg_out, void *workspace, size_t workspace_bytes,
+                               manet_stream_t stream);
+int manet_global_match_backward_f32(const float *query, int64_t q_stride_n, int64_t q_stride_c,
+                                    const float *bank, int64_t b_stride_m, int64_t b_stride_c,
+                                    const int32_t *arg, const float *grad_out, int64_t N, int64_t M0,
+                                    int C, int n_ids, float *grad_query, int64_t gq_stride_n,
+                                    int64_t gq_stride_c, float *grad_bank, int64_t gb_stride_m,
+                                    int64_t gb_stride_c, manet_stream_t stream);
+
+/* manet_local_match_arg_f32: manet_local_match_f32 (downsample on) that also returns
+ *   arg_out [h][w][n_ids] int32 = the window offset l = dy*(2d+1)+dx whose masked value is the minimum
+ *   (first offset on ties), -1 when the constant 1.0 of IntVOS.py:429-430 wins, and keeps
+ *   vol_out [(2d+1)^2][h/2][w/2] = the normalised pooled distance volume for the backward.
+ * manet_local_match_backward_f32: gradient of `out` w.r.t. both embeddings through
+ *   min -> where -> bilinear(align_corners) -> (sigmoid-0.5)*2 -> sum_c (x - y_off)^2 -> avg_pool2d
+ *   (IntVOS.py:266-296, :398-432).  grad_prev / grad_cur: [h][w][C] with element strides, fully
+ *   overwritten. */
+int manet_local_match_arg_workspace_bytes(int h, int w, int C, int max_distance, size_t *bytes);
+int manet_local_match_arg_f32(const float *prev, int64_t p_sy, int64_t p_sx, int64_t p_sc,
+                              const float *cur, int64_t c_sy, int64_t c_sx, int64_t c_sc,
+                              const int32_t *prev_labels, int h, int w, int C, int n_ids,
+                              int max_distance, float *out, int32_t *arg_out, float *vol_out,
+                              void *workspace, size_t workspace_bytes, manet_stream_t stream);
+int manet_local_match_backward_workspace_bytes(int h, int w, int C, int max_distance, size_t *bytes);
+int manet_local_match_backward_f32(const float *prev, int64_t p_sy, int64_t p_sx, int64_t p_sc,
+                                   const float *cur, int64_t c_sy, int64_t c_sx, int64_t c_sc,
+                                   const float *vol, const int32_t *arg, const float *grad_out, int h,
+                                   int w, int C, int n_ids, int max_distance, float *grad_prev,
+                                   int64_t gp_sy, int64_t gp_sx, int64_t gp_sc, float *grad_cur,
+                                   int64_t gc_sy, int64_t gc_sx, int64_t gc_sc, void *workspace,
+                                   size_t workspace_bytes, manet_stream_t stream);
+
+/* correlation_package backward (correlation_cuda.cc:89-167): gradients w.r.t. both inputs,
+ * [B][C][H][W] fp32 contiguous, fully overwritten. */
+int manet_correlation_backward_f32(const float *in1, const float *in2, const float *grad_out, int B,
+                                   int C, int H, int W, int pad_size, int kernel_size,
+                                   int max_displacement, int stride1, int stride2, float *grad_in1,
+                                   float *grad_in2, manet_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Opt-in measurement hook (not part of the data path, used by bench.py): between _begin and _end
  * every launch of the dominant kernel (the global-match MFMA kernel) is bracketed by two HIP
  * events on its own stream.  manet_profile_end synchronises on those events (the only call in
@@ -180,8 +242,9 @@ int manet_profile_begin(int max_launches);
 /* Tuning knobs for experiments (process-wide; the defaults are the shipped configuration):
  * key 0 = block -> (query tile, bank split) mapping of the global-match kernel (0 XCD-aware),
  * key 1 = forced number of bank splits (0 = automatic),
- * key 2 = workgroup shape of the bf16 kernels (0 = 8 waves, 2 tiles per barrier; 1 = 4 waves;
- *         2 = 8 waves, 1 tile per barrier; 3 = 8 waves, 4 tiles per barrier). */
+ * key 2 = form of the bf16 kernels (bit field, see launch_main_bf16 in csrc/global_match.hip),
+ * key 3 = timing ablations (results are garbage), key 4 = 1: the r1 three-launch local match.
+ * No knob changes a workspace layout. */
 int manet_tune_set(int key, int value);
 int manet_profile_end(float *ms_out, int capacity, int *n_launches);
 

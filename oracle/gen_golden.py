@@ -304,6 +304,84 @@ def variant_config():
     print("wrote config_defaults", len(d))
 
 
+def variant_grad():
+    """8f rank 3: gradients the reference gets from torch.autograd, in TRAINING configuration (TEST_MODE False,
+    train_stage1.py:126-156): d loss / d embeddings through the global match (+ normalisation), through the
+    local match, and through a whole IntVOS.forward step with tiny heads (module in train() mode)."""
+    torch, R = import_reference(["--TEST_MODE", "False", "--MODEL_SEMANTIC_EMBEDDING_DIM", "12",
+                                 "--MODEL_HEAD_EMBEDDING_DIM", "8", "--MODEL_ASPP_OUTDIM", "6",
+                                 "--MODEL_MAX_LOCAL_DISTANCE", "2"])
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(20200620)
+    out = {}
+    # ---- global match, k = 1, labels incl. -1 and an object without pixels (id 3)
+    C, h, w = 16, 11, 14
+    ref = emb(torch, g, C, h, w).requires_grad_(True)
+    qry = emb(torch, g, C, h, w).requires_grad_(True)
+    lab = torch.randint(-1, 3, (h, w, 1), generator=g).int()
+    o, _ = R.nearest_neighbor_features_per_object(ref.permute(1, 2, 0), qry.permute(1, 2, 0), lab, 1,
+                                                  gt_ids=torch.tensor(3.), n_chunks=3)
+    wgt = torch.randn(o.shape, generator=g)
+    norm = (torch.sigmoid(o) - 0.5) * 2
+    g_ref, g_qry = torch.autograd.grad((norm * wgt).sum(), [ref, qry])
+    out.update(g_ref_chw=ref.detach(), g_qry_chw=qry.detach(), g_labels=lab, g_weight=wgt, g_out=o.detach(),
+               g_grad_ref=g_ref, g_grad_qry=g_qry)
+    # raw (un-normalised) distances too
+    o2, _ = R.nearest_neighbor_features_per_object(ref.permute(1, 2, 0), qry.permute(1, 2, 0), lab, 1,
+                                                   gt_ids=torch.tensor(2.), n_chunks=2)
+    wgt2 = torch.randn(o2.shape, generator=g)
+    g_ref2, g_qry2 = torch.autograd.grad((o2 * wgt2).sum(), [ref, qry])
+    out.update(g_weight_raw=wgt2, g_grad_ref_raw=g_ref2, g_grad_qry_raw=g_qry2)
+    # ---- local match (downsample on, the default), several sizes incl. odd ones
+    for i, (C, h, w, d, nobj) in enumerate([(16, 12, 15, 2, 2), (8, 9, 11, 1, 1), (20, 14, 18, 4, 3)]):
+        prev = emb(torch, g, C, h, w).requires_grad_(True)
+        cur = emb(torch, g, C, h, w).requires_grad_(True)
+        lab = torch.randint(0, nobj + 1, (h, w, 1), generator=g).int()
+        ids = torch.arange(0, nobj + 1).int()
+        o = R.local_previous_frame_nearest_neighbor_features_per_object(prev.permute(1, 2, 0), cur.permute(1, 2, 0), lab,
+                                                                      ids, max_distance=d)
+        wgt = torch.randn(o.shape, generator=g)
+        gp, gc = torch.autograd.grad((o * wgt).sum(), [prev, cur])
+        out.update({"l%d_prev_chw" % i: prev.detach(), "l%d_cur_chw" % i: cur.detach(), "l%d_labels" % i: lab,
+                    "l%d_d" % i: d, "l%d_n_ids" % i: nobj + 1, "l%d_weight" % i: wgt, "l%d_out" % i: o.detach(),
+                    "l%d_grad_prev" % i: gp, "l%d_grad_cur" % i: gc})
+    # ---- one training step through IntVOS.forward (train_stage1.py:126-156 shape) with tiny heads
+    torch.manual_seed(20200621)
+
+    class TinyExtractor(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = nn.Conv2d(3, 6, 3, stride=4, padding=1)
+            self.cls_conv = nn.Identity()
+            self.upsample4 = nn.Identity()
+
+        def forward(self, x):
+            return self.conv(x)
+
+    model = R.IntVOS(R.cfg, TinyExtractor())
+    model.train()
+    H, W = 40, 52
+    x3 = torch.randn(3, 3, H, W)  # [ref; prev; cur]
+    nobj = 2
+    ref_lab = torch.randint(0, nobj + 1, (1, 1, H, W)).float()
+    prev_lab = torch.randint(0, nobj + 1, (1, 1, H, W)).float()
+    sd0 = {("sd::" + k): v.clone() for k, v in model.state_dict().items()}
+    dic = model.forward(x3, ref_lab, prev_lab, seq_names=["clip"], gt_ids=torch.Tensor([nobj]), k_nearest_neighbors=1,
+                        global_map_tmp_dic=None, local_map_dics=None, interaction_num=1, start_annotated_frame=0,
+                        frame_num=[2])
+    logits = dic["clip"]
+    wl = torch.randn(logits.shape)
+    (logits * wl).sum().backward()
+    names = ["feature_extracter.conv.weight", "embedding_conv.weight", "seperate_conv.weight",
+             "dynamic_seghead.layer1.conv1.weight", "dynamic_seghead.conv.weight"]
+    params = dict(model.named_parameters())
+    for nme in names:
+        out["t_grad::" + nme] = params[nme].grad.clone()
+    out.update(t_x=x3, t_ref_lab=ref_lab, t_prev_lab=prev_lab, t_logits=logits.detach(), t_wl=wl, t_nobj=nobj,
+               t_grad_names=np.array(names))
+    save("grad_tiny", **out, **sd0)
+
+
 VARIANTS = {
     "global_tm1": lambda: variant_global(True),
     "global_tm0": lambda: variant_global(False),
@@ -315,6 +393,7 @@ VARIANTS = {
     "mask_step": variant_mask_step,
     "seg_head": variant_seg_head,
     "config": variant_config,
+    "grad": variant_grad,
 }
 
 if __name__ == "__main__":

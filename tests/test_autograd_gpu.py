@@ -1,0 +1,171 @@
+"""gradients of the matching path against what torch.autograd gives the reference.
+`tests/golden/grad_tiny.npz` was produced by oracle/gen_golden.py:variant_grad, which imports the reference and
+calls torch.autograd.grad / loss.backward() on its functions and on a whole IntVOS.forward training step
+(train_stage1.py:126-156 shape) with tiny heads.  Tolerances: fp32 rounding through ~10 ops (rtol 2e-4) -- the
+reference's own torch.matmul / pow / sum orders differ from the kernels' fmaf chains."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import load_golden
+from test_intvos_module import TinyExtractor
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 2e-4, 2e-6
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from cvpr2020_manet_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def g():
+    return load_golden("grad_tiny")
+
+
+def dev(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.requires_grad_(True) if grad else t
+
+
+def test_global_match_gradients_match_reference_autograd(ops, g):
+    ref, qry = dev(g["g_ref_chw"], True), dev(g["g_qry_chw"], True)
+    lab = dev(g["g_labels"])
+    out = ops.global_match(ref.permute(1, 2, 0), qry.permute(1, 2, 0), lab, 4, normalize=True)
+    assert out.requires_grad
+    # forward: same values as the no-grad kernel, bit for bit
+    with torch.no_grad():
+        plain = ops.global_match(ref.permute(1, 2, 0), qry.permute(1, 2, 0), lab, 4, normalize=True)
+    assert torch.equal(out.detach(), plain)
+    w = dev(g["g_weight"]).reshape(out.shape)
+    gr, gq = torch.autograd.grad((out * w).sum(), [ref, qry])
+    np.testing.assert_allclose(gr.cpu().numpy(), g["g_grad_ref"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(gq.cpu().numpy(), g["g_grad_qry"], rtol=RTOL, atol=ATOL)
+    # raw distances, 3 ids
+    out = ops.global_match(ref.permute(1, 2, 0), qry.permute(1, 2, 0), lab, 3)
+    w = dev(g["g_weight_raw"]).reshape(out.shape)
+    gr, gq = torch.autograd.grad((out * w).sum(), [ref, qry])
+    np.testing.assert_allclose(gr.cpu().numpy(), g["g_grad_ref_raw"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(gq.cpu().numpy(), g["g_grad_qry_raw"], rtol=RTOL, atol=ATOL)
+
+
+def test_global_match_arg_is_the_first_nearest_row(ops):
+    """the recorded bank row really attains the minimum; ties resolve to the first row of the object"""
+    from cvpr2020_manet_amd.autograd import GlobalMatchFn
+    torch.manual_seed(3)
+    C, N, M = 100, 700, 900
+    q = torch.relu(torch.randn(N, C, device="cuda")) * 0.1
+    k = torch.relu(torch.randn(M, C, device="cuda")) * 0.1
+    k[500:520] = k[100:120]  # duplicated rows: exact ties
+    lab = torch.randint(-1, 3, (M,), device="cuda", dtype=torch.int32)
+    lab[500:520] = lab[100:120]
+    out, arg = GlobalMatchFn.apply(k, q, lab, 4)
+    d = (q.double() ** 2).sum(1, keepdim=True) + (k.double() ** 2).sum(1)[None] - 2 * q.double() @ k.double().t()
+    for o in range(4):
+        rows = arg[:, o].long()
+        if not (lab == o).any():
+            assert torch.all(rows == -1) and torch.all(out[:, o] == 1e20)
+            continue
+        assert torch.all(lab[rows] == o)
+        dm = d.masked_fill((lab != o)[None], float("inf"))
+        assert torch.allclose(dm.gather(1, rows[:, None])[:, 0], dm.min(1).values, rtol=0, atol=2e-6)
+        assert not ((rows >= 500) & (rows < 520)).any()  # the earlier twin wins a tie
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_local_match_gradients_match_reference_autograd(ops, g, i):
+    prev, cur = dev(g["l%d_prev_chw" % i], True), dev(g["l%d_cur_chw" % i], True)
+    lab, d, n_ids = dev(g["l%d_labels" % i]), int(g["l%d_d" % i]), int(g["l%d_n_ids" % i])
+    out = ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), lab, n_ids, d)
+    assert out.requires_grad
+    np.testing.assert_allclose(out.detach().cpu().numpy().reshape(g["l%d_out" % i].shape), g["l%d_out" % i],
+                               rtol=1e-5, atol=2e-6)
+    with torch.no_grad():  # the training forward equals the fused inference kernel bit for bit
+        assert torch.equal(out.detach(), ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), lab, n_ids, d))
+    w = dev(g["l%d_weight" % i]).reshape(out.shape)
+    gp, gc = torch.autograd.grad((out * w).sum(), [prev, cur])
+    scale = max(np.abs(g["l%d_grad_cur" % i]).max(), 1e-6)
+    np.testing.assert_allclose(gp.cpu().numpy(), g["l%d_grad_prev" % i], rtol=RTOL, atol=2e-5 * scale)
+    np.testing.assert_allclose(gc.cpu().numpy(), g["l%d_grad_cur" % i], rtol=RTOL, atol=2e-5 * scale)
+
+
+def test_training_step_through_forward_matches_reference(ops, g):
+    """IntVOS.forward in train() mode + backward: logits and parameter gradients of the reference's own run"""
+    from cvpr2020_manet_amd.config import make_cfg
+    from cvpr2020_manet_amd.networks import IntVOS as M
+    cfg = make_cfg(["--TEST_MODE", "False", "--MODEL_SEMANTIC_EMBEDDING_DIM", "12", "--MODEL_HEAD_EMBEDDING_DIM", "8",
+                    "--MODEL_ASPP_OUTDIM", "6", "--MODEL_MAX_LOCAL_DISTANCE", "2"])
+    model = M.IntVOS(cfg, TinyExtractor())
+    sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd::")}
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    nobj = int(g["t_nobj"])
+    dic = model.forward(dev(g["t_x"]), dev(g["t_ref_lab"]), dev(g["t_prev_lab"]), seq_names=["clip"],
+                        gt_ids=torch.Tensor([nobj]), k_nearest_neighbors=1, global_map_tmp_dic=None,
+                        local_map_dics=None, interaction_num=1, start_annotated_frame=0, frame_num=[2])
+    logits = dic["clip"]
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["t_logits"], rtol=1e-3, atol=1e-4)
+    (logits * dev(g["t_wl"])).sum().backward()
+    params = dict(model.named_parameters())
+    for name in g["t_grad_names"].tolist():
+        want = g["t_grad::" + name]
+        got = params[name].grad.cpu().numpy()
+        assert np.abs(got).max() > 0  # the gradient really arrived (r1: silently dropped)
+        np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4 * max(np.abs(want).max(), 1e-6))
+
+
+def _corr_reference(a, b, pad, K, md, s1, s2):
+    """differentiable torch restatement of the correlation_package forward contract (correlation_cuda_kernel.cu:73-147)"""
+    B, C, H, W = a.shape
+    kr, r = (K - 1) // 2, md // s2
+    ap = nn.functional.pad(a, (pad,) * 4)
+    bp = nn.functional.pad(b, (pad,) * 4)
+    ph, pw = H + 2 * pad, W + 2 * pad
+    border = kr + md
+    oh = -(-(ph - 2 * border) // s1)
+    ow = -(-(pw - 2 * border) // s1)
+    outs = []
+    for tj in range(-r, r + 1):
+        for ti in range(-r, r + 1):
+            acc = 0
+            for j in range(-kr, kr + 1):
+                for i in range(-kr, kr + 1):
+                    ys = torch.arange(oh) * s1 + md + j
+                    xs = torch.arange(ow) * s1 + md + i
+                    pa = ap[:, :, ys][:, :, :, xs]
+                    pb = bp[:, :, ys + tj * s2][:, :, :, xs + ti * s2]
+                    acc = acc + (pa * pb).sum(1)
+            outs.append(acc / (K * K * C))
+    return torch.stack(outs, 1)
+
+
+@pytest.mark.parametrize("cfgc", [(2, 5, 9, 8, 3, 3, 2, 2, 2), (1, 12, 10, 11, 2, 1, 2, 1, 1), (1, 7, 12, 12, 6, 1, 6, 1, 2)])
+def test_correlation_backward_vs_torch_autograd(ops, cfgc):
+    B, C, H, W, pad, K, md, s1, s2 = cfgc
+    torch.manual_seed(11)
+    a = torch.randn(B, C, H, W, device="cuda", requires_grad=True)
+    b = torch.randn(B, C, H, W, device="cuda", requires_grad=True)
+    out = ops.correlation_forward(a, b, pad, K, md, s1, s2)
+    ref = _corr_reference(a, b, pad, K, md, s1, s2)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+    w = torch.randn_like(out)
+    ga, gb = torch.autograd.grad((out * w).sum(), [a, b])
+    ra, rb = torch.autograd.grad((ref * w).sum(), [a, b])
+    torch.testing.assert_close(ga, ra, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(gb, rb, rtol=1e-4, atol=1e-6)
+
+
+def test_unsupported_training_configurations_raise(ops):
+    q = (torch.rand(6, 7, 16, device="cuda")).requires_grad_(True)
+    k = torch.rand(6, 7, 16, device="cuda")
+    lab = torch.zeros(6, 7, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="backward exists"):
+        ops.global_match(k, q, lab, 2, compute="bf16")
+    with pytest.raises(RuntimeError, match="backward exists"):
+        ops.global_match(k, q, lab, 2, k_nearest_neighbors=2)
+    with pytest.raises(RuntimeError, match="downsample"):
+        ops.local_match(k, q, lab, 2, 2, downsample=False)
