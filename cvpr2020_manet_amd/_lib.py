@@ -40,6 +40,15 @@ SIGNATURES = {
     "manet_tune_set": (_i, [_i, _i]),
     "manet_profile_end": (_i, [ctypes.POINTER(ctypes.c_float), _i, _ip]),
     "manet_correlation_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "manet_bank_prepare_ex": (_i, [_vp, _i, _i64, _i64, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
+    "manet_query_pack_bytes": (_i, [_i64, _i, _i, _szp]),
+    "manet_query_pack": (_i, [_vp, _i, _i64, _i64, _i64, _i, _i, _vp, _sz, _vp]),
+    "manet_global_match_prepared_ex": (_i, [_vp, _i, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _sz,
+                                            _vp]),
+    "manet_global_match_ex": (_i, [_vp, _i, _i64, _i64, _vp, _i, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp,
+                                   _i, _vp, _sz, _vp]),
+    "manet_local_match_ex": (_i, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i, _vp, _i, _i, _i, _i, _i, _i, _vp,
+                                  _vp, _sz, _vp]),
     "manet_global_match_arg_workspace_bytes": (_i, [_i64, _i64, _i, _i, _szp]),
     "manet_global_match_arg_f32": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp, _sz,
                                         _vp]),
@@ -55,6 +64,7 @@ SIGNATURES = {
 }
 
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2
+EMB_F32, EMB_BF16, EMB_PACKED = 0, 1, 2
 EPI_NORMALIZE = 1
 
 _lib = None

@@ -1372,6 +1372,26 @@ __global__ void normalize_merge_kernel(float *__restrict__ x, float *__restrict_
     x[i] = g;
 }
 
+// pack launch for either row-block size and either embedding storage type
+template <int ROWS>
+int launch_pack(const void *src, int emb_dtype, long s_row, long s_c, const int *src_of, const int *meta, long n_rows,
+                int C, const Geom &G, char *dst, long nblocks, float pad_norm, hipStream_t st)
+{
+    if (nblocks <= 0) return MANET_OK;
+    const size_t lds = (size_t)ROWS * (G.kpad + 1) * sizeof(float) + 2 * ROWS * sizeof(int);
+    const long blk = ROWS == QB ? (long)G.qblk_bytes : (long)G.tile_bytes;
+    if (emb_dtype == MANET_EMB_F32)
+        hipLaunchKernelGGL((pack_rows_kernel<ROWS, float>), dim3((unsigned)nblocks), dim3(256), lds, st, (const float *)src,
+                           s_row, s_c, src_of, meta, n_rows, C, G.compute, G.units, G.kpad, dst, blk, pad_norm);
+    else if (emb_dtype == MANET_EMB_BF16)
+        hipLaunchKernelGGL((pack_rows_kernel<ROWS, unsigned short>), dim3((unsigned)nblocks), dim3(256), lds, st,
+                           (const unsigned short *)src, s_row, s_c, src_of, meta, n_rows, C, G.compute, G.units, G.kpad,
+                           dst, blk, pad_norm);
+    else
+        return manet_set_error(MANET_E_INVALID, "embedding dtype %d (MANET_EMB_F32 / MANET_EMB_BF16)", emb_dtype);
+    return MANET_OK;
+}
+
 // arg-min form: decode (distance key, bank slot) -> raw distance + source row of the caller's bank (-1: no row)
 __global__ void global_finish_arg_kernel(const unsigned long long *__restrict__ keys64, const int *__restrict__ src_of,
                                          const int *__restrict__ meta, long N, long N_pad, int n_ids,
@@ -1557,6 +1577,14 @@ int manet_bank_prepare(const float *bank, int64_t b_stride_m, int64_t b_stride_c
                        int64_t M0, int C, int n_ids, int compute, void *bank_ws, size_t bank_ws_bytes,
                        manet_stream_t stream)
 {
+    return manet_bank_prepare_ex(bank, MANET_EMB_F32, b_stride_m, b_stride_c, labels, M0, C, n_ids, compute, bank_ws,
+                                 bank_ws_bytes, stream);
+}
+
+int manet_bank_prepare_ex(const void *bank, int emb_dtype, int64_t b_stride_m, int64_t b_stride_c, const int32_t *labels,
+                          int64_t M0, int C, int n_ids, int compute, void *bank_ws, size_t bank_ws_bytes,
+                          manet_stream_t stream)
+{
     int rc = check_common(1, M0, C, n_ids, 1, compute);
     if (rc) return rc;
     if ((M0 > 0 && (!bank || !labels)) || !bank_ws) return manet_set_error(MANET_E_INVALID, "null pointer");
@@ -1578,19 +1606,50 @@ int manet_bank_prepare(const float *bank, int64_t b_stride_m, int64_t b_stride_c
     if (M0 > 0)
         hipLaunchKernelGGL(label_scatter_kernel, dim3((unsigned)L.nblocks), dim3(RPB), 0, st, labels, (long)M0, n_ids,
                            (const int *)hist, (const int *)meta, src_of);
-    {
-        size_t lds = (size_t)BT * (L.G.kpad + 1) * sizeof(float) + 2 * BT * sizeof(int);
-        hipLaunchKernelGGL((pack_rows_kernel<BT, float>), dim3((unsigned)L.T_max), dim3(256), lds, st, bank, (long)b_stride_m,
-                           (long)b_stride_c, (const int *)src_of, (const int *)meta, (long)M0, C, compute, L.G.units,
-                           L.G.kpad, ws + L.off_pack, (long)L.tile_bytes, MANET_WRONG_LABEL_PADDING_DISTANCE);
-    }
+    rc = launch_pack<BT>(bank, emb_dtype, (long)b_stride_m, (long)b_stride_c, (const int *)src_of, (const int *)meta, (long)M0,
+                         C, L.G, ws + L.off_pack, L.T_max, MANET_WRONG_LABEL_PADDING_DISTANCE, st);
+    if (rc) return rc;
     return manet_check_launch("manet_bank_prepare");
+}
+
+int manet_query_pack_bytes(int64_t N, int C, int compute, size_t *bytes)
+{
+    if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
+    int rc = check_common(N, 0, C, 1, 1, compute);
+    if (rc) return rc;
+    MatchLayout ML = match_layout(N, C, 1, compute);
+    *bytes = (size_t)(ML.N_pad / QB) * ML.qblk_bytes;
+    return MANET_OK;
+}
+
+int manet_query_pack(const void *query, int emb_dtype, int64_t q_stride_n, int64_t q_stride_c, int64_t N, int C,
+                     int compute, void *packed, size_t packed_bytes, manet_stream_t stream)
+{
+    int rc = check_common(N, 0, C, 1, 1, compute);
+    if (rc) return rc;
+    if (!query || !packed) return manet_set_error(MANET_E_INVALID, "null pointer");
+    MatchLayout ML = match_layout(N, C, 1, compute);
+    const size_t need = (size_t)(ML.N_pad / QB) * ML.qblk_bytes;
+    if (packed_bytes < need) return manet_set_error(MANET_E_WORKSPACE, "packed query buffer %zu < %zu bytes", packed_bytes, need);
+    rc = launch_pack<QB>(query, emb_dtype, (long)q_stride_n, (long)q_stride_c, nullptr, nullptr, (long)N, C, ML.G,
+                         (char *)packed, ML.N_pad / QB, 0.0f, (hipStream_t)stream);
+    if (rc) return rc;
+    return manet_check_launch("manet_query_pack");
 }
 
 int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t q_stride_c,
                                 const void *bank_ws, int64_t N, int64_t M0, int C, int n_ids, int k_nn,
                                 int compute, float *out, float *mem_inout, int epilogue_flags,
                                 void *match_ws, size_t match_ws_bytes, manet_stream_t stream)
+{
+    return manet_global_match_prepared_ex(query, MANET_EMB_F32, q_stride_n, q_stride_c, bank_ws, N, M0, C, n_ids, k_nn,
+                                          compute, out, mem_inout, epilogue_flags, match_ws, match_ws_bytes, stream);
+}
+
+int manet_global_match_prepared_ex(const void *query, int emb_dtype, int64_t q_stride_n, int64_t q_stride_c,
+                                   const void *bank_ws, int64_t N, int64_t M0, int C, int n_ids, int k_nn,
+                                   int compute, float *out, float *mem_inout, int epilogue_flags,
+                                   void *match_ws, size_t match_ws_bytes, manet_stream_t stream)
 {
     int rc = check_common(N, M0, C, n_ids, k_nn, compute);
     if (rc) return rc;
@@ -1605,13 +1664,14 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
     const int *meta = (const int *)(bws + BL.off_meta);
     unsigned *keys = (unsigned *)(mws + ML.off_keys);
     fill32(keys, 0xffffffffu, (size_t)n_ids * ML.N_pad, st);
-    {
-        size_t lds = (size_t)QB * (ML.G.kpad + 1) * sizeof(float) + 2 * QB * sizeof(int);
-        hipLaunchKernelGGL((pack_rows_kernel<QB, float>), dim3((unsigned)(ML.N_pad / QB)), dim3(256), lds, st, query,
-                           (long)q_stride_n, (long)q_stride_c, (const int *)nullptr, (const int *)nullptr, (long)N,
-                           C, compute, ML.G.units, ML.G.kpad, mws + ML.off_q, (long)ML.qblk_bytes, 0.0f);
+    // MANET_EMB_PACKED: `query` already is the operand image manet_query_pack wrote (same N, C, compute)
+    const char *qpack = (const char *)query;
+    if (emb_dtype != MANET_EMB_PACKED) {
+        rc = launch_pack<QB>(query, emb_dtype, (long)q_stride_n, (long)q_stride_c, nullptr, nullptr, (long)N, C, ML.G,
+                             mws + ML.off_q, ML.N_pad / QB, 0.0f, st);
+        if (rc) return rc;
+        qpack = mws + ML.off_q;
     }
-    // resident workgroup slots: f32 = 2 x 256-thread workgroups per CU, bf16 = 1 x 512-thread workgroup per CU
     // resident workgroup slots: f32 and plain bf16 (wide kernel) = 2 x 256-thread workgroups per CU,
     // split-bf16 (and the tuning-only narrow/flat bf16 forms) = 1 x 512-thread workgroup per CU
     const int bv = manet_tune_get(MANET_TUNE_BF16_VARIANT, 0);
@@ -1623,7 +1683,6 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
         if (forced > 0) S = (forced + 7) / 8 * 8;
     }
     if (k_nn > 1) S = TOPK_SPLITS;
-    const char *qpack = mws + ML.off_q;
     const char *bpack = bws + BL.off_pack;
     float *topk = (float *)(mws + ML.off_topk);
     if (k_nn > 1) {
@@ -1676,6 +1735,16 @@ int manet_global_match(const float *query, int64_t q_stride_n, int64_t q_stride_
                        int C, int n_ids, int k_nn, int compute, float *out, float *mem_inout,
                        int epilogue_flags, void *workspace, size_t workspace_bytes, manet_stream_t stream)
 {
+    return manet_global_match_ex(query, MANET_EMB_F32, q_stride_n, q_stride_c, bank, MANET_EMB_F32, b_stride_m, b_stride_c,
+                                 labels, N, M0, C, n_ids, k_nn, compute, out, mem_inout, epilogue_flags, workspace,
+                                 workspace_bytes, stream);
+}
+
+int manet_global_match_ex(const void *query, int q_dtype, int64_t q_stride_n, int64_t q_stride_c, const void *bank,
+                          int b_dtype, int64_t b_stride_m, int64_t b_stride_c, const int32_t *labels, int64_t N,
+                          int64_t M0, int C, int n_ids, int k_nn, int compute, float *out, float *mem_inout,
+                          int epilogue_flags, void *workspace, size_t workspace_bytes, manet_stream_t stream)
+{
     int rc = check_common(N, M0, C, n_ids, k_nn, compute);
     if (rc) return rc;
     if (!workspace) return manet_set_error(MANET_E_INVALID, "workspace == NULL");
@@ -1684,10 +1753,10 @@ int manet_global_match(const float *query, int64_t q_stride_n, int64_t q_stride_
     if (workspace_bytes < bbytes + mbytes)
         return manet_set_error(MANET_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, bbytes + mbytes);
     char *ws = (char *)workspace;
-    rc = manet_bank_prepare(bank, b_stride_m, b_stride_c, labels, M0, C, n_ids, compute, ws, bbytes, stream);
+    rc = manet_bank_prepare_ex(bank, b_dtype, b_stride_m, b_stride_c, labels, M0, C, n_ids, compute, ws, bbytes, stream);
     if (rc) return rc;
-    return manet_global_match_prepared(query, q_stride_n, q_stride_c, ws, N, M0, C, n_ids, k_nn, compute, out,
-                                       mem_inout, epilogue_flags, ws + bbytes, mbytes, stream);
+    return manet_global_match_prepared_ex(query, q_dtype, q_stride_n, q_stride_c, ws, N, M0, C, n_ids, k_nn, compute, out,
+                                          mem_inout, epilogue_flags, ws + bbytes, mbytes, stream);
 }
 
 int manet_global_match_arg_workspace_bytes(int64_t N, int64_t M0, int C, int n_ids, size_t *bytes)
@@ -1719,12 +1788,9 @@ int manet_global_match_arg_f32(const float *query, int64_t q_stride_n, int64_t q
     const int *meta = (const int *)(bws + BL.off_meta);
     unsigned long long *keys64 = (unsigned long long *)(mws + ML.off_topk);
     fill32(keys64, 0xffffffffu, (size_t)2 * n_ids * ML.N_pad, st);
-    {
-        size_t lds = (size_t)QB * (ML.G.kpad + 1) * sizeof(float) + 2 * QB * sizeof(int);
-        hipLaunchKernelGGL((pack_rows_kernel<QB, float>), dim3((unsigned)(ML.N_pad / QB)), dim3(256), lds, st, query,
-                           (long)q_stride_n, (long)q_stride_c, (const int *)nullptr, (const int *)nullptr, (long)N,
-                           C, compute, ML.G.units, ML.G.kpad, mws + ML.off_q, (long)ML.qblk_bytes, 0.0f);
-    }
+    rc = launch_pack<QB>(query, MANET_EMB_F32, (long)q_stride_n, (long)q_stride_c, nullptr, nullptr, (long)N, C, ML.G,
+                         mws + ML.off_q, ML.N_pad / QB, 0.0f, st);
+    if (rc) return rc;
     int S = pick_splits(ML.nQT, BL.T_max, 512);
     const char *qpack = mws + ML.off_q, *bpack = bws + BL.off_pack;
     unsigned *keys = (unsigned *)(mws + ML.off_keys);

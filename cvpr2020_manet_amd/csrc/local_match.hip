@@ -416,8 +416,11 @@ static PoolPad lf_pool_pad(int h, int w, int d)
 // IntVOS.py:282-284 F.avg_pool2d(x, (2,2), (2,2)) of both frames into padded planes: window summed row-major,
 // times 1/4 (exact) -- the arithmetic of pool2x2_kernel; border = 0 for the current frame (never used), 1e20 for
 // the previous frame (IntVOS.py:287: (x - 1e20)^2 = inf -> 1.0 after normalisation, no bounds logic downstream)
-__global__ void lf_pool_pad_kernel(const float *__restrict__ a, long a_sy, long a_sx, long a_sc,
-                                   const float *__restrict__ b, long b_sy, long b_sx, long b_sc, int C, int hp, int wp,
+__device__ __forceinline__ float lf_ld(const float *p, long i) { return p[i]; }
+__device__ __forceinline__ float lf_ld(const unsigned short *p, long i) { return __uint_as_float((unsigned)p[i] << 16); }  // bf16
+template <typename SRC>  // float, or bf16 as raw 16-bit words (the producer's storage)
+__global__ void lf_pool_pad_kernel(const SRC *__restrict__ a, long a_sy, long a_sx, long a_sc,
+                                   const SRC *__restrict__ b, long b_sy, long b_sx, long b_sc, int C, int hp, int wp,
                                    int d, int HPAD, int WS, float *__restrict__ ap, float *__restrict__ bp)
 {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -429,10 +432,10 @@ __global__ void lf_pool_pad_kernel(const float *__restrict__ a, long a_sy, long 
     int py = r - d, px = col - d;
     float va = 0.0f, vb = 1e20f;
     if (py >= 0 && py < hp && px >= 0 && px < wp) {
-        const float *p = a + (2L * py) * a_sy + (2L * px) * a_sx + (long)c * a_sc;
-        const float *q = b + (2L * py) * b_sy + (2L * px) * b_sx + (long)c * b_sc;
-        va = (((p[0] + p[a_sx]) + p[a_sy]) + p[a_sy + a_sx]) * 0.25f;
-        vb = (((q[0] + q[b_sx]) + q[b_sy]) + q[b_sy + b_sx]) * 0.25f;
+        const SRC *p = a + (2L * py) * a_sy + (2L * px) * a_sx + (long)c * a_sc;
+        const SRC *q = b + (2L * py) * b_sy + (2L * px) * b_sx + (long)c * b_sc;
+        va = (((lf_ld(p, 0) + lf_ld(p, a_sx)) + lf_ld(p, a_sy)) + lf_ld(p, a_sy + a_sx)) * 0.25f;
+        vb = (((lf_ld(q, 0) + lf_ld(q, b_sx)) + lf_ld(q, b_sy)) + lf_ld(q, b_sy + b_sx)) * 0.25f;
     }
     ap[i] = va;
     bp[i] = vb;
@@ -659,16 +662,22 @@ __global__ void fill_f32_kernel(float *__restrict__ p, float v, long n)
 }
 
 // `pooled`: room for the two padded pooled frames (2 * C * lf_pool_pad().plane floats)
-static void launch_fused(int d, hipStream_t st, const float *cur, long c_sy, long c_sx, long c_sc, const float *prev,
-                         long p_sy, long p_sx, long p_sc, const int *labels, int h, int w, int C, int n_ids, float *out,
-                         float *pooled)
+static void launch_fused(int d, hipStream_t st, const void *cur, long c_sy, long c_sx, long c_sc, const void *prev,
+                         long p_sy, long p_sx, long p_sc, int emb_dtype, const int *labels, int h, int w, int C, int n_ids,
+                         float *out, float *pooled)
 {
     const PoolPad G = lf_pool_pad(h, w, d);
     float *ap = pooled, *bp = pooled + G.plane * C;
     {
         long n = G.plane * C;
-        hipLaunchKernelGGL(lf_pool_pad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cur, c_sy, c_sx, c_sc,
-                           prev, p_sy, p_sx, p_sc, C, G.hp, G.wp, d, G.HPAD, G.WS, ap, bp);
+        if (emb_dtype == MANET_EMB_BF16)
+            hipLaunchKernelGGL(lf_pool_pad_kernel<unsigned short>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                               (const unsigned short *)cur, c_sy, c_sx, c_sc, (const unsigned short *)prev, p_sy, p_sx, p_sc, C,
+                               G.hp, G.wp, d, G.HPAD, G.WS, ap, bp);
+        else
+            hipLaunchKernelGGL(lf_pool_pad_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                               (const float *)cur, c_sy, c_sx, c_sc, (const float *)prev, p_sy, p_sx, p_sc, C, G.hp, G.wp, d,
+                               G.HPAD, G.WS, ap, bp);
     }
     if (lf_ndg(d) > 1) {  // partial minima meet by atomicMin: start from the "no match" value
         long n = (long)h * w * n_ids;
@@ -902,8 +911,22 @@ int manet_local_match_f32(const float *prev, int64_t p_sy, int64_t p_sx, int64_t
                           int C, int n_ids, int max_distance, int downsample, float *out, void *workspace,
                           size_t workspace_bytes, manet_stream_t stream)
 {
+    return manet_local_match_ex(prev, p_sy, p_sx, p_sc, cur, c_sy, c_sx, c_sc, MANET_EMB_F32, prev_labels, h, w, C, n_ids,
+                                max_distance, downsample, out, workspace, workspace_bytes, stream);
+}
+
+int manet_local_match_ex(const void *prev_v, int64_t p_sy, int64_t p_sx, int64_t p_sc, const void *cur_v, int64_t c_sy,
+                         int64_t c_sx, int64_t c_sc, int emb_dtype, const int32_t *prev_labels, int h, int w, int C,
+                         int n_ids, int max_distance, int downsample, float *out, void *workspace, size_t workspace_bytes,
+                         manet_stream_t stream)
+{
+    const float *prev = (const float *)prev_v, *cur = (const float *)cur_v;  // (typed below)
     int rc = check_local(h, w, C, max_distance, downsample);
     if (rc) return rc;
+    if (emb_dtype != MANET_EMB_F32 && emb_dtype != MANET_EMB_BF16)
+        return manet_set_error(MANET_E_INVALID, "embedding dtype %d (MANET_EMB_F32 / MANET_EMB_BF16)", emb_dtype);
+    if (emb_dtype == MANET_EMB_BF16 && (!downsample || manet_tune_get(MANET_TUNE_LOCAL_UNFUSED, 0)))
+        return manet_set_error(MANET_E_INVALID, "bf16 embeddings: the downsample configuration (fused path) only");
     if (n_ids <= 0 || n_ids > MANET_MAX_IDS)
         return manet_set_error(MANET_E_INVALID, "n_ids=%d (supported 1..%d)", n_ids, MANET_MAX_IDS);
     if (!cur || !prev || !prev_labels || !out) return manet_set_error(MANET_E_INVALID, "null pointer");
@@ -912,8 +935,8 @@ int manet_local_match_f32(const float *prev, int64_t p_sy, int64_t p_sx, int64_t
         return manet_set_error(MANET_E_WORKSPACE, "local workspace %zu < %zu bytes", workspace_bytes, L.total);
     hipStream_t st = (hipStream_t)stream;
     if (downsample && !manet_tune_get(MANET_TUNE_LOCAL_UNFUSED, 0)) {  // the live configuration: pooling pass + fused kernel
-        launch_fused(max_distance, st, cur, (long)c_sy, (long)c_sx, (long)c_sc, prev, (long)p_sy, (long)p_sx, (long)p_sc,
-                     prev_labels, h, w, C, n_ids, out, (float *)((char *)workspace + L.off_ap));
+        launch_fused(max_distance, st, cur_v, (long)c_sy, (long)c_sx, (long)c_sc, prev_v, (long)p_sy, (long)p_sx, (long)p_sc,
+                     emb_dtype, prev_labels, h, w, C, n_ids, out, (float *)((char *)workspace + L.off_ap));
         return manet_check_launch("manet_local_match_f32");
     }
     // IntVOS.py:370: local_pairwise_distances2(query_embedding, prev_frame_embedding)

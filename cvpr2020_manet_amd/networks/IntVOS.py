@@ -302,11 +302,28 @@ class IntVOS(nn.Module):
         for m in self.semantic_embedding:
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self._bank_cache = {}  # seq_name -> (identity key, ops.PreparedBank, keyed tensors): see _prepared_bank
         self.dynamic_seghead = DynamicSegHead()  # propagation head
         if cfg.MODEL_USEIntSeg:
             self.inter_seghead = IntSegHead(in_dim=cfg.MODEL_SEMANTIC_EMBEDDING_DIM + 3)
         else:
             self.inter_seghead = DynamicSegHead(in_dim=cfg.MODEL_SEMANTIC_EMBEDDING_DIM + 2)  # interaction head
+
+    def _prepared_bank(self, seq_name, ref_emb_chw, ref_label, ref_emb_hwc, ref_lab_flat, n_ids):
+        """The sorted / packed memory bank of the annotated frame, reused while the caller keeps passing the SAME
+        embedding and scribble tensors (identity = storage pointer, shape, strides and torch's in-place version
+        counter): test.py:237-259 / :276-295 propagate a whole clip against one annotated frame, so the bank is
+        sorted and packed once per interaction instead of once per frame.  One bank per sequence name."""
+        key = (ref_emb_chw.data_ptr(), tuple(ref_emb_chw.shape), tuple(ref_emb_chw.stride()), ref_emb_chw._version,
+               ref_emb_chw.dtype, ref_label.data_ptr(), tuple(ref_label.shape), ref_label._version, ref_label.dtype,
+               n_ids, COMPUTE, bool(self.cfg.TEST_MODE))
+        hit = self._bank_cache.get(seq_name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        bank = ops.PreparedBank(ref_emb_hwc, ref_lab_flat, n_ids, compute=COMPUTE)
+        # keep the keyed tensors alive so that their storage pointers cannot be recycled under the key
+        self._bank_cache[seq_name] = (key, bank, ref_emb_chw, ref_label)
+        return bank
 
     # reference IntVOS.py:556-575
     def forward(self, x=None, ref_scribble_label=None, previous_frame_mask=None,
@@ -373,10 +390,21 @@ class IntVOS(nn.Module):
             if k_nearest_neighbors > 1 and cfg.TEST_MODE:
                 keep = ref_lab != -1
                 ref_emb, ref_lab = ref_emb.reshape(-1, c)[keep], ref_lab[keep]
-            nn_features_n = ops.global_match(ref_emb, seq_current_frame_embedding, ref_lab, n_ids,
-                                             k_nearest_neighbors=k_nearest_neighbors, compute=COMPUTE,
-                                             normalize=bool(normalize_nearest_neighbor_distances),
-                                             mem=mem).view(1, h, w, n_ids, 1)
+            bank = None
+            if (k_nearest_neighbors == 1 and current_frame_embedding.is_cuda
+                    and not (torch.is_grad_enabled() and (ref_frame_embedding.requires_grad
+                                                          or current_frame_embedding.requires_grad))):
+                bank = self._prepared_bank(seq_names[n], ref_frame_embedding[n], ref_scribble_label[n], ref_emb,
+                                           ref_lab, n_ids)
+            if bank is not None:  # the propagation loop matches every frame against ONE annotated frame (test.py:237-259)
+                nn_features_n = bank.match(seq_current_frame_embedding,
+                                           normalize=bool(normalize_nearest_neighbor_distances),
+                                           mem=mem).view(1, h, w, n_ids, 1)
+            else:
+                nn_features_n = ops.global_match(ref_emb, seq_current_frame_embedding, ref_lab, n_ids,
+                                                 k_nearest_neighbors=k_nearest_neighbors, compute=COMPUTE,
+                                                 normalize=bool(normalize_nearest_neighbor_distances),
+                                                 mem=mem).view(1, h, w, n_ids, 1)
 
             # ---- local map
             seq_previous_frame_label = scale_previous_frame_label[n].permute(1, 2, 0)

@@ -56,6 +56,7 @@ def _global_match_autograd(reference_embeddings, query_embeddings, reference_lab
     lab = _labels(reference_labels, "reference_labels")
     if lab.numel() != M0:
         raise ValueError("reference_labels has %d entries for %d reference pixels" % (lab.numel(), M0))
+    ref, qry = ref.float(), qry.float()  # (a differentiable widening if the embeddings are stored in bf16)
     out, _ = GlobalMatchFn.apply(ref, qry, lab, n_ids)
     if normalize:
         out = (torch.sigmoid(out) - 0.5) * 2
@@ -81,12 +82,21 @@ def _workspace(device, tag, nbytes):
     return ws
 
 
+def _emb(t):
+    """embeddings are consumed in the producer's storage: float32, or bfloat16 (2-byte reads end to end,
+    SURVEY.md 8f rank 4); anything else is widened to float32"""
+    return t if t.dtype in (torch.float32, torch.bfloat16) else t.float()
+
+
+def _emb_code(t):
+    return _lib.EMB_BF16 if t.dtype == torch.bfloat16 else _lib.EMB_F32
+
+
 def _flat(t, name):
     """[..., C] -> ([rows, C] view, rows, C); like the reference's .view(-1, C) (IntVOS.py:203-204)
     but a non-viewable input is copied instead of raising."""
     _need_gpu(t, name)
-    if t.dtype != torch.float32:
-        t = t.float()
+    t = _emb(t)
     t2 = t.reshape(-1, t.shape[-1])
     return t2, t2.shape[0], t2.shape[1]
 
@@ -132,12 +142,12 @@ def global_match(reference_embeddings, query_embeddings, reference_labels, n_ids
         mem_ptr = mem.data_ptr()
     flags = _lib.EPI_NORMALIZE if normalize else 0
     with torch.cuda.device(dev):
-        rc = lib.manet_global_match(qry.data_ptr(), qry.stride(0), qry.stride(1), ref.data_ptr(),
-                                    ref.stride(0) if M0 > 0 else C, ref.stride(1) if M0 > 0 else 1,
-                                    lab.data_ptr(), N, M0, C, n_ids, k_nearest_neighbors, cmp_,
-                                    out.data_ptr(), mem_ptr, flags, ws.data_ptr(), ws.numel(),
-                                    _stream_ptr(dev))
-    _lib.check(rc, "manet_global_match")
+        rc = lib.manet_global_match_ex(qry.data_ptr(), _emb_code(qry), qry.stride(0), qry.stride(1), ref.data_ptr(),
+                                       _emb_code(ref), ref.stride(0) if M0 > 0 else C, ref.stride(1) if M0 > 0 else 1,
+                                       lab.data_ptr(), N, M0, C, n_ids, k_nearest_neighbors, cmp_,
+                                       out.data_ptr(), mem_ptr, flags, ws.data_ptr(), ws.numel(),
+                                       _stream_ptr(dev))
+    _lib.check(rc, "manet_global_match_ex")
     return out
 
 
@@ -160,22 +170,33 @@ class PreparedBank:
                    "manet_bank_workspace_bytes")
         self.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            rc = lib.manet_bank_prepare(ref.data_ptr(), ref.stride(0) if M0 > 0 else C,
-                                        ref.stride(1) if M0 > 0 else 1, lab.data_ptr(), M0, C, n_ids,
-                                        self.compute, self.ws.data_ptr(), self.ws.numel(),
-                                        _stream_ptr(self.device))
-        _lib.check(rc, "manet_bank_prepare")
+            rc = lib.manet_bank_prepare_ex(ref.data_ptr(), _emb_code(ref), ref.stride(0) if M0 > 0 else C,
+                                           ref.stride(1) if M0 > 0 else 1, lab.data_ptr(), M0, C, n_ids,
+                                           self.compute, self.ws.data_ptr(), self.ws.numel(),
+                                           _stream_ptr(self.device))
+        _lib.check(rc, "manet_bank_prepare_ex")
 
     def match(self, query_embeddings, k_nearest_neighbors=1, normalize=False, mem=None, out=None):
+        """query_embeddings: [..., C] float32 / bfloat16 tensor, or a PackedQuery (operand image made once,
+        e.g. for every frame of a clip right after extract_feature: no per-frame pack pass)"""
         import ctypes
-        _refuse_autograd("PreparedBank.match", query_embeddings, mem)
         lib = _lib.load()
-        qry, N, C = _flat(query_embeddings, "query_embeddings")
+        if isinstance(query_embeddings, PackedQuery):
+            pq = query_embeddings
+            if pq.C != self.C or pq.compute != self.compute:
+                raise ValueError("PackedQuery was packed for C=%d compute=%d, bank has C=%d compute=%d"
+                                 % (pq.C, pq.compute, self.C, self.compute))
+            _refuse_autograd("PreparedBank.match", mem)
+            qry, N, C, q_code, q_s0, q_s1 = pq.image, pq.N, pq.C, _lib.EMB_PACKED, 0, 0
+        else:
+            _refuse_autograd("PreparedBank.match", query_embeddings, mem)
+            qry, N, C = _flat(query_embeddings, "query_embeddings")
+            q_code, q_s0, q_s1 = _emb_code(qry), qry.stride(0), qry.stride(1)
         if C != self.C:
             raise ValueError("embedding_dim mismatch: %d vs %d" % (C, self.C))
         if k_nearest_neighbors > 1 and self.M0 < k_nearest_neighbors:
             raise RuntimeError("selected index k out of range")
-        dev = qry.device
+        dev = qry.device if isinstance(qry, torch.Tensor) else self.device
         nbytes = ctypes.c_size_t(0)
         _lib.check(lib.manet_match_workspace_bytes(N, self.M0, C, self.n_ids, k_nearest_neighbors,
                                                    self.compute, ctypes.byref(nbytes)),
@@ -191,12 +212,33 @@ class PreparedBank:
             mem_ptr = mem.data_ptr()
         flags = _lib.EPI_NORMALIZE if normalize else 0
         with torch.cuda.device(dev):
-            rc = lib.manet_global_match_prepared(qry.data_ptr(), qry.stride(0), qry.stride(1),
-                                                 self.ws.data_ptr(), N, self.M0, C, self.n_ids,
-                                                 k_nearest_neighbors, self.compute, out.data_ptr(), mem_ptr,
-                                                 flags, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
-        _lib.check(rc, "manet_global_match_prepared")
+            rc = lib.manet_global_match_prepared_ex(qry.data_ptr(), q_code, q_s0, q_s1,
+                                                    self.ws.data_ptr(), N, self.M0, C, self.n_ids,
+                                                    k_nearest_neighbors, self.compute, out.data_ptr(), mem_ptr,
+                                                    flags, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "manet_global_match_prepared_ex")
         return out
+
+
+class PackedQuery:
+    """The query operand image of ONE frame (manet_query_pack): made once per frame of a clip -- the reference
+    computes all embeddings of a clip up front (test.py:143-154) -- and matched against any number of banks /
+    interaction rounds without a per-frame pack pass."""
+
+    def __init__(self, query_embeddings, compute="f32"):
+        import ctypes
+        _refuse_autograd("PackedQuery", query_embeddings)
+        lib = _lib.load()
+        qry, N, C = _flat(query_embeddings, "query_embeddings")
+        self.N, self.C, self.compute = N, C, COMPUTE[compute]
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(lib.manet_query_pack_bytes(N, C, self.compute, ctypes.byref(nbytes)), "manet_query_pack_bytes")
+        self.image = torch.empty(nbytes.value, dtype=torch.uint8, device=qry.device)
+        with torch.cuda.device(qry.device):
+            rc = lib.manet_query_pack(qry.data_ptr(), _emb_code(qry), qry.stride(0), qry.stride(1), N, C, self.compute,
+                                      self.image.data_ptr(), self.image.numel(), _stream_ptr(qry.device))
+        _lib.check(rc, "manet_query_pack")
+        self.device = qry.device
 
 
 def normalize_merge_(x, mem=None, normalize=True):
@@ -220,10 +262,12 @@ def normalize_merge_(x, mem=None, normalize=True):
     return x
 
 
-def _hwc(t, name):
+def _hwc(t, name, allow_bf16=False):
     _need_gpu(t, name)
     if t.dim() != 3:
         raise ValueError("%s must be [height, width, embedding_dim]" % name)
+    if allow_bf16 and t.dtype == torch.bfloat16:
+        return t
     return t if t.dtype == torch.float32 else t.float()
 
 
@@ -271,8 +315,10 @@ def local_match(prev_frame_embedding, query_embedding, prev_frame_labels, n_ids,
         if lab.numel() != cur.shape[0] * cur.shape[1]:
             raise ValueError("prev_frame_labels must have height*width entries")
         return LocalMatchFn.apply(prev, cur, lab, n_ids, max_distance)
-    prev = _hwc(prev_frame_embedding, "prev_frame_embedding")
-    cur = _hwc(query_embedding, "query_embedding")
+    both_bf16 = (prev_frame_embedding.dtype == torch.bfloat16 and query_embedding.dtype == torch.bfloat16
+                 and downsample)  # 2-byte embeddings are read as they are by the pooling pass
+    prev = _hwc(prev_frame_embedding, "prev_frame_embedding", both_bf16)
+    cur = _hwc(query_embedding, "query_embedding", both_bf16)
     h, w, C = cur.shape
     if tuple(prev.shape) != (h, w, C):
         raise ValueError("prev_frame_embedding and query_embedding must have the same shape")
@@ -286,11 +332,11 @@ def local_match(prev_frame_embedding, query_embedding, prev_frame_labels, n_ids,
     ws = _workspace(dev, "local", nbytes.value)
     out = torch.empty((h, w, n_ids), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        rc = lib.manet_local_match_f32(prev.data_ptr(), prev.stride(0), prev.stride(1), prev.stride(2),
-                                       cur.data_ptr(), cur.stride(0), cur.stride(1), cur.stride(2),
-                                       lab.data_ptr(), h, w, C, n_ids, max_distance, int(bool(downsample)),
-                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
-    _lib.check(rc, "manet_local_match_f32")
+        rc = lib.manet_local_match_ex(prev.data_ptr(), prev.stride(0), prev.stride(1), prev.stride(2),
+                                      cur.data_ptr(), cur.stride(0), cur.stride(1), cur.stride(2), _emb_code(cur),
+                                      lab.data_ptr(), h, w, C, n_ids, max_distance, int(bool(downsample)),
+                                      out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "manet_local_match_ex")
     return out
 
 

@@ -54,6 +54,11 @@ typedef void *manet_stream_t; /* a hipStream_t */
 #define MANET_COMPUTE_BF16 1    /* v_mfma_f32_32x32x16_bf16 on inputs rounded to bf16, fp32 accumulate */
 #define MANET_COMPUTE_BF16X3 2  /* split-bf16 (hi+lo, 3 MFMAs): fp32-class accuracy at bf16 rate */
 
+/* storage type of an embedding operand of the *_ex entry points (take the producer's layout) */
+#define MANET_EMB_F32 0    /* float */
+#define MANET_EMB_BF16 1   /* bfloat16 as raw 16-bit words (what a bf16 encoder epilogue stores) */
+#define MANET_EMB_PACKED 2 /* query only: the MFMA operand image written by manet_query_pack */
+
 /* flags of the fused epilogue of manet_global_match */
 #define MANET_EPI_NORMALIZE 1 /* g = (sigmoid(g) - 0.5) * 2            IntVOS.py:611-612 */
 
@@ -107,6 +112,30 @@ int manet_global_match_prepared(const float *query, int64_t q_stride_n, int64_t 
                                 int epilogue_flags, void *match_ws, size_t match_ws_bytes,
                                 manet_stream_t stream);
 
+/* The same three entry points for embeddings in the PRODUCER's storage (the embeddings of a
+ * whole clip are computed once, test.py:143-154, and live in HBM as [F,C,h,w]): `*_dtype` = MANET_EMB_*.
+ * With bf16 storage the path reads 2-byte embeddings end to end (for MANET_COMPUTE_BF16 the values are used as
+ * they are; MANET_COMPUTE_F32 widens them exactly).
+ * manet_query_pack writes a frame's query operand image once (e.g. right behind the encoder, for every frame
+ * of the clip); manet_global_match_prepared_ex(query = that image, MANET_EMB_PACKED, ...) then skips the
+ * per-frame pack pass entirely.  The image depends on (N, C, compute) only. */
+int manet_bank_prepare_ex(const void *bank, int emb_dtype, int64_t b_stride_m, int64_t b_stride_c,
+                          const int32_t *labels, int64_t M0, int C, int n_ids, int compute,
+                          void *bank_ws, size_t bank_ws_bytes, manet_stream_t stream);
+int manet_query_pack_bytes(int64_t N, int C, int compute, size_t *bytes);
+int manet_query_pack(const void *query, int emb_dtype, int64_t q_stride_n, int64_t q_stride_c, int64_t N,
+                     int C, int compute, void *packed, size_t packed_bytes, manet_stream_t stream);
+int manet_global_match_prepared_ex(const void *query, int emb_dtype, int64_t q_stride_n,
+                                   int64_t q_stride_c, const void *bank_ws, int64_t N, int64_t M0, int C,
+                                   int n_ids, int k_nn, int compute, float *out, float *mem_inout,
+                                   int epilogue_flags, void *match_ws, size_t match_ws_bytes,
+                                   manet_stream_t stream);
+int manet_global_match_ex(const void *query, int q_dtype, int64_t q_stride_n, int64_t q_stride_c,
+                          const void *bank, int b_dtype, int64_t b_stride_m, int64_t b_stride_c,
+                          const int32_t *labels, int64_t N, int64_t M0, int C, int n_ids, int k_nn,
+                          int compute, float *out, float *mem_inout, int epilogue_flags, void *workspace,
+                          size_t workspace_bytes, manet_stream_t stream);
+
 /* Stand-alone normalise / min-merge (IntVOS.py:611-622, :718-723), in place on x[n]
  * (and on mem_inout[n] when not NULL). */
 int manet_normalize_merge_f32(float *x, float *mem_inout, int64_t n, int normalize,
@@ -142,6 +171,15 @@ int manet_local_match_f32(const float *prev, int64_t p_sy, int64_t p_sx, int64_t
                           const int32_t *prev_labels, int h, int w, int C, int n_ids,
                           int max_distance, int downsample, float *out, void *workspace,
                           size_t workspace_bytes, manet_stream_t stream);
+
+/* manet_local_match_f32 for embeddings in the producer's storage (MANET_EMB_F32 / MANET_EMB_BF16; bf16 only in the
+ * downsample configuration): the pooling pass reads the 2-byte embeddings, everything after it is fp32 --
+ * i.e. exactly manet_local_match_f32 on the bf16-rounded embeddings. */
+int manet_local_match_ex(const void *prev, int64_t p_sy, int64_t p_sx, int64_t p_sc, const void *cur,
+                         int64_t c_sy, int64_t c_sx, int64_t c_sc, int emb_dtype,
+                         const int32_t *prev_labels, int h, int w, int C, int n_ids, int max_distance,
+                         int downsample, float *out, void *workspace, size_t workspace_bytes,
+                         manet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* correlation_package forward (correlation_cuda.cc:10-87).
