@@ -9,13 +9,19 @@ T-frame memory bank with the fused normalise + min-aggregation (IntVOS.py:609-62
 (2d+1)^2 window match against the previous frame (IntVOS.py:629-631), embeddings already resident
 in HBM (they come out of the encoder on the GPU; test.py:149-154).  Workload = BASELINE.json
 configs[1]: 480p grid 120x214, C=100, 5-frame fully labelled bank (M = 128 400, the worst case
-after rough_ROI), 1 object (+ background = 2 ids), fp32.  The one-shot API is timed, i.e. the bank
-is re-sorted/re-packed every frame exactly as the reference recomputes everything every frame.
+after rough_ROI), 1 object (+ background = 2 ids), fp32.
 
-Multi-GPU: frames of the clip are sharded, K per rank (weak scaling); the timed region contains the
-single RCCL all-gather that distributes the memory bank + halo frame, then K frames per rank.
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and
-`cpu_baseline` objects.
+Timed region (exactly K steps + the clip's one-off work): the bank exchange (N > 1), ONE sort/pack
+of the memory bank (it is the same for every frame of the propagation loop, test.py:237-259 -- what
+the drop-in module does through its PreparedBank cache), then K frames, each = query pack + global
+match + fused epilogue + local match.  `--one-shot` re-sorts / re-packs the bank every frame instead
+(r1's definition; the reference recomputes everything per frame).  `--prepacked` also takes the query
+operand images as given (packed when the embeddings were produced).
+
+Multi-GPU: `python bench.py --gpus N` starts its own N ranks (one process per GPU, RCCL); frames of
+the clip are sharded, K per rank (weak scaling); the timed region contains the single RCCL
+all-gather that distributes the memory bank + halo frame.  Prints ONE JSON line on rank 0 (contract
+in the task description) with `roofline` and `cpu_baseline` objects.
 """
 import argparse
 import ctypes
@@ -42,9 +48,10 @@ LOCAL_D = 12
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
-def synth_frame(gen, device):
-    """C-major embedding as extract_feature produces it (post-ReLU): relu(randn) * 0.1."""
-    return (torch.relu(torch.randn(C, H, W, generator=gen, device=device)) * 0.1).contiguous()
+def synth_frame(gen, device, dtype=torch.float32):
+    """C-major embedding as extract_feature produces it (post-ReLU): relu(randn) * 0.1,
+    stored in `dtype` (bf16 configs keep 2-byte embeddings in HBM)."""
+    return (torch.relu(torch.randn(C, H, W, generator=gen, device=device)) * 0.1).to(dtype).contiguous()
 
 
 def blob_labels(n_ids, shift, device):
@@ -57,14 +64,16 @@ def blob_labels(n_ids, shift, device):
     return lab
 
 
-def cpu_baseline(bank_rows, bank_lab, cur, prev, prev_lab, gpu_global=None, gpu_local=None):
-    """The CPU oracle (a C port of the reference path, kind="port") on the host cores, on a bounded
-    sample of the same frame: a subset of query pixels against the FULL bank for the global match
-    (cost is linear in query pixels), the whole frame for the local match.  ~10-30 s.
+def cpu_baseline(bank_rows, bank_lab, cur, prev, prev_lab, gpu_global=None, gpu_local=None, quant_bf16=False):
+    """The CPU oracle (a C port of the reference path, kind="port": OpenMP over query blocks, the distance loop
+    vectorised across bank rows with AVX-512/AVX2 FMA -- same fmaf chains, bit-identical to the scalar form) on
+    the host cores, on a bounded sample of the same frame: a subset of query pixels against the FULL bank for the
+    global match (cost is linear in query pixels), the whole frame for the local match.  ~10-30 s.
     The oracle's outputs double as the parity check of the metric ("mask max-abs-err vs ref"): when the
     GPU results of the same frame are passed in, their max abs deviation is returned as well."""
     from oracle import oracle as orc
     cores = os.cpu_count() or 1
+    cur, prev, bank_rows = cur.float(), prev.float(), bank_rows.float()  # (bf16-stored embeddings widen exactly)
     qry = cur.permute(1, 2, 0).cpu().numpy()
     ref = bank_rows.cpu().numpy()
     lab = bank_lab.cpu().numpy().reshape(-1, 1, 1)
@@ -76,24 +85,33 @@ def cpu_baseline(bank_rows, bank_lab, cur, prev, prev_lab, gpu_global=None, gpu_
     def run(nq):
         q = np.ascontiguousarray(qry.reshape(-1, C)[:nq]).reshape(nq, 1, C)
         t0 = time.perf_counter()
-        last["raw"] = orc.global_match(ref3, q, lab, 1, n_ids=N_IDS, test_mode=True)
+        last["raw"] = orc.global_match(ref3, q, lab, 1, n_ids=N_IDS, test_mode=True, quant_bf16=quant_bf16)
         return time.perf_counter() - t0
 
-    probe_n = 4 * cores
-    t_probe = run(probe_n)
-    per_q = t_probe / probe_n
+    probe_n = 8 * cores
+    t_probe = run(min(probe_n, N))
+    per_q = t_probe / min(probe_n, N)
     nq = int(min(N, max(probe_n, 12.0 / per_q)))
-    nq -= nq % cores or 0
-    nq = max(nq, cores)
-    t_glob = run(nq)
+    nq -= nq % (8 * cores) or 0
+    nq = min(N, max(nq, 8 * cores))
+    # ~10-15 s of CPU work: the sample is a whole frame's worth of query pixels (or what fits) repeated
+    reps = int(max(1, min(30, round(10.0 / max(per_q * nq, 1e-3)))))
+    t_glob = sum(run(nq) for _ in range(reps)) / reps
     t0 = time.perf_counter()
-    loc = orc.local_match(prev.permute(1, 2, 0).cpu().numpy(), qry, prev_lab.cpu().numpy(), N_IDS, LOCAL_D)
-    t_loc = time.perf_counter() - t0
+    lreps = 0
+    while True:
+        loc = orc.local_match(prev.permute(1, 2, 0).cpu().numpy(), qry, prev_lab.cpu().numpy(), N_IDS, LOCAL_D)
+        lreps += 1
+        if time.perf_counter() - t0 > 3.0 or lreps >= 10:
+            break
+    t_loc = (time.perf_counter() - t0) / lreps
     frame_s = t_glob / nq * N + t_loc
     res = {"value": 1.0 / frame_s, "unit": "frames/s", "cores": cores, "kind": "port",
-           "sample": "global match: %d of %d query pixels x full %d-row bank (%.1f s, scaled linearly); "
-                     "local match d=%d: whole frame (%.1f s); oracle/manet_oracle.c with OpenMP on %d threads"
-                     % (nq, N, ref.shape[0], t_glob, LOCAL_D, t_loc, cores)}
+           "sample": "global match: %d of %d query pixels x full %d-row bank, %d repetition(s), %.2f s each (scaled "
+                     "linearly to the frame); local match d=%d: whole frame, %d repetition(s), %.2f s each; "
+                     "oracle/manet_oracle.c, OpenMP on %d threads, distance loop vectorised across bank rows "
+                     "(AVX-512/AVX2 FMA, bit-identical to the scalar chains)"
+                     % (nq, N, ref.shape[0], reps, t_glob, LOCAL_D, lreps, t_loc, cores)}
     parity = None
     if gpu_global is not None:
         want, _ = orc.normalize_merge(last["raw"].reshape(-1, N_IDS), None, normalize=True)
@@ -132,7 +150,15 @@ def main():
     ap.add_argument("--cfg", type=int, default=2, choices=[2, 3, 5],
                     help="BASELINE config: 2 = 480p T=5 2 ids d=12 (headline); 3 = 480p T=5 4 ids d=4; "
                          "5 = 720p T=10 6 ids d=4")
+    ap.add_argument("--emb", type=str, default="auto", choices=["auto", "f32", "bf16"],
+                    help="storage of the embeddings in HBM (auto: bf16 for --compute bf16, else f32)")
+    ap.add_argument("--one-shot", action="store_true", help="re-sort / re-pack the bank every frame (r1's step)")
+    ap.add_argument("--prepacked", action="store_true",
+                    help="query operand images packed when the embeddings were produced (outside the timed region)")
     args = ap.parse_args()
+    if args.emb == "auto":
+        args.emb = "bf16" if args.compute == "bf16" else "f32"
+    emb_dtype = torch.bfloat16 if args.emb == "bf16" else torch.float32
 
     # MANET_BENCH_BACKEND=gloo: dry run of the N>1 flow on fewer GPUs than ranks (ranks share devices)
     backend = os.environ.get("MANET_BENCH_BACKEND", "nccl")
@@ -188,7 +214,7 @@ def main():
     # this rank's K frames of the clip (synthetic embeddings, resident in HBM) + 1 warm-up halo
     # (the clip is at least long enough to contain T_BANK distinct annotated frames; only K are timed)
     n_local = max(K, -(-T_BANK // world))
-    frames = [synth_frame(gen, device) for _ in range(min(n_local, 8))]  # cycled: 8 x 10.3 MB
+    frames = [synth_frame(gen, device, emb_dtype) for _ in range(min(n_local, 8))]  # cycled: 8 x 10.3 MB (fp32)
     local_emb = torch.stack(frames)  # [f, C, H, W]
     F_total = world * n_local
     my_start, _ = clip_parallel.shard_frames(F_total, world, rank)
@@ -235,12 +261,23 @@ def main():
 
     gmap = torch.ones(104, H * W, N_IDS, device=device)  # IntVOS.py:617
     prev_labs = [blob_labels(N_IDS, s, device) for s in range(8)]
+    packed = None
+    if args.prepacked:  # the producer's job: one operand image per resident frame
+        packed = [ops.PackedQuery(f.permute(1, 2, 0), compute=args.compute) for f in frames]
 
-    def step(i, bank_rows, bank_lab, halo):
+    def prepare(bank_rows, bank_lab):
+        """the clip's one-off: sort + pack the memory bank (None in --one-shot mode)"""
+        return None if args.one_shot else ops.PreparedBank(bank_rows, bank_lab, N_IDS, compute=args.compute)
+
+    def step(i, bank, bank_rows, bank_lab, halo):
         cur = frame_emb(i)
         prev = frame_emb(i - 1) if i > 0 else (halo if halo is not None else frame_emb(0))
-        g = ops.global_match(bank_rows, cur.permute(1, 2, 0), bank_lab, N_IDS, normalize=True,
-                             mem=gmap[i % 104], compute=args.compute)
+        if bank is None:
+            g = ops.global_match(bank_rows, cur.permute(1, 2, 0), bank_lab, N_IDS, normalize=True,
+                                 mem=gmap[i % 104], compute=args.compute)
+        else:
+            qsrc = packed[i % len(packed)] if packed is not None else cur.permute(1, 2, 0)
+            g = bank.match(qsrc, normalize=True, mem=gmap[i % 104])
         l = ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), prev_labs[i % 8], N_IDS, LOCAL_D)
         return g, l
 
@@ -252,17 +289,19 @@ def main():
 
     # warm-up (untimed)
     bank_rows, bank_lab, halo = build_bank()
+    bank = prepare(bank_rows, bank_lab)
     for i in range(Wm):
-        step(i, bank_rows, bank_lab, halo)
+        step(i, bank, bank_rows, bank_lab, halo)
     barrier()
 
-    # timed: the bank exchange + exactly K frames
+    # timed: the bank exchange + the bank's one-off sort/pack + exactly K frames
     _lib.check(lib.manet_profile_begin(K), "manet_profile_begin")
     barrier()
     t0 = time.perf_counter()
     bank_rows, bank_lab, halo = build_bank()
+    bank = prepare(bank_rows, bank_lab)
     for i in range(K):
-        step(i, bank_rows, bank_lab, halo)
+        step(i, bank, bank_rows, bank_lab, halo)
     barrier()
     elapsed = time.perf_counter() - t0
     ms = (ctypes.c_float * K)()
@@ -280,11 +319,14 @@ def main():
         assert M == T_BANK * H * W, "bank must hold T_BANK distinct frames"
         flops = 2.0 * N * M * C  # algorithmic flops of one launch
         achieved = flops / (kern_ms * 1e-3) / 1e12
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic_global_match_f32.json")
+        # HBM/fabric bytes of the dominant kernel come from the tracked rocprofv3 --pmc capture of THIS command line
+        # (PMC counters cannot be read from inside the run); the file records where and when it was measured
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "traffic_cfg%d_%s.json" % (args.cfg, args.compute))
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tp))
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), {k: tj.get(k) for k in ("source", "captured_at", "kernel")}
             except Exception:
                 traffic = None
         line = {
@@ -301,15 +343,19 @@ def main():
             "dtype": args.compute,
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: grid %dx%d, C=%d, %d-frame fully-labelled bank "
-                                   "(M=%d), %d ids, %s; step = global match + fused normalise/min-merge + "
-                                   "local match d=%d; one-shot API (bank re-packed every frame)"
-                                   % (args.cfg - 1, H, W, C, T_BANK, M, N_IDS, args.compute, LOCAL_D),
+                                   "(M=%d), %d ids, %s arithmetic, %s-stored embeddings; step = query pack%s + global "
+                                   "match + fused normalise/min-merge + local match d=%d; bank %s"
+                                   % (args.cfg - 1, H, W, C, T_BANK, M, N_IDS, args.compute, args.emb,
+                                      " (done by the producer, untimed)" if args.prepacked else "", LOCAL_D,
+                                      "re-sorted/re-packed every frame (one-shot API)" if args.one_shot else
+                                      "sorted/packed once per clip inside the timed region"),
                        "frames_per_gpu": K, "bank_exchange": "1 RCCL all-gather in the timed region" if world > 1
                        else "none (1 GPU)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic if (args.compute == "f32" and args.cfg == 2) else None,
-                         "kernel": "global_match_f32_kernel<50,1>" if args.compute == "f32" else
-                                   "global_match_bf16_kernel<7,%s>" % ("true" if args.compute == "bf16x3" else "false"),
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": {"f32": "global_match_f32_kernel<50, 1, false>",
+                                    "bf16": "global_match_bf16_wide_kernel<7, 0>",
+                                    "bf16x3": "global_match_bf16_kernel<7, true, 1, true>"}[args.compute],
                          "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": flops},
         }
@@ -319,8 +365,10 @@ def main():
                                      compute=args.compute)
             l_chk = ops.local_match(frame_emb(1).permute(1, 2, 0), frame_emb(0).permute(1, 2, 0), prev_labs[0], N_IDS,
                                     LOCAL_D)
+            # bf16 arithmetic is checked against the oracle on the bf16-rounded embeddings (its quant_bf16 mode)
             line["cpu_baseline"], line["parity"] = cpu_baseline(bank_rows, bank_lab, frame_emb(0), frame_emb(1),
-                                                                prev_labs[0], g_chk, l_chk)
+                                                                prev_labs[0], g_chk, l_chk,
+                                                                quant_bf16=(args.compute == "bf16"))
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None  # measured on rank 0 at N=1 only (see the N=1 line)
     if use_dist:

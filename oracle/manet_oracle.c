@@ -86,6 +86,97 @@ static inline float normalize_dist(float x)
  * quant_bf16 != 0: inputs are rounded to bf16 first (oracle for the bf16 HIP path).
  * returns 0, or -1 when the top-k path has fewer than k_nn bank rows (torch.topk raises).
  */
+/* k = 1 fast path of the CPU baseline (the scalar loop ran one dependent fmaf chain per
+ * (n, m) pair, ~50 GFLOP/s on 256 threads).  Same arithmetic, vectorised ACROSS bank rows: the bank is held
+ * channel-major kT[c][m], a block of QBLK queries x 16 bank rows keeps QBLK x 16 running dot products in vector
+ * registers, every pair still accumulates q[c]*k[c] with fmaf in ascending c -- bit-identical results, the bank
+ * block is reused by QBLK queries from L1.  target_clones: one binary, AVX-512 / AVX2 / baseline picked at
+ * load time (the library is built in the build container and runs on the GPU box's host). */
+#define QBLK 8
+#define MBLK 16
+#define K1_MAX_IDS 64
+__attribute__((target_clones("avx512f", "avx2", "default")))
+static void k1_block(const float *qv /* [QBLK][C] */, const float *xs /* [QBLK] */, int nq, const float *kT, long Mpad,
+                     const float *ys /* [Mpad], +inf beyond M */, const int32_t *lab /* [Mpad], -1 beyond M */, int C,
+                     int n_ids, float *bestv /* [QBLK][n_ids][MBLK] lane-wise running minima */)
+{
+    for (long m0 = 0; m0 < Mpad; m0 += MBLK) {
+        float mm[QBLK][MBLK];
+        for (int qi = 0; qi < QBLK; ++qi)
+#pragma omp simd
+            for (int j = 0; j < MBLK; ++j) mm[qi][j] = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float *kv = kT + (long)c * Mpad + m0;
+            for (int qi = 0; qi < QBLK; ++qi) {
+                const float qc = qv[qi * C + c];
+#pragma omp simd
+                for (int j = 0; j < MBLK; ++j) mm[qi][j] = fmaf(qc, kv[j], mm[qi][j]);
+            }
+        }
+        for (int qi = 0; qi < nq; ++qi) {
+            float d[MBLK];
+#pragma omp simd
+            for (int j = 0; j < MBLK; ++j) d[j] = fmaf(-2.0f, mm[qi][j], xs[qi] + ys[m0 + j]); /* IntVOS.py:39 */
+            for (int o = 0; o < n_ids; ++o) {
+                float *b = bestv + ((long)qi * n_ids + o) * MBLK;
+#pragma omp simd
+                for (int j = 0; j < MBLK; ++j) {
+                    /* IntVOS.py:81-85: dists + wrong_label_mask * 1e20, min */
+                    const float dd = d[j] + ((lab[m0 + j] != o) ? 1.0f : 0.0f) * WRONG_LABEL_PADDING_DISTANCE;
+                    b[j] = (dd < b[j]) ? dd : b[j];
+                }
+            }
+        }
+    }
+}
+
+static void global_match_k1_fast(const float *q, long qs_n, long qs_c, const float *kb, const float *ys_in,
+                                 const long *rows, const int32_t *labels, long N, long M, int C, int n_ids,
+                                 int quant_bf16, float *out)
+{
+    const long Mpad = (M + MBLK - 1) / MBLK * MBLK;
+    float *kT = (float *)calloc((size_t)(Mpad > 0 ? Mpad : 1) * (size_t)C, sizeof(float));
+    float *ys = (float *)malloc(sizeof(float) * (size_t)(Mpad > 0 ? Mpad : 1));
+    int32_t *lab = (int32_t *)malloc(sizeof(int32_t) * (size_t)(Mpad > 0 ? Mpad : 1));
+    for (long m = 0; m < Mpad; ++m) {
+        ys[m] = (m < M) ? ys_in[m] : INFINITY; /* padding rows: d = +inf, never the minimum */
+        lab[m] = (m < M) ? labels[rows[m]] : -1;
+    }
+    for (long m = 0; m < M; ++m)
+        for (int c = 0; c < C; ++c) kT[(long)c * Mpad + m] = kb[m * C + c];
+#pragma omp parallel
+    {
+        float *qv = (float *)calloc((size_t)QBLK * (size_t)C, sizeof(float));
+        float *bestv = (float *)malloc(sizeof(float) * (size_t)QBLK * (size_t)n_ids * MBLK);
+        float xs[QBLK];
+#pragma omp for schedule(dynamic, 4)
+        for (long n0 = 0; n0 < N; n0 += QBLK) {
+            const int nq = (N - n0) < QBLK ? (int)(N - n0) : QBLK;
+            for (int qi = 0; qi < nq; ++qi) {
+                for (int c = 0; c < C; ++c) {
+                    float v = q[(n0 + qi) * qs_n + (long)c * qs_c];
+                    qv[qi * C + c] = quant_bf16 ? bf16_round(v) : v;
+                }
+                xs[qi] = sq_norm_chain(qv + qi * C, 1, C); /* IntVOS.py:32 */
+            }
+            for (long i = 0; i < (long)QBLK * n_ids * MBLK; ++i) bestv[i] = INFINITY;
+            k1_block(qv, xs, nq, kT, Mpad, ys, lab, C, n_ids, bestv);
+            for (int qi = 0; qi < nq; ++qi)
+                for (int o = 0; o < n_ids; ++o) {
+                    const float *b = bestv + ((long)qi * n_ids + o) * MBLK;
+                    float best = INFINITY;
+                    for (int j = 0; j < MBLK; ++j) best = (b[j] < best) ? b[j] : best;
+                    out[(n0 + qi) * n_ids + o] = (M == 0) ? WRONG_LABEL_PADDING_DISTANCE : best;
+                }
+        }
+        free(qv);
+        free(bestv);
+    }
+    free(kT);
+    free(ys);
+    free(lab);
+}
+
 int oracle_global_match_f32(const float *q, long qs_n, long qs_c,
                             const float *bank, long bs_m, long bs_c,
                             const int32_t *labels, long N, long M0, int C,
@@ -109,6 +200,13 @@ int oracle_global_match_f32(const float *q, long qs_n, long qs_c,
             kb[m * C + c] = quant_bf16 ? bf16_round(v) : v;
         }
         ys[m] = sq_norm_chain(kb + m * C, 1, C); /* IntVOS.py:35 */
+    }
+    if (k_nn == 1 && !getenv("MANET_ORACLE_SCALAR")) { /* vectorised across bank rows, bit-identical to the loop below */
+        global_match_k1_fast(q, qs_n, qs_c, kb, ys, rows, labels, N, M, C, n_ids, quant_bf16, out);
+        free(kb);
+        free(ys);
+        free(rows);
+        return 0;
     }
 
 #pragma omp parallel

@@ -30,7 +30,11 @@ def test_bank_slots():
     slots, table = cp.bank_slots([0, 3, 9, 10, 15], 16, 4)  # ranks own 4 frames each
     assert slots == 2
     assert table == [(0, 0, 0), (0, 1, 3), (2, 0, 9), (2, 1, 10), (3, 0, 15)]
-    assert cp.slab_bytes(100, 120, 214, 5, 8) == 4 * (1 * (100 * 120 * 214 + 120 * 214) + 100 * 120 * 214)
+    # slab size follows bank_slots(): spread-out annotations -> 1 slot, clustered ones -> as many as one rank owns
+    spread = [0, 16, 32, 48, 63]
+    assert cp.slab_bytes(100, 120, 214, spread, 64, 8) == 4 * (1 * (100 * 120 * 214 + 120 * 214) + 100 * 120 * 214)
+    assert cp.slab_bytes(100, 120, 214, [0, 1, 2, 3, 4], 64, 8) == 4 * (5 * (100 * 120 * 214 + 120 * 214) + 100 * 120 * 214)
+    assert cp.slab_bytes(100, 120, 214, spread, 64, 8, elem_size=2) == 2 * 100 * 120 * 214 + 4 * 120 * 214 + 2 * 100 * 120 * 214
 
 
 def _free_port():
@@ -48,13 +52,15 @@ def _clip(F, C, h, w):
     return emb, lab
 
 
-def _worker(rank, world, port, F, bank_frames, q):
+def _worker(rank, world, port, F, bank_frames, q, bf16=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         C, h, w = 5, 6, 7
         emb, lab = _clip(F, C, h, w)
+        if bf16:  # the producer's 2-byte storage travels bit for bit through the byte slab
+            emb = emb.bfloat16()
         s, e = cp.shard_frames(F, world, rank)
         local = emb[s:e].clone()
         labels = {f: lab[f] for f in bank_frames if s <= f < e}  # a rank only knows its own frames' labels
@@ -70,12 +76,13 @@ def _worker(rank, world, port, F, bank_frames, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,F,bank", [(2, 8, [0, 2, 5, 6, 7]), (3, 7, [1, 3]), (2, 3, [2])])
-def test_exchange_bank_and_halo_gloo(world, F, bank):
+@pytest.mark.parametrize("world,F,bank,bf16", [(2, 8, [0, 2, 5, 6, 7], False), (3, 7, [1, 3], False), (2, 3, [2], False),
+                                               (2, 8, [0, 2, 5, 6, 7], True)])
+def test_exchange_bank_and_halo_gloo(world, F, bank, bf16):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, F, bank, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, F, bank, q, bf16)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
