@@ -16,7 +16,8 @@ def short(name):
 
 
 def main(paths):
-    print("kernel,counter,avg_per_dispatch,dispatches,avg_duration_us")
+    out = csv.writer(sys.stdout)
+    out.writerow(["kernel", "counter", "avg_per_dispatch", "dispatches", "avg_duration_us"])
     for p in paths:
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         dur = collections.defaultdict(list)
@@ -29,7 +30,7 @@ def main(paths):
         for k in sorted(acc):
             for c in sorted(acc[k]):
                 v = acc[k][c]
-                print("%s,%s,%.4f,%d,%.2f" % (k, c, sum(v) / len(v), len(v), sum(dur[k]) / len(dur[k])))
+                out.writerow([k, c, "%.4f" % (sum(v) / len(v)), len(v), "%.2f" % (sum(dur[k]) / len(dur[k]))])
 
 
 if __name__ == "__main__":
