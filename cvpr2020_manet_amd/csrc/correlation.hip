@@ -9,10 +9,12 @@
 //
 // The reference launches one 32-thread block per output pixel, strides channels over the warp
 // and shuffles the partial sums together, after materialising padded NHWC copies of both inputs.
-// Here a thread owns one output element and walks channels serially: lanes run along ox, so
-// every load is a coalesced row segment of the NCHW planes, there are no copies, no cross-lane
-// traffic and no scratch.  (This op is dead code in the reference's live tree -- SURVEY.md 0 --
-// and is kept for API coverage; it is not on the benchmarked path.)
+// Two kernels: an LDS-tiled one (below; float / double / half) that stages both patches once per channel chunk
+// and reuses them for every displacement, and -- as the fallback for displacement grids / halos the tile cannot
+// hold -- correlation_forward_kernel, where a thread owns one output element and walks channels serially (lanes
+// along ox: every load is a coalesced row segment of the NCHW planes).  No padded copies, no cross-lane traffic.
+// (This op is dead code in the reference's live tree -- SURVEY.md 0 -- and is not on the benchmarked path.)
+#include <hip/hip_fp16.h>
 #include <math.h>
 
 #include "manet_common.h"
@@ -51,6 +53,120 @@ __global__ __launch_bounds__(256) void correlation_forward_kernel(
             for (int c = 0; c < C; ++c) acc = fmaf(pa[c * plane], pb[c * plane], acc);
         }
     out[i] = acc / nelems;
+}
+
+// ---- LDS-tiled forward, float / double / half (the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+// correlation_cuda_kernel.cu:386-415) -------------------------------------------------------------------------
+// Workgroup = 16 consecutive output columns of one output row, all (2r+1)^2 displacements.  Per chunk of channels
+// the first input's K x (15 s1 + K) patch and the second input's halo (K + 2 r s2 rows, 15 s1 + K + 2 r s2 columns),
+// zero outside the image (= the reference's zero-padded copies, correlation_cuda_kernel.cu:46-70), are staged in
+// LDS once and reused by every displacement: global traffic drops from one load pair per multiply-add to one load
+// per staged element.  Thread = (output column, displacement row tj [+16]); it keeps the DMAX displacement columns
+// of its row(s) as running sums.  Arithmetic as the reference's kernel (:121-127): the product is formed in the
+// tensor's type (half: rounded to half; double: then narrowed), accumulated in fp32, the mean written in the
+// tensor's type.  float: fmaf chain -- for kernel_size 1 the same order as the one-thread-per-output kernel above
+// and the oracle (bit-identical); for larger kernels the channel chunks reorder the sum (fp32 rounding).
+__device__ __forceinline__ float corr_prod(float a, float b, float acc) { return fmaf(a, b, acc); }
+__device__ __forceinline__ float corr_prod(double a, double b, float acc) { return acc + (float)(a * b); }
+__device__ __forceinline__ float corr_prod(__half a, __half b, float acc) { return acc + __half2float(__hmul(a, b)); }
+__device__ __forceinline__ void corr_store(float *p, float v) { *p = v; }
+__device__ __forceinline__ void corr_store(double *p, float v) { *p = (double)v; }
+__device__ __forceinline__ void corr_store(__half *p, float v) { *p = __float2half(v); }
+template <typename T> __device__ __forceinline__ T corr_zero();
+template <> __device__ __forceinline__ float corr_zero<float>() { return 0.0f; }
+template <> __device__ __forceinline__ double corr_zero<double>() { return 0.0; }
+template <> __device__ __forceinline__ __half corr_zero<__half>() { return __float2half(0.0f); }
+
+template <typename T, int DMAX>
+__global__ __launch_bounds__(256) void correlation_forward_tiled_kernel(
+    const T *__restrict__ in1, const T *__restrict__ in2, int C, int H, int W, int pad, int kr, int max_disp, int s1,
+    int s2, int r, int oh, int ow, int CC, float nelems, T *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char corr_smem[];
+    constexpr int NP = DMAX > 16 ? 2 : 1;  // displacement rows per thread
+    const int D = 2 * r + 1, K = 2 * kr + 1;
+    const int W1 = 15 * s1 + K, R2 = K + 2 * r * s2, W2 = W1 + 2 * r * s2;
+    T *A = (T *)corr_smem;            // [CC][K][W1]
+    T *Bh = A + (size_t)CC * K * W1;  // [CC][R2][W2]
+    const int tid = threadIdx.x, oxl = tid & 15, slot = tid >> 4;
+    const int ox0 = blockIdx.x * 16, oy = blockIdx.y, n = blockIdx.z;
+    // padded coordinates of the tile's first-input patch origin and of the halo origin
+    const int y1 = oy * s1 + max_disp - kr, x1 = ox0 * s1 + max_disp - kr;
+    const int y2 = y1 - r * s2, x2 = x1 - r * s2;
+    const long plane = (long)H * W;
+    const T *a0 = in1 + (long)n * C * plane, *b0 = in2 + (long)n * C * plane;
+    float acc[NP][DMAX];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int t = 0; t < DMAX; ++t) acc[p][t] = 0.0f;
+    for (int c0 = 0; c0 < C; c0 += CC) {
+        const int cn = (C - c0) < CC ? (C - c0) : CC;
+        __syncthreads();  // the previous chunk is consumed
+        for (int e = tid; e < cn * K * W1; e += 256) {
+            const int c = e / (K * W1), rem = e - c * (K * W1), yy = rem / W1, xx = rem - yy * W1;
+            const int iy = y1 + yy - pad, ix = x1 + xx - pad;
+            A[e] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? a0[(long)(c0 + c) * plane + (long)iy * W + ix] : corr_zero<T>();
+        }
+        for (int e = tid; e < cn * R2 * W2; e += 256) {
+            const int c = e / (R2 * W2), rem = e - c * (R2 * W2), yy = rem / W2, xx = rem - yy * W2;
+            const int iy = y2 + yy - pad, ix = x2 + xx - pad;
+            Bh[e] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? b0[(long)(c0 + c) * plane + (long)iy * W + ix] : corr_zero<T>();
+        }
+        __syncthreads();
+        for (int j = 0; j < K; ++j)
+            for (int i = 0; i < K; ++i)
+                for (int c = 0; c < cn; ++c) {
+                    const T a = A[(c * K + j) * W1 + oxl * s1 + i];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const int tj = slot + 16 * p;
+                        if (tj < D) {
+                            const T *brow = Bh + ((size_t)c * R2 + tj * s2 + j) * W2 + oxl * s1 + i;
+#pragma unroll
+                            for (int t = 0; t < DMAX; ++t)
+                                if (t < D) acc[p][t] = corr_prod(a, brow[t * s2], acc[p][t]);
+                        }
+                    }
+                }
+    }
+    const int ox = ox0 + oxl;
+    if (ox >= ow) return;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int tj = slot + 16 * p;
+        if (tj >= D) continue;
+#pragma unroll
+        for (int t = 0; t < DMAX; ++t)
+            if (t < D) corr_store(out + (((long)n * D * D + (long)tj * D + t) * oh + oy) * ow + ox, acc[p][t] / nelems);
+    }
+}
+
+template <typename T>
+static bool launch_corr_tiled(hipStream_t st, const T *in1, const T *in2, int B, int C, int H, int W, int pad, int kr,
+                              int md, int s1, int s2, int r, int oh, int ow, float nelems, T *out)
+{
+    const int D = 2 * r + 1, K = 2 * kr + 1;
+    if (D > 32) return false;
+    const size_t per_c = ((size_t)K * (15 * s1 + K) + (size_t)(K + 2 * r * s2) * (15 * s1 + K + 2 * r * s2)) * sizeof(T);
+    int CC = (int)(65536 / per_c);
+    if (CC < 1) return false;  // halo of one channel does not fit: the one-thread-per-output kernel handles it
+    if (CC > C) CC = C;
+    if (CC > 32) CC = 32;
+    const size_t lds = per_c * CC;
+    dim3 grid((unsigned)((ow + 15) / 16), (unsigned)oh, (unsigned)B);
+#define MANET_CORR_LAUNCH(DM_)                                                                                          \
+    {                                                                                                                   \
+        (void)hipFuncSetAttribute((const void *)correlation_forward_tiled_kernel<T, DM_>,                               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+        hipLaunchKernelGGL((correlation_forward_tiled_kernel<T, DM_>), grid, dim3(256), lds, st, in1, in2, C, H, W, pad, \
+                           kr, md, s1, s2, r, oh, ow, CC, nelems, out);                                                 \
+    }
+    if (D <= 8) MANET_CORR_LAUNCH(8)
+    else if (D <= 16) MANET_CORR_LAUNCH(16)
+    else MANET_CORR_LAUNCH(32)
+#undef MANET_CORR_LAUNCH
+    return true;
 }
 
 // Backward (reference: correlation_cuda_kernel.cu:150-241 grad wrt input1, :243-334 grad wrt input2; host wrapper
@@ -140,10 +256,41 @@ int manet_correlation_forward_f32(const float *in1, const float *in2, int B, int
     int r = max_displacement / stride2;
     long total = (long)B * oc * oh * ow;
     float nelems = (float)(kernel_size * kernel_size * C);
-    hipLaunchKernelGGL(correlation_forward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, in1, in2, B, C, H, W, pad_size, kr, max_displacement, stride1, stride2, r,
-                       oh, ow, nelems, out);
+    if (!launch_corr_tiled<float>((hipStream_t)stream, in1, in2, B, C, H, W, pad_size, kr, max_displacement, stride1,
+                                  stride2, r, oh, ow, nelems, out))
+        hipLaunchKernelGGL(correlation_forward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, in1, in2, B, C, H, W, pad_size, kr, max_displacement, stride1, stride2, r,
+                           oh, ow, nelems, out);
     return manet_check_launch("manet_correlation_forward_f32");
+}
+
+int manet_correlation_forward(const void *in1, const void *in2, int dtype, int B, int C, int H, int W, int pad_size,
+                              int kernel_size, int max_displacement, int stride1, int stride2, void *out,
+                              manet_stream_t stream)
+{
+    if (dtype == MANET_CORR_F32)
+        return manet_correlation_forward_f32((const float *)in1, (const float *)in2, B, C, H, W, pad_size, kernel_size,
+                                             max_displacement, stride1, stride2, (float *)out, stream);
+    int oc, oh, ow;
+    int rc = manet_correlation_out_dims(H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &oc, &oh, &ow);
+    if (rc) return rc;
+    if (!in1 || !in2 || !out || B <= 0 || C <= 0) return manet_set_error(MANET_E_INVALID, "bad arguments");
+    int kr = (kernel_size - 1) / 2;
+    int r = max_displacement / stride2;
+    float nelems = (float)(kernel_size * kernel_size * C);
+    bool ok = false;
+    if (dtype == MANET_CORR_F16)
+        ok = launch_corr_tiled<__half>((hipStream_t)stream, (const __half *)in1, (const __half *)in2, B, C, H, W, pad_size, kr,
+                                       max_displacement, stride1, stride2, r, oh, ow, nelems, (__half *)out);
+    else if (dtype == MANET_CORR_F64)
+        ok = launch_corr_tiled<double>((hipStream_t)stream, (const double *)in1, (const double *)in2, B, C, H, W, pad_size, kr,
+                                       max_displacement, stride1, stride2, r, oh, ow, nelems, (double *)out);
+    else
+        return manet_set_error(MANET_E_INVALID, "correlation dtype %d (MANET_CORR_F32 / _F16 / _F64)", dtype);
+    if (!ok)
+        return manet_set_error(MANET_E_INVALID, "half / double correlation: displacement grid (2r+1 = %d) or halo too "
+                                                "large for the tiled kernel (float has a fallback)", 2 * r + 1);
+    return manet_check_launch("manet_correlation_forward");
 }
 
 int manet_correlation_backward_f32(const float *in1, const float *in2, const float *grad_out, int B, int C, int H, int W,

@@ -351,7 +351,8 @@ def correlation_out_dims(H, W, pad_size, kernel_size, max_displacement, stride1,
 
 
 def correlation_forward(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2):
-    """correlation_cuda.forward (correlation_cuda.cc:10-87) -> [B, (2r+1)^2, outH, outW] fp32."""
+    """correlation_cuda.forward (correlation_cuda.cc:10-87) -> [B, (2r+1)^2, outH, outW] in the inputs' dtype
+    (float32 / float16 / float64; anything else is computed in float32)."""
     lib = _lib.load()
     if _wants_grad(input1, input2):
         from .autograd import CorrelationFn
@@ -360,18 +361,22 @@ def correlation_forward(input1, input2, pad_size, kernel_size, max_displacement,
         return CorrelationFn.apply(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2)
     _need_gpu(input1, "input1")
     _need_gpu(input2, "input2")
-    a = input1.float().contiguous()
-    b = input2.float().contiguous()
+    # the reference's forward dispatches float / double / half (correlation_cuda_kernel.cu:386-415)
+    code = {torch.float32: 0, torch.float16: 1, torch.float64: 2}.get(input1.dtype)
+    if code is None or input2.dtype != input1.dtype:
+        input1, input2, code = input1.float(), input2.float(), 0
+    a = input1.contiguous()
+    b = input2.contiguous()
     if a.dim() != 4 or a.shape != b.shape:
         raise ValueError("input1 and input2 must be [B, C, H, W] of the same shape")
     B, C, H, W = a.shape
     oc, oh, ow = correlation_out_dims(H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
-    out = torch.empty((B, oc, oh, ow), dtype=torch.float32, device=a.device)
+    out = torch.empty((B, oc, oh, ow), dtype=a.dtype, device=a.device)
     with torch.cuda.device(a.device):
-        rc = lib.manet_correlation_forward_f32(a.data_ptr(), b.data_ptr(), B, C, H, W, pad_size, kernel_size,
-                                               max_displacement, stride1, stride2, out.data_ptr(),
-                                               _stream_ptr(a.device))
-    _lib.check(rc, "manet_correlation_forward_f32")
+        rc = lib.manet_correlation_forward(a.data_ptr(), b.data_ptr(), code, B, C, H, W, pad_size, kernel_size,
+                                           max_displacement, stride1, stride2, out.data_ptr(),
+                                           _stream_ptr(a.device))
+    _lib.check(rc, "manet_correlation_forward")
     return out
 
 

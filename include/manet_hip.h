@@ -193,6 +193,15 @@ int manet_correlation_out_dims(int H, int W, int pad_size, int kernel_size, int 
 int manet_correlation_forward_f32(const float *in1, const float *in2, int B, int C, int H, int W,
                                   int pad_size, int kernel_size, int max_displacement, int stride1,
                                   int stride2, float *out, manet_stream_t stream);
+/* the same for the three tensor types the reference's forward dispatches (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ * correlation_cuda_kernel.cu:386-415): in1 / in2 / out all of `dtype`; product in that type, fp32 accumulate,
+ * mean stored in that type (correlation_cuda_kernel.cu:121-143). */
+#define MANET_CORR_F32 0
+#define MANET_CORR_F16 1 /* IEEE half */
+#define MANET_CORR_F64 2
+int manet_correlation_forward(const void *in1, const void *in2, int dtype, int B, int C, int H, int W,
+                              int pad_size, int kernel_size, int max_displacement, int stride1,
+                              int stride2, void *out, manet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Mask step between two propagated frames (the driver side of the path):

@@ -130,7 +130,30 @@ def test_correlation_vs_oracle(ops, oracle):
         out = ops.correlation_forward(dev(a), dev(b), pad, K, md, s1, s2).cpu().numpy()
         want = oracle.correlation_forward(a, b, pad, K, md, s1, s2)
         assert out.shape == want.shape
-        np.testing.assert_array_equal(out, want)  # same fmaf chain order
+        if K == 1:
+            np.testing.assert_array_equal(out, want)  # same fmaf chain order
+        else:  # the LDS-tiled kernel sums (channel chunk, j, i, c) instead of (j, i, c): fp32 rounding
+            np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float64])
+@pytest.mark.parametrize("cfgc", [(2, 5, 9, 8, 3, 3, 2, 2, 2), (1, 100, 20, 27, 4, 1, 4, 1, 1), (1, 16, 14, 40, 12, 1, 12, 1, 1)])
+def test_correlation_half_and_double(ops, dtype, cfgc):
+    """the reference's forward dispatches float / double / half (correlation_cuda_kernel.cu:386-415): product in the
+    tensor's type, fp32 accumulation, mean stored in the tensor's type (:121-143)"""
+    B, C, H, W, pad, K, md, s1, s2 = cfgc
+    g = torch.Generator().manual_seed(5)
+    a = (torch.randn(B, C, H, W, generator=g) * 0.5).to(dtype).cuda()
+    b = (torch.randn(B, C, H, W, generator=g) * 0.5).to(dtype).cuda()
+    out = ops.correlation_forward(a, b, pad, K, md, s1, s2)
+    assert out.dtype == dtype
+    ref = ops.correlation_forward(a.float(), b.float(), pad, K, md, s1, s2)  # fp32 kernel on the same values
+    if dtype == torch.float16:
+        # each product carries a 2^-11 relative rounding before the fp32 sum, the result one more
+        scale = (a.float().abs().max() * b.float().abs().max()).item()
+        assert (out.float() - ref).abs().max().item() < 3e-3 * scale
+    else:
+        torch.testing.assert_close(out.float(), ref, rtol=1e-5, atol=1e-6)
 
 
 def test_correlation_tied_to_reference_distance(ops):
