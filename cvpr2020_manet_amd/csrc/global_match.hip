@@ -320,17 +320,23 @@ __device__ __forceinline__ float emb_load(const unsigned short *p, long i) { ret
 // fmaf chain of the oracle (IntVOS.py:32,35) -- over the bf16-rounded values in MANET_COMPUTE_BF16
 // (the path then IS the reference formula on rounded embeddings), over the fp32 values otherwise.
 // f32 images carry the norms in a trailing block; bf16 images carry them in the spare k slots (Geom).
-template <int ROWS, typename SRC>
+// ROWS = rows staged per workgroup (a whole number of image blocks); IMG = rows per image block (64: bank tile,
+// 32: query block).  keys != nullptr (query):
+// the rows' match keys are reset to "no candidate" here, which saves the fill launch of the per-frame sequence.
+template <int ROWS, int IMG, typename SRC>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const SRC *__restrict__ src, long s_row,
                                                         long s_c, const int *__restrict__ src_of,
                                                         const int *__restrict__ meta, long n_rows,
                                                         int C, int compute, int units, int kpad,
                                                         char *__restrict__ dst, long tile_bytes,
-                                                        float pad_norm)
+                                                        float pad_norm, unsigned *__restrict__ keys, long N_pad,
+                                                        int n_ids)
 {
-    constexpr bool IS_QUERY = (ROWS == QB);
+    constexpr bool IS_QUERY = (IMG == QB);
     const long tile = blockIdx.x;
     if (meta && tile >= meta[META_T]) return;
+    if (keys)
+        for (int i = threadIdx.x; i < ROWS * n_ids; i += 256) keys[(size_t)(i / ROWS) * N_pad + tile * ROWS + (i % ROWS)] = 0xffffffffu;
     extern __shared__ __attribute__((aligned(16))) char pack_smem[];
     const int KP = kpad + 1;  // odd row stride: column reads are conflict-free
     float *rows = (float *)pack_smem;                  // [ROWS][KP]
@@ -377,15 +383,16 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const SRC *__restrict__ 
         s_norm[tid] = n;
     }
     __syncthreads();
-    char *out = dst + tile * tile_bytes;
+    // image block of staged row r: block (tile * ROWS/IMG + r / IMG), row r % IMG inside it
+    char *out0 = dst + tile * (ROWS / IMG) * tile_bytes;
     if (compute == MANET_COMPUTE_F32) {
         for (int item = tid; item < units * ROWS; item += 256) {
             int r = item % ROWS, u = item / ROWS;
             const float *row = rows + r * KP + 8 * (u >> 1) + (u & 1);
             f32x4 v = {row[0], row[2], row[4], row[6]};
-            *(f32x4 *)(out + ((long)u * ROWS + r) * 16) = v;
+            *(f32x4 *)(out0 + (r / IMG) * tile_bytes + ((long)u * IMG + r % IMG) * 16) = v;
         }
-        if (tid < ROWS) *(float *)(out + (long)units * ROWS * 16 + tid * 4) = s_norm[tid];
+        if (tid < ROWS) *(float *)(out0 + (tid / IMG) * tile_bytes + (long)units * IMG * 16 + (tid % IMG) * 4) = s_norm[tid];
     } else {
         const int hi_units = (compute == MANET_COMPUTE_BF16X3) ? units / 2 : units;
         const float scale = IS_QUERY ? -2.0f : 1.0f;  // the query operand is -2q (exact in bf16)
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const SRC *__restrict__ 
                     }
                 }
             }
-            *(uint4 *)(out + ((long)u * ROWS + r) * 16) =
+            *(uint4 *)(out0 + (r / IMG) * tile_bytes + ((long)u * IMG + r % IMG) * 16) =
                 make_uint4(e8[0] | (e8[1] << 16), e8[2] | (e8[3] << 16), e8[4] | (e8[5] << 16), e8[6] | (e8[7] << 16));
         }
     }
@@ -1372,21 +1379,40 @@ __global__ void normalize_merge_kernel(float *__restrict__ x, float *__restrict_
     x[i] = g;
 }
 
-// pack launch for either row-block size and either embedding storage type
-template <int ROWS>
-int launch_pack(const void *src, int emb_dtype, long s_row, long s_c, const int *src_of, const int *meta, long n_rows,
-                int C, const Geom &G, char *dst, long nblocks, float pad_norm, hipStream_t st)
+// bank pack (64-row tiles) and query pack (32-row blocks; keys != nullptr: also resets the rows' match keys)
+// for either embedding storage type
+int launch_bank_pack(const void *src, int emb_dtype, long s_row, long s_c, const int *src_of, const int *meta, long n_rows,
+                     int C, const Geom &G, char *dst, long ntiles, hipStream_t st)
 {
-    if (nblocks <= 0) return MANET_OK;
-    const size_t lds = (size_t)ROWS * (G.kpad + 1) * sizeof(float) + 2 * ROWS * sizeof(int);
-    const long blk = ROWS == QB ? (long)G.qblk_bytes : (long)G.tile_bytes;
+    if (ntiles <= 0) return MANET_OK;
+    const size_t lds = (size_t)BT * (G.kpad + 1) * sizeof(float) + 2 * BT * sizeof(int);
     if (emb_dtype == MANET_EMB_F32)
-        hipLaunchKernelGGL((pack_rows_kernel<ROWS, float>), dim3((unsigned)nblocks), dim3(256), lds, st, (const float *)src,
-                           s_row, s_c, src_of, meta, n_rows, C, G.compute, G.units, G.kpad, dst, blk, pad_norm);
+        hipLaunchKernelGGL((pack_rows_kernel<BT, BT, float>), dim3((unsigned)ntiles), dim3(256), lds, st, (const float *)src,
+                           s_row, s_c, src_of, meta, n_rows, C, G.compute, G.units, G.kpad, dst, (long)G.tile_bytes,
+                           MANET_WRONG_LABEL_PADDING_DISTANCE, (unsigned *)nullptr, 0L, 0);
     else if (emb_dtype == MANET_EMB_BF16)
-        hipLaunchKernelGGL((pack_rows_kernel<ROWS, unsigned short>), dim3((unsigned)nblocks), dim3(256), lds, st,
+        hipLaunchKernelGGL((pack_rows_kernel<BT, BT, unsigned short>), dim3((unsigned)ntiles), dim3(256), lds, st,
                            (const unsigned short *)src, s_row, s_c, src_of, meta, n_rows, C, G.compute, G.units, G.kpad,
-                           dst, blk, pad_norm);
+                           dst, (long)G.tile_bytes, MANET_WRONG_LABEL_PADDING_DISTANCE, (unsigned *)nullptr, 0L, 0);
+    else
+        return manet_set_error(MANET_E_INVALID, "embedding dtype %d (MANET_EMB_F32 / MANET_EMB_BF16)", emb_dtype);
+    return MANET_OK;
+}
+
+int launch_query_pack(const void *src, int emb_dtype, long s_row, long s_c, long N, long N_pad, int C, const Geom &G,
+                      char *dst, unsigned *keys, int n_ids, hipStream_t st)
+{
+    constexpr int SR = QB;  // staged rows per workgroup (two blocks per workgroup measured slower: 22 vs 16 us at 480p)
+    const size_t lds = (size_t)SR * (G.kpad + 1) * sizeof(float) + 2 * SR * sizeof(int);
+    const unsigned blocks = (unsigned)(N_pad / SR);
+    if (emb_dtype == MANET_EMB_F32)
+        hipLaunchKernelGGL((pack_rows_kernel<SR, QB, float>), dim3(blocks), dim3(256), lds, st, (const float *)src, s_row, s_c,
+                           (const int *)nullptr, (const int *)nullptr, N, C, G.compute, G.units, G.kpad, dst,
+                           (long)G.qblk_bytes, 0.0f, keys, N_pad, n_ids);
+    else if (emb_dtype == MANET_EMB_BF16)
+        hipLaunchKernelGGL((pack_rows_kernel<SR, QB, unsigned short>), dim3(blocks), dim3(256), lds, st,
+                           (const unsigned short *)src, s_row, s_c, (const int *)nullptr, (const int *)nullptr, N, C,
+                           G.compute, G.units, G.kpad, dst, (long)G.qblk_bytes, 0.0f, keys, N_pad, n_ids);
     else
         return manet_set_error(MANET_E_INVALID, "embedding dtype %d (MANET_EMB_F32 / MANET_EMB_BF16)", emb_dtype);
     return MANET_OK;
@@ -1606,8 +1632,8 @@ int manet_bank_prepare_ex(const void *bank, int emb_dtype, int64_t b_stride_m, i
     if (M0 > 0)
         hipLaunchKernelGGL(label_scatter_kernel, dim3((unsigned)L.nblocks), dim3(RPB), 0, st, labels, (long)M0, n_ids,
                            (const int *)hist, (const int *)meta, src_of);
-    rc = launch_pack<BT>(bank, emb_dtype, (long)b_stride_m, (long)b_stride_c, (const int *)src_of, (const int *)meta, (long)M0,
-                         C, L.G, ws + L.off_pack, L.T_max, MANET_WRONG_LABEL_PADDING_DISTANCE, st);
+    rc = launch_bank_pack(bank, emb_dtype, (long)b_stride_m, (long)b_stride_c, (const int *)src_of, (const int *)meta, (long)M0,
+                          C, L.G, ws + L.off_pack, L.T_max, st);
     if (rc) return rc;
     return manet_check_launch("manet_bank_prepare");
 }
@@ -1631,8 +1657,8 @@ int manet_query_pack(const void *query, int emb_dtype, int64_t q_stride_n, int64
     MatchLayout ML = match_layout(N, C, 1, compute);
     const size_t need = (size_t)(ML.N_pad / QB) * ML.qblk_bytes;
     if (packed_bytes < need) return manet_set_error(MANET_E_WORKSPACE, "packed query buffer %zu < %zu bytes", packed_bytes, need);
-    rc = launch_pack<QB>(query, emb_dtype, (long)q_stride_n, (long)q_stride_c, nullptr, nullptr, (long)N, C, ML.G,
-                         (char *)packed, ML.N_pad / QB, 0.0f, (hipStream_t)stream);
+    rc = launch_query_pack(query, emb_dtype, (long)q_stride_n, (long)q_stride_c, (long)N, ML.N_pad, C, ML.G, (char *)packed,
+                           nullptr, 0, (hipStream_t)stream);
     if (rc) return rc;
     return manet_check_launch("manet_query_pack");
 }
@@ -1663,14 +1689,15 @@ int manet_global_match_prepared_ex(const void *query, int emb_dtype, int64_t q_s
     char *mws = (char *)match_ws;
     const int *meta = (const int *)(bws + BL.off_meta);
     unsigned *keys = (unsigned *)(mws + ML.off_keys);
-    fill32(keys, 0xffffffffu, (size_t)n_ids * ML.N_pad, st);
     // MANET_EMB_PACKED: `query` already is the operand image manet_query_pack wrote (same N, C, compute)
     const char *qpack = (const char *)query;
     if (emb_dtype != MANET_EMB_PACKED) {
-        rc = launch_pack<QB>(query, emb_dtype, (long)q_stride_n, (long)q_stride_c, nullptr, nullptr, (long)N, C, ML.G,
-                             mws + ML.off_q, ML.N_pad / QB, 0.0f, st);
+        rc = launch_query_pack(query, emb_dtype, (long)q_stride_n, (long)q_stride_c, (long)N, ML.N_pad, C, ML.G,
+                               mws + ML.off_q, keys, n_ids, st);  // also resets the keys
         if (rc) return rc;
         qpack = mws + ML.off_q;
+    } else {
+        fill32(keys, 0xffffffffu, (size_t)n_ids * ML.N_pad, st);
     }
     // resident workgroup slots: f32 and plain bf16 (wide kernel) = 2 x 256-thread workgroups per CU,
     // split-bf16 (and the tuning-only narrow/flat bf16 forms) = 1 x 512-thread workgroup per CU
@@ -1788,8 +1815,8 @@ int manet_global_match_arg_f32(const float *query, int64_t q_stride_n, int64_t q
     const int *meta = (const int *)(bws + BL.off_meta);
     unsigned long long *keys64 = (unsigned long long *)(mws + ML.off_topk);
     fill32(keys64, 0xffffffffu, (size_t)2 * n_ids * ML.N_pad, st);
-    rc = launch_pack<QB>(query, MANET_EMB_F32, (long)q_stride_n, (long)q_stride_c, nullptr, nullptr, (long)N, C, ML.G,
-                         mws + ML.off_q, ML.N_pad / QB, 0.0f, st);
+    rc = launch_query_pack(query, MANET_EMB_F32, (long)q_stride_n, (long)q_stride_c, (long)N, ML.N_pad, C, ML.G,
+                           mws + ML.off_q, nullptr, 0, st);
     if (rc) return rc;
     int S = pick_splits(ML.nQT, BL.T_max, 512);
     const char *qpack = mws + ML.off_q, *bpack = bws + BL.off_pack;

@@ -360,15 +360,17 @@ __global__ void local_upsample_kernel(const float *__restrict__ dvol, int h, int
 // by atomicMin on the float bits (all candidates lie in [0, 1]; `out` is pre-set to 1.0, the reference's
 // "no match" value, IntVOS.py:429-430).
 __host__ __device__ constexpr int lf_cols(int d) { return d <= 6 ? 2 : 4; }                       // columns per thread
-// d >= 10: a thread owns one HALF of the window columns (dx 0..11 | 12..2d): 4 x 13 instead of 4 x 25 running sums,
-// twice the threads -- two waves per SIMD for the arithmetic and twice the lanes for the per-pixel phase
-__host__ __device__ constexpr int lf_dxs(int d) { return d >= 10 ? 2 : 1; }
-constexpr int LF_PH = 12;  // window columns of the first half (a multiple of 4: the second half's reads stay 16-byte aligned)
+// d = 3, 4 and d >= 10: a thread owns one HALF of the window columns (d=4: dx 0..3 | 4..8, d=12: 0..11 | 12..24): half
+// the running sums, twice the threads -- two waves per SIMD for the arithmetic (a workgroup per CU is all the grid
+// offers, so threads are the only source of latency hiding) and twice the lanes for the per-pixel phase
+__host__ __device__ constexpr int lf_dxs(int d) { return (d == 3 || d == 4 || d >= 10) ? 2 : 1; }
+// window columns of the first half: a multiple of the column group, so the second half's vector reads stay aligned
+__host__ __device__ constexpr int lf_ph(int d) { return lf_cols(d) == 4 ? 12 : ((d + 1) & ~1); }
 __host__ __device__ constexpr int lf_pa(int d)  // running sums per column per thread
 {
-    return lf_dxs(d) == 1 ? 2 * d + 1 : ((2 * d + 1 - LF_PH) > LF_PH ? (2 * d + 1 - LF_PH) : LF_PH);
+    return lf_dxs(d) == 1 ? 2 * d + 1 : ((2 * d + 1 - lf_ph(d)) > lf_ph(d) ? (2 * d + 1 - lf_ph(d)) : lf_ph(d));
 }
-__host__ __device__ constexpr int lf_nt(int d) { return d <= 4 ? 256 : (d <= 6 ? 512 : (d <= 9 ? 256 : 512)); }  // threads
+__host__ __device__ constexpr int lf_nt(int d) { return d <= 2 ? 256 : (d <= 6 ? 512 : (d <= 9 ? 256 : 512)); }  // threads
 __host__ __device__ constexpr int lf_slots(int d) { return lf_nt(d) / ((16 / lf_cols(d)) * lf_dxs(d)); }  // (row, dy) slots
 __host__ __device__ constexpr int lf_nd(int d) { return d <= 10 ? 2 * d + 1 : (d == 11 ? 12 : 5); }  // dy per workgroup
 __host__ __device__ constexpr int lf_ndg(int d) { return (2 * d + 1 + lf_nd(d) - 1) / lf_nd(d); }
@@ -376,7 +378,7 @@ __host__ __device__ constexpr int lf_sy(int d) { return lf_slots(d) / lf_nd(d) >
 constexpr int LF_SX = 16;  // columns of S
 __host__ __device__ constexpr int lf_cw(int d)  // halo row stride (every thread reads whole vectors: room for the over-read)
 {
-    return lf_dxs(d) == 2 ? 40 : ((LF_SX + 2 * d + 3) & ~3);
+    return lf_cols(d) == 4 && lf_dxs(d) == 2 ? 40 : ((LF_SX + 2 * d + 3) & ~3);
 }
 __host__ __device__ constexpr int lf_yr(int d) { return lf_sy(d) + lf_nd(d) - 1; }                // halo rows
 __host__ __device__ constexpr int lf_yplane(int d) { return lf_yr(d) * lf_cw(d); }
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int P = 2 * D + 1, NT = lf_nt(D), ND = lf_nd(D), NDG = lf_ndg(D), SY = lf_sy(D), TY = SY - 1;
     constexpr int TX = LF_SX - 1, CW = lf_cw(D), YR = lf_yr(D), CC = lf_cc(D), COLS = lf_cols(D), NG = LF_SX / COLS;
-    constexpr int DXS = lf_dxs(D), PA = lf_pa(D);
+    constexpr int DXS = lf_dxs(D), PA = lf_pa(D), LF_PH = lf_ph(D);
     constexpr int yplane = YR * CW, xplane = SY * LF_SX;
     constexpr int buf_floats = CC * (yplane + xplane);
     constexpr int NVY = yplane / 4, NVX = xplane / 4;          // float4 per channel
@@ -483,8 +485,10 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         xgo[k] = (D + a + r) * WS + D + b0 + 4 * q;
         xlo[k] = CC * yplane + c * xplane + r * LF_SX + 4 * q;
     }
-    f32x4 ry_[KY], rx_[KX];
-    auto load_regs = [&](int c0) __attribute__((always_inline)) {  // unconditional, clamped: no branches
+    // two register sets: a stage's loads are issued TWO compute phases before its LDS store (one phase is shorter
+    // than the L2 / Infinity-Cache latency of the pooled planes, which the previous launch has only just written)
+    f32x4 ryA[KY], rxA[KX], ryB[KY], rxB[KX];
+    auto load_regs = [&](f32x4 (&ry_)[KY], f32x4 (&rx_)[KX], int c0) __attribute__((always_inline)) {  // unconditional, clamped
 #pragma unroll
         for (int k = 0; k < KY; ++k) {
             int ch = c0 + (ych[k] < 0 ? 0 : ych[k]);
@@ -498,8 +502,8 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
             rx_[k] = *(const f32x4 *)(curp + (long)ch * PS + xgo[k]);
         }
     };
-    auto store_lds = [&](int buf, int c0) __attribute__((always_inline)) {  // channels beyond C: x = y = 0 (add 0)
-        float *st = smem + (long)buf * buf_floats;
+    auto store_lds = [&](const f32x4 (&ry_)[KY], const f32x4 (&rx_)[KX], int buf, int c0) __attribute__((always_inline)) {
+        float *st = smem + (long)buf * buf_floats;  // channels beyond C: x = y = 0 (they add 0)
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < KY; ++k)
@@ -523,55 +527,65 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
 #pragma unroll
         for (int i = 0; i < PA; ++i) acc[j][i] = 0.0f;
 
-    load_regs(0);
-    store_lds(0, 0);
-    __syncthreads();
-    int buf = 0;
-    for (int c0 = 0; c0 < C; c0 += CC, buf ^= 1) {
-        const bool more = (c0 + CC) < C;
-        if (more) load_regs(c0 + CC);  // next stage's global loads fly under this stage's math
+    auto compute = [&](int buf_) __attribute__((always_inline)) {
         if (active && !(abl & 1)) {
-            const float *ys = smem + (long)buf * buf_floats;
-            const float *xs = ys + CC * yplane;
+        const float *ys = smem + (long)buf_ * buf_floats;
+        const float *xs = ys + CC * yplane;
 #pragma unroll 2
-            for (int c = 0; c < CC; ++c) {
-                const float *yrow = ys + c * yplane + (ry + dyi) * CW + COLS * g + dx_lo;
-                const float *xrow = xs + c * xplane + ry * LF_SX + COLS * g;
-                float win[WN], xv[COLS];
-                if constexpr (COLS == 2) {
-                    const float2 t = *(const float2 *)xrow;
-                    xv[0] = t.x;
-                    xv[1] = t.y;
+        for (int c = 0; c < CC; ++c) {
+            const float *yrow = ys + c * yplane + (ry + dyi) * CW + COLS * g + dx_lo;
+            const float *xrow = xs + c * xplane + ry * LF_SX + COLS * g;
+            float win[WN], xv[COLS];
+            if constexpr (COLS == 2) {
+                const float2 t = *(const float2 *)xrow;
+                xv[0] = t.x;
+                xv[1] = t.y;
 #pragma unroll
-                    for (int i = 0; i < WN / 2; ++i) {
-                        const float2 u = *(const float2 *)(yrow + 2 * i);
-                        win[2 * i] = u.x;
-                        win[2 * i + 1] = u.y;
-                    }
-                } else {
-                    const f32x4 t = *(const f32x4 *)xrow;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) xv[j] = t[j];
-#pragma unroll
-                    for (int i = 0; i < WN / 4; ++i) {
-                        const f32x4 u = *(const f32x4 *)(yrow + 4 * i);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) win[4 * i + j] = u[j];
-                    }
+                for (int i = 0; i < WN / 2; ++i) {
+                    const float2 u = *(const float2 *)(yrow + 2 * i);
+                    win[2 * i] = u.x;
+                    win[2 * i + 1] = u.y;
                 }
+            } else {
+                const f32x4 t = *(const f32x4 *)xrow;
 #pragma unroll
-                for (int dx = 0; dx < PA; ++dx) {
+                for (int j = 0; j < 4; ++j) xv[j] = t[j];
 #pragma unroll
-                    for (int j = 0; j < COLS; ++j) {
-                        const float dd = xv[j] - win[dx + j];
-                        acc[j][dx] = fmaf(dd, dd, acc[j][dx]);
-                    }
+                for (int i = 0; i < WN / 4; ++i) {
+                    const f32x4 u = *(const f32x4 *)(yrow + 4 * i);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) win[4 * i + j] = u[j];
+                }
+            }
+#pragma unroll
+            for (int dx = 0; dx < PA; ++dx) {
+#pragma unroll
+                for (int j = 0; j < COLS; ++j) {
+                    const float dd = xv[j] - win[dx + j];
+                    acc[j][dx] = fmaf(dd, dd, acc[j][dx]);
                 }
             }
         }
-        if (more) store_lds(buf ^ 1, c0 + CC);
+    }
+    };
+    load_regs(ryA, rxA, 0);
+    store_lds(ryA, rxA, 0, 0);
+    if (CC < C) load_regs(ryB, rxB, CC);
+    __syncthreads();
+    for (int c0 = 0; c0 < C; c0 += 2 * CC) {
+        // stage c0 is in LDS buffer 0, set B holds stage c0 + CC
+        if (c0 + 2 * CC < C) load_regs(ryA, rxA, c0 + 2 * CC);
+        compute(0);
+        if (c0 + CC >= C) break;
+        store_lds(ryB, rxB, 1, c0 + CC);
+        __syncthreads();
+        // stage c0 + CC is in LDS buffer 1, set A holds stage c0 + 2 CC
+        if (c0 + 3 * CC < C) load_regs(ryB, rxB, c0 + 3 * CC);
+        compute(1);
+        if (c0 + 2 * CC < C) store_lds(ryA, rxA, 0, c0 + 2 * CC);
         __syncthreads();
     }
+    __syncthreads();
 
     // ---- phase 2: normalised volume of S and the labels around the tile into LDS -----------------
     float *V = smem;                                           // [ND][P][SY][16]
