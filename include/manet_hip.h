@@ -26,6 +26,11 @@
  *   manet_upsample_argmax     test.py:253-255 + networks/IntVOS.py:598-599
  *   manet_dwconv7x7_bn_relu_f32  networks/IntVOS.py:491-493,500-502
  *
+ * NaN inputs (outside the reference's contract, documented deviation): the global match propagates a NaN
+ * distance to the output like torch.min does, but a NaN bank row poisons only its own object (in the reference
+ * the +1e20 label mask spreads it to every object); the local masked min (fminf) and the mask-step argmax ignore
+ * NaN candidates where torch.min / torch.argmax would return them.
+ *
  * Status codes: 0 = ok; negative = error (see MANET_E_*); manet_last_error_string() gives the
  * text of the last error raised on the calling thread.
  * Thread-safety: the data-path functions are re-entrant and keep no state between calls (the
