@@ -943,9 +943,10 @@ __global__ __launch_bounds__(512, 1) void global_match_bf16_kernel(const char *_
 //     registers, so the barrier (a) publishes the next step's buffer, whose first fragments tile B's k-steps
 //     prefetch, and (b) frees the current buffer for the LDS-DMA of the step after next.  No fragment read
 //     ever follows a barrier directly; two LDS buffers suffice.
-// NBUF = LDS ring depth (2: a step's DMA has one step of lead; 3: two).  ABL: timing ablations only (results are
-// garbage): 1 = no DMA / no vmcnt wait, 2 = no barrier, 4 = epilogue reduced to one min3, 8 = no fragment refills.
-template <int KSB, int NBUF, int ABL>
+// ABL: timing ablations only (results are garbage): 1 = no DMA / no vmcnt wait, 2 = no barrier, 4 = epilogue
+// reduced to one min3, 8 = no fragment refills.  (A 3-deep LDS ring with counted vmcnt(N) waits -- the DMA two
+// steps ahead -- was measured slower, 0.529 vs 0.498 ms, and removed: DMA latency is not the stall.)
+template <int KSB, int ABL>
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void global_match_bf16_pipe_kernel(const char *__restrict__ qpack, const char *__restrict__ bpack,
                                    const int *__restrict__ meta, int n_ids, int nQT, int S, long N_pad,
@@ -958,6 +959,7 @@ void global_match_bf16_pipe_kernel(const char *__restrict__ qpack, const char *_
     constexpr size_t QBLK_BYTES = query_block_bytes_u(UNITS, false);
     constexpr size_t STEP_BYTES = TILE_BYTES * TPS;
     constexpr int QTB = NW * 64;
+    constexpr int NBUF = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // NBUF x STEP_BYTES
 
     const int tid = threadIdx.x;
@@ -995,26 +997,8 @@ void global_match_bf16_pipe_kernel(const char *__restrict__ qpack, const char *_
             if (pc < np) lds_dma16(g + (size_t)pc * 1024, l + (unsigned)pc * 1024u);
         }
     };
-    // s_waitcnt vmcnt(n) with n = this wave's pieces of the `keep` youngest FULL steps: waits for everything
-    // older (VMEM loads return in order).  A full step is PIECES pieces dealt round-robin to the 8 waves.
-    constexpr int P_HI = (PIECES + NW - 1) / NW, P_LO = PIECES / NW;
-    const bool many = (PIECES % NW) != 0 && wave < (PIECES % NW);  // wave-uniform
-    auto wait_dma_keep = [&](int keep) __attribute__((always_inline)) {
-        if (ABL & 1) keep = 0;
-        if (keep == 2) {
-            if (many) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P_HI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P_LO) : "memory");
-        } else if (keep == 1) {
-            if (many) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_HI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_LO) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    };
-    auto full_step = [&](int t) { return t + TPS <= t1; };  // both tiles exist
     stage_dma(t0, 0, true);
     if (t0 + TPS < t1) stage_dma(t0 + TPS, 1, true);
-    if (NBUF == 3 && t0 + 2 * TPS < t1) stage_dma(t0 + 2 * TPS, 2, true);
 
     u32x4 q0[KSB], q1[KSB];
     {
@@ -1086,26 +1070,24 @@ void global_match_bf16_pipe_kernel(const char *__restrict__ qpack, const char *_
         }                                                                                          \
     }
 
-    // prologue: steps 0, 1, 2 in flight; publish step 0 (1 and 2 keep flying if they are full steps),
-    // fetch tile A's fragments
-    wait_dma_keep(NBUF == 3 ? (full_step(t0 + 2 * TPS) ? 2 : 0) : (full_step(t0 + TPS) ? 1 : 0));
+    // prologue: steps 0 and 1 in flight; publish step 0, fetch tile A's fragments
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int k = 0; k < KSB; ++k) MANET_LOADF(k, smem);
 
     int buf = 0;
-    for (int t = t0; t < t1; t += TPS, buf = (buf == NBUF - 1 ? 0 : buf + 1)) {
+    for (int t = t0; t < t1; t += TPS, buf ^= 1) {
         const char *cur = smem + (size_t)buf * STEP_BYTES;
-        const char *nxt = smem + (size_t)(buf == NBUF - 1 ? 0 : buf + 1) * STEP_BYTES;
+        const char *nxt = smem + (size_t)(buf ^ 1) * STEP_BYTES;
         // ---- tile A (its fragments are in F; refill F with tile B of the same buffer)
         next_object(t);
         MANET_TILE(cur + TILE_BYTES);
-        // ---- mid-step: everything of this buffer is in registers now.  Wait for this wave's pieces of the
-        // NEXT step (issued two steps ago; the step after next keeps flying), then the barrier publishes the
-        // next step's buffer and frees this one for step + 3.  (An LDS-DMA piece takes ~1 us from issue to
-        // landed at ~25 GB/s per CU -- about one step of matrix work, so one step of lead is not enough.)
-        wait_dma_keep(NBUF == 3 && full_step(t + 2 * TPS) ? 1 : 0);
+        // ---- mid-step: everything of this buffer is in registers now.  This wave's pieces of the next step have
+        // landed (issued one step ago); the barrier publishes the next step's buffer and frees this one for the
+        // step after next.
+        if (!(ABL & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of `cur` have returned
         if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1513,11 +1495,15 @@ void launch_main_bf16_v(const char *qpack, const char *bpack, const int *meta, i
     manet_profile_record(st, false);
 }
 
-// Shipped shape of the bf16 kernels: 2 tiles per step (1 for split-bf16), asm LDS-DMA staging.
-// MANET_TUNE_BF16_VARIANT (experiments; bit field): bits 0-1: tiles per step 0 = default, 1 = one,
-// 2 = four (two for split-bf16); bit 2: register staging instead of LDS-DMA; bit 3: static s_setprio 1
-// for waves 4-7; bit 4: plain bf16 on the un-pipelined kernel (the split-bf16 structure).  None of it changes
-// a workspace layout.
+// Shipped: plain bf16 -> global_match_bf16_wide_kernel (global_match_bf16_pipe_kernel for C > 106);
+// split-bf16 -> global_match_bf16_kernel<KSB, true, 1, true> (1 tile per step, asm LDS-DMA staging).
+// MANET_TUNE_BF16_VARIANT (experiments; bit field, none of it changes a workspace layout):
+//   bits 0-1  global_match_bf16_kernel: tiles per step 0 = default, 1 = one, 2 = four (two for split-bf16)
+//   bit 2     global_match_bf16_kernel: register staging instead of LDS-DMA
+//   bit 3     static s_setprio 1 for waves 4-7 (8-wave kernels)
+//   bit 4     plain bf16 on global_match_bf16_kernel (the un-pipelined loop)
+//   bit 6     plain bf16 on global_match_bf16_pipe_kernel (8 waves, 64 x 64 wave tile)
+// MANET_TUNE_ABLATION (key 3) selects the timing-ablation instantiations of the two pipelined kernels.
 template <int KSB, bool X3>
 void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S, long N_pad,
                       unsigned *keys, hipStream_t st)
@@ -1526,19 +1512,18 @@ void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int
     const int tps = v & 3, reg = (v >> 2) & 1, flat = (v >> 4) & 1;
     int prio = (v >> 3) & 1;
     if (!X3 && !flat) {  // plain-bf16 kernels: software-pipelined fragments, barrier in front of the step's last pass
-        const int nbuf = (v >> 5) & 1 ? 3 : 2;
         // the 8-wave 64x64-wave-tile form: tuning, and KSB = 9 (C > 106), whose 144 operand VGPRs do not fit the wide form
         const int narrow = ((v >> 6) & 1) || KSB == 9;
         const int abl = KSB == 7 ? manet_tune_get(MANET_TUNE_ABLATION, 0) : 0;  // timing experiments only
         const void *fn = nullptr;
         unsigned threads = 512;
-        size_t lds = (size_t)nbuf * 2 * bank_tile_bytes_u(2 * KSB, false);
+        size_t lds = (size_t)2 * 2 * bank_tile_bytes_u(2 * KSB, false);
         if (narrow) {
-#define MANET_PK(NB_, AB_)                                                                         \
-    if (nbuf == NB_ && abl == AB_) fn = (const void *)global_match_bf16_pipe_kernel<KSB, NB_, (KSB == 7 ? AB_ : 0)>;
-            MANET_PK(2, 0) MANET_PK(3, 0) MANET_PK(2, 1) MANET_PK(2, 2) MANET_PK(2, 4) MANET_PK(2, 8) MANET_PK(2, 15)
+#define MANET_PK(AB_) \
+    if (abl == AB_) fn = (const void *)global_match_bf16_pipe_kernel<KSB, (KSB == 7 ? AB_ : 0)>;
+            MANET_PK(0) MANET_PK(1) MANET_PK(2) MANET_PK(4) MANET_PK(8) MANET_PK(15)
 #undef MANET_PK
-            if (!fn) fn = (const void *)global_match_bf16_pipe_kernel<KSB, 2, 0>;
+            if (!fn) fn = (const void *)global_match_bf16_pipe_kernel<KSB, 0>;
         } else {
             threads = 256;
             lds = (size_t)2 * 2 * bank_tile_bytes_u(2 * KSB, false);
