@@ -420,13 +420,17 @@ static PoolPad lf_pool_pad(int h, int w, int d)
 // the previous frame (IntVOS.py:287: (x - 1e20)^2 = inf -> 1.0 after normalisation, no bounds logic downstream)
 __device__ __forceinline__ float lf_ld(const float *p, long i) { return p[i]; }
 __device__ __forceinline__ float lf_ld(const unsigned short *p, long i) { return __uint_as_float((unsigned)p[i] << 16); }  // bf16
+// out_init != nullptr (window rows dealt to several workgroups per tile): `out` is pre-set to 1.0 here, the value the
+// partial minima are atomicMin'ed into -- one launch fewer than a separate fill.
 template <typename SRC>  // float, or bf16 as raw 16-bit words (the producer's storage)
 __global__ void lf_pool_pad_kernel(const SRC *__restrict__ a, long a_sy, long a_sx, long a_sc,
                                    const SRC *__restrict__ b, long b_sy, long b_sx, long b_sc, int C, int hp, int wp,
-                                   int d, int HPAD, int WS, float *__restrict__ ap, float *__restrict__ bp)
+                                   int d, int HPAD, int WS, float *__restrict__ ap, float *__restrict__ bp,
+                                   float *__restrict__ out_init, long n_out)
 {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long plane = (long)HPAD * WS;
+    if (out_init && i < n_out) out_init[i] = 1.0f;  // the launcher checked n_out <= plane * C
     if (i >= plane * C) return;
     int c = (int)(i / plane);
     int rem = (int)(i - (long)c * plane);
@@ -531,7 +535,8 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         if (active && !(abl & 1)) {
         const float *ys = smem + (long)buf_ * buf_floats;
         const float *xs = ys + CC * yplane;
-#pragma unroll 2
+        constexpr int UNR = COLS * PA <= 16 ? 4 : 2;  // small windows: more channels' LDS reads in flight
+#pragma unroll UNR
         for (int c = 0; c < CC; ++c) {
             const float *yrow = ys + c * yplane + (ry + dyi) * CW + COLS * g + dx_lo;
             const float *xrow = xs + c * xplane + ry * LF_SX + COLS * g;
@@ -684,20 +689,26 @@ static void launch_fused(int d, hipStream_t st, const void *cur, long c_sy, long
     float *ap = pooled, *bp = pooled + G.plane * C;
     {
         long n = G.plane * C;
+        // partial minima of several workgroups per tile meet by atomicMin: `out` starts from the "no match" value,
+        // set by the pooling pass when it has enough threads for it (always, for real shapes), else by a fill
+        const long n_out = (long)h * w * n_ids;
+        float *init = nullptr;
+        if (lf_ndg(d) > 1) {
+            if (n_out <= n) init = out;
+            else {
+                unsigned blocks = (unsigned)((n_out + 255) / 256);
+                if (blocks > 1024) blocks = 1024;
+                hipLaunchKernelGGL(fill_f32_kernel, dim3(blocks), dim3(256), 0, st, out, 1.0f, n_out);
+            }
+        }
         if (emb_dtype == MANET_EMB_BF16)
             hipLaunchKernelGGL(lf_pool_pad_kernel<unsigned short>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                (const unsigned short *)cur, c_sy, c_sx, c_sc, (const unsigned short *)prev, p_sy, p_sx, p_sc, C,
-                               G.hp, G.wp, d, G.HPAD, G.WS, ap, bp);
+                               G.hp, G.wp, d, G.HPAD, G.WS, ap, bp, init, n_out);
         else
             hipLaunchKernelGGL(lf_pool_pad_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                (const float *)cur, c_sy, c_sx, c_sc, (const float *)prev, p_sy, p_sx, p_sc, C, G.hp, G.wp, d,
-                               G.HPAD, G.WS, ap, bp);
-    }
-    if (lf_ndg(d) > 1) {  // partial minima meet by atomicMin: start from the "no match" value
-        long n = (long)h * w * n_ids;
-        unsigned blocks = (unsigned)((n + 255) / 256);
-        if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(fill_f32_kernel, dim3(blocks), dim3(256), 0, st, out, 1.0f, n);
+                               G.HPAD, G.WS, ap, bp, init, n_out);
     }
 #define MANET_LF_CASE(D_) case D_: launch_fused_d<D_>(st, ap, bp, G, labels, h, w, C, n_ids, out); break;
     switch (d) {

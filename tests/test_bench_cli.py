@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -22,6 +24,23 @@ def test_gpus_n_spawns_n_ranks_and_propagates_failure():
         assert r.returncode != 0
         assert text.count("bench.py needs an MI355X") == 2  # both ranks were started
         assert '"metric"' not in r.stdout
+
+
+@pytest.mark.gpu
+def test_two_rank_flow_on_one_gpu():
+    """the whole N > 1 flow of bench.py (self-spawned ranks, byte-slab bank exchange, sharded frames, max-over-ranks
+    timing) on the 1-GPU box: two ranks share the device, the collective goes over gloo.  K > 8 frames per rank
+    exercises the cycled-frame view of the exchange."""
+    env = dict(os.environ, MANET_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "1",
+                        "--cfg", "3", "--compute", "bf16"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 10 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["cpu_baseline"] is None
 
 
 def test_mismatched_world_size_is_an_error():
