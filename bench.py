@@ -304,10 +304,11 @@ def main():
         step(i, bank, bank_rows, bank_lab, halo)
     barrier()
     elapsed = time.perf_counter() - t0
-    ms = (ctypes.c_float * K)()
-    nrec = ctypes.c_int(0)
-    _lib.check(lib.manet_profile_end(ms, K, ctypes.byref(nrec)), "manet_profile_end")
+    ms, lms = (ctypes.c_float * K)(), (ctypes.c_float * K)()
+    nrec, nloc = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.manet_profile_end2(ms, K, ctypes.byref(nrec), lms, K, ctypes.byref(nloc)), "manet_profile_end2")
     kern_ms = float(np.mean([ms[i] for i in range(nrec.value)])) if nrec.value else float("nan")
+    local_ms = float(np.mean([lms[i] for i in range(nloc.value)])) if nloc.value else float("nan")
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if use_dist:
@@ -358,6 +359,12 @@ def main():
                                     "bf16x3": "global_match_bf16_kernel<7, true, 1, true>"}[args.compute],
                          "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": flops},
+            # the HBM-bound stage of the path: pooling pass + fused window/min kernel, HIP events over
+            # both launches; algorithmic bytes = both embeddings read once + labels + the [h,w,n_ids] result
+            "local_stage": (lambda b: {"bound": "hbm", "achieved": b / (local_ms * 1e-3) / 1e9, "peak": 8000.0,
+                                       "unit": "GB/s", "frac": b / (local_ms * 1e-3) / 8e12, "stage_ms": local_ms,
+                                       "algorithmic_bytes": b, "max_distance": LOCAL_D})(
+                2.0 * (2 if args.emb == "bf16" else 4) * C * H * W + 4.0 * H * W * (1 + N_IDS)),
         }
         if not args.no_cpu_baseline and world == 1:
             # the same frame once more on the GPU (fresh map, outside the timed region) for the parity figures

@@ -39,6 +39,7 @@ SIGNATURES = {
     "manet_profile_begin": (_i, [_i]),
     "manet_tune_set": (_i, [_i, _i]),
     "manet_profile_end": (_i, [ctypes.POINTER(ctypes.c_float), _i, _ip]),
+    "manet_profile_end2": (_i, [ctypes.POINTER(ctypes.c_float), _i, _ip, ctypes.POINTER(ctypes.c_float), _i, _ip]),
     "manet_correlation_forward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "manet_correlation_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "manet_bank_prepare_ex": (_i, [_vp, _i, _i64, _i64, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),

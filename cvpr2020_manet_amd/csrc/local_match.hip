@@ -396,7 +396,8 @@ __host__ __device__ constexpr int lf_lab_cols(int d) { return 2 * (LF_SX - 1) + 
 __host__ __device__ constexpr size_t lf_lds_bytes(int d)
 {
     size_t stage = 2 * (size_t)lf_cc(d) * (lf_yplane(d) + lf_xplane(d)) * 4;
-    size_t vol = (size_t)lf_nd(d) * (2 * d + 1) * lf_sy(d) * LF_SX * 4 + (((size_t)lf_lab_rows(d) * lf_lab_cols(d) + 15) & ~(size_t)15);
+    size_t vol = (size_t)lf_nd(d) * (2 * d + 1) * lf_sy(d) * LF_SX * 4 + (((size_t)lf_lab_rows(d) * lf_lab_cols(d) + 15) & ~(size_t)15) +
+                 (size_t)(2 * (lf_sy(d) - 1) + 4) * (2 * (LF_SX - 1) + 4) * NI * 4;  // + per-pixel partial minima
     return stage > vol ? stage : vol;
 }
 // padded pooled plane [HPAD][WS]: image pixel (py, px) at (d + py, d + px)
@@ -628,37 +629,46 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     }
     __syncthreads();
     const int nd_here = (P - dy0) < ND ? (P - dy0) : ND;  // window rows this workgroup really owns
-    for (int pix = tid; pix < ny * nx; pix += NT) {
-        const int py = pix / nx, pxx = pix - py * nx;
-        const int y = ya + py, x = xa + pxx;
-        const Bilin cy = bilin_coeff(y, hp, h), cx = bilin_coeff(x, wp, w);
-        const int r0 = (cy.i0 - a) * LF_SX, r1 = (cy.i1 - a) * LF_SX, q0 = cx.i0 - b0, q1 = cx.i1 - b0;
-        for (int o0 = 0; o0 < n_ids; o0 += NI) {
+    // work item = (pixel, window row): every lane busy whatever the tile's pixel count; the rows' partial minima
+    // meet in LDS (atomic min on the float bits: all candidates lie in [0, 1], start value 1.0 = "no match")
+    unsigned *M2 = (unsigned *)(L + (((size_t)lf_lab_rows(D) * lf_lab_cols(D) + 15) & ~(size_t)15));  // [npix][NI]
+    const int npix = ny * nx;
+    for (int o0 = 0; o0 < n_ids; o0 += NI) {
+        for (int e = tid; e < npix * NI; e += NT) M2[e] = 0x3f800000u;
+        __syncthreads();
+        for (int item = tid; item < ((abl & 2) ? 0 : npix * nd_here); item += NT) {
+            const int by = item / npix, pix = item - by * npix;
+            const int py = pix / nx, pxx = pix - py * nx;
+            const Bilin cy = bilin_coeff(ya + py, hp, h), cx = bilin_coeff(xa + pxx, wp, w);
+            const int r0 = (cy.i0 - a) * LF_SX, r1 = (cy.i1 - a) * LF_SX, q0 = cx.i0 - b0, q1 = cx.i1 - b0;
             float m[NI];
 #pragma unroll
             for (int k = 0; k < NI; ++k) m[k] = INFINITY;
-            for (int by = 0; by < ((abl & 2) ? 0 : nd_here); ++by) {
-                const unsigned char *lrow = L + (py + 2 * by) * lcols + pxx;
-                const float *vp = V + (by * P) * SY * LF_SX;
+            const unsigned char *lrow = L + (py + 2 * by) * lcols + pxx;
+            const float *vp = V + (by * P) * SY * LF_SX;
 #pragma unroll 5
-                for (int bx = 0; bx < P; ++bx) {
-                    const int lab = lrow[2 * bx];
-                    const float *pl = vp + bx * SY * LF_SX;
-                    const float v = cy.l0 * (cx.l0 * pl[r0 + q0] + cx.l1 * pl[r0 + q1]) +
-                                    cy.l1 * (cx.l0 * pl[r1 + q0] + cx.l1 * pl[r1 + q1]);
+            for (int bx = 0; bx < P; ++bx) {
+                const int lab = lrow[2 * bx];
+                const float *pl = vp + bx * SY * LF_SX;
+                const float v = cy.l0 * (cx.l0 * pl[r0 + q0] + cx.l1 * pl[r0 + q1]) +
+                                cy.l1 * (cx.l0 * pl[r1 + q0] + cx.l1 * pl[r1 + q1]);
 #pragma unroll
-                    for (int k = 0; k < NI; ++k) m[k] = fminf(m[k], (lab == o0 + k) ? v : 1.0f);
-                }
+                for (int k = 0; k < NI; ++k) m[k] = fminf(m[k], (lab == o0 + k) ? v : 1.0f);
             }
-            float *o = out + ((long)y * w + x) * n_ids + o0;
 #pragma unroll
-            for (int k = 0; k < NI; ++k) {
-                if (o0 + k < n_ids) {
-                    if (NDG == 1) o[k] = m[k];
-                    else atomicMin((unsigned *)(o + k), __float_as_uint(m[k]));  // values in [0, 1]: uint order = float order
-                }
-            }
+            for (int k = 0; k < NI; ++k)
+                if (o0 + k < n_ids) atomicMin(M2 + pix * NI + k, __float_as_uint(m[k]));
         }
+        __syncthreads();
+        for (int e = tid; e < npix * NI; e += NT) {
+            const int pix = e / NI, k = e - pix * NI;
+            if (o0 + k >= n_ids) continue;
+            const int py = pix / nx, pxx = pix - py * nx;
+            float *o = out + ((long)(ya + py) * w + (xa + pxx)) * n_ids + o0 + k;
+            if (NDG == 1) *o = __uint_as_float(M2[e]);
+            else atomicMin((unsigned *)o, M2[e]);  // several workgroups per tile: `out` was pre-set to 1.0
+        }
+        __syncthreads();
     }
 }
 
@@ -960,8 +970,10 @@ int manet_local_match_ex(const void *prev_v, int64_t p_sy, int64_t p_sx, int64_t
         return manet_set_error(MANET_E_WORKSPACE, "local workspace %zu < %zu bytes", workspace_bytes, L.total);
     hipStream_t st = (hipStream_t)stream;
     if (downsample && !manet_tune_get(MANET_TUNE_LOCAL_UNFUSED, 0)) {  // the live configuration: pooling pass + fused kernel
+        manet_profile_record(st, true, 1);
         launch_fused(max_distance, st, cur_v, (long)c_sy, (long)c_sx, (long)c_sc, prev_v, (long)p_sy, (long)p_sx, (long)p_sc,
                      emb_dtype, prev_labels, h, w, C, n_ids, out, (float *)((char *)workspace + L.off_ap));
+        manet_profile_record(st, false, 1);
         return manet_check_launch("manet_local_match_f32");
     }
     // IntVOS.py:370: local_pairwise_distances2(query_embedding, prev_frame_embedding)

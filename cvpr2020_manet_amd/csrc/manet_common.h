@@ -28,9 +28,9 @@ static inline int manet_check_launch(const char *what)
     return MANET_OK;
 }
 
-// opt-in launch timing of the dominant kernel (manet_profile_begin/_end, used by bench.py):
-// when enabled, the launcher of the global-match main kernel brackets it with two HIP events.
-void manet_profile_record(hipStream_t st, bool start);
+// opt-in launch timing (manet_profile_begin/_end, used by bench.py): when enabled, the launcher of the global-match
+// main kernel (channel 0) and the local-window stage (channel 1) are bracketed with two HIP events each.
+void manet_profile_record(hipStream_t st, bool start, int channel = 0);
 
 // tuning knobs (manet_tune_set; defaults are the shipped configuration)
 enum { MANET_TUNE_BLOCK_MAP = 0, MANET_TUNE_SPLITS = 1, MANET_TUNE_BF16_VARIANT = 2, MANET_TUNE_ABLATION = 3,

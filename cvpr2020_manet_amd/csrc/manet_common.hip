@@ -12,26 +12,29 @@ int manet_set_error(int code, const char *fmt, ...)
     return code;
 }
 
-// ---- opt-in profiling: HIP event pairs around the dominant kernel --------------------------------
+// ---- opt-in profiling: HIP event pairs around the dominant kernel (channel 0) and the local-window stage
+// (channel 1: pooling pass + fused kernel) -----------------------------------------------------------------
 #include <mutex>
 #include <vector>
 namespace {
 struct ProfState {
     std::mutex mu;
     bool enabled = false;
-    size_t used = 0;  // events used (2 per launch)
-    std::vector<hipEvent_t> ev;
+    size_t used[2] = {0, 0};  // events used per channel (2 per bracket)
+    std::vector<hipEvent_t> ev[2];
 } g_prof;
 }  // namespace
 
-void manet_profile_record(hipStream_t st, bool start)
+void manet_profile_record(hipStream_t st, bool start, int channel)
 {
     if (!g_prof.enabled) return;
     std::lock_guard<std::mutex> lk(g_prof.mu);
-    if (!g_prof.enabled) return;
-    if (start && g_prof.used + 2 > g_prof.ev.size()) return;  // pool exhausted: stop recording
-    if (!start && (g_prof.used & 1) == 0) return;              // no matching start
-    (void)hipEventRecord(g_prof.ev[g_prof.used++], st);
+    if (!g_prof.enabled || channel < 0 || channel > 1) return;
+    size_t &used = g_prof.used[channel];
+    std::vector<hipEvent_t> &ev = g_prof.ev[channel];
+    if (start && used + 2 > ev.size()) return;  // pool exhausted: stop recording
+    if (!start && (used & 1) == 0) return;       // no matching start
+    (void)hipEventRecord(ev[used++], st);
 }
 
 static int g_tune[MANET_TUNE_COUNT] = {0};
@@ -52,34 +55,51 @@ int manet_profile_begin(int max_launches)
 {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (max_launches <= 0) return manet_set_error(MANET_E_INVALID, "max_launches=%d", max_launches);
-    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
-    g_prof.ev.assign((size_t)max_launches * 2, nullptr);
-    for (auto &e : g_prof.ev)
-        if (hipEventCreate(&e) != hipSuccess) return manet_set_error(MANET_E_NODEVICE, "hipEventCreate failed");
-    g_prof.used = 0;
+    for (int c = 0; c < 2; ++c) {
+        for (hipEvent_t e : g_prof.ev[c]) (void)hipEventDestroy(e);
+        g_prof.ev[c].assign((size_t)max_launches * 2, nullptr);
+        for (auto &e : g_prof.ev[c])
+            if (hipEventCreate(&e) != hipSuccess) return manet_set_error(MANET_E_NODEVICE, "hipEventCreate failed");
+        g_prof.used[c] = 0;
+    }
     g_prof.enabled = true;
     return MANET_OK;
 }
 
-int manet_profile_end(float *ms_out, int capacity, int *n_launches)
+static int profile_collect(int c, float *ms_out, int capacity, int *n_launches)
 {
-    std::lock_guard<std::mutex> lk(g_prof.mu);
-    g_prof.enabled = false;
-    int n = (int)(g_prof.used / 2);
+    int n = (int)(g_prof.used[c] / 2);
     int wrote = 0;
     for (int i = 0; i < n && i < capacity; ++i) {
         float ms = 0.f;
-        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess ||
-            hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess)
+        if (hipEventSynchronize(g_prof.ev[c][2 * i + 1]) != hipSuccess ||
+            hipEventElapsedTime(&ms, g_prof.ev[c][2 * i], g_prof.ev[c][2 * i + 1]) != hipSuccess)
             return manet_set_error(MANET_E_LAUNCH, "event timing failed");
         if (ms_out) ms_out[i] = ms;
         ++wrote;
     }
     if (n_launches) *n_launches = wrote;
-    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
-    g_prof.ev.clear();
-    g_prof.used = 0;
     return MANET_OK;
+}
+
+int manet_profile_end2(float *ms_out, int capacity, int *n_launches, float *local_ms_out, int local_capacity,
+                       int *n_local)
+{
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.enabled = false;
+    int rc = profile_collect(0, ms_out, capacity, n_launches);
+    if (!rc) rc = profile_collect(1, local_ms_out, local_capacity, n_local);
+    for (int c = 0; c < 2; ++c) {
+        for (hipEvent_t e : g_prof.ev[c]) (void)hipEventDestroy(e);
+        g_prof.ev[c].clear();
+        g_prof.used[c] = 0;
+    }
+    return rc;
+}
+
+int manet_profile_end(float *ms_out, int capacity, int *n_launches)
+{
+    return manet_profile_end2(ms_out, capacity, n_launches, nullptr, 0, nullptr);
 }
 
 const char *manet_version(void) { return "manet_hip 0.1 (gfx950)"; }

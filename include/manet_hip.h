@@ -299,6 +299,10 @@ int manet_profile_begin(int max_launches);
  * No knob changes a workspace layout. */
 int manet_tune_set(int key, int value);
 int manet_profile_end(float *ms_out, int capacity, int *n_launches);
+/* the same, also returning the durations of the local-window stage (pooling pass + fused kernel of
+ * manet_local_match_*), the HBM-bound stage of the path */
+int manet_profile_end2(float *ms_out, int capacity, int *n_launches, float *local_ms_out,
+                       int local_capacity, int *n_local);
 
 #ifdef __cplusplus
 }
