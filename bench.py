@@ -369,7 +369,7 @@ def main():
                        else "none (1 GPU)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": {"f32": "global_match_f32_kernel<50, 1, false>",
+                         "kernel": {"f32": "global_match_f32_pipe_kernel<50>",
                                     "bf16": "global_match_bf16_wide_kernel<7, 0>",
                                     "bf16x3": "global_match_bf16_kernel<7, true, 1, true>"}[args.compute],
                          "kernel_ms": kern_ms,

@@ -707,6 +707,198 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Half-tile pipelined form of the fp32 kernel (k = 1, the shipped headline path).  Same decomposition, operand
+// images and arithmetic as global_match_f32_kernel<KS, 1> -- every accumulator is the same k-ascending fmaf chain,
+// d = fmaf(-2, mm, xs + ys): bit-identical results -- but the tile is computed as two phases of 100 MFMAs:
+//   phase A  rows  0-31 (c00, c01)   while the VALU reduces rows 32-63 of the PREVIOUS tile (c10, c11 still hold
+//                                     them; their |k|^2 were copied to 16 registers before the buffer was recycled)
+//   phase B  rows 32-63 (c10, c11)   while the VALU reduces rows 0-31 of this tile
+// r2 PMC of the un-pipelined kernel: matrix pipe 90 % busy -- the two co-resident workgroups of a CU run in
+// lockstep, so their ~1.3 k-cycle epilogues (add, fma, min per element) coincide and the pipe idles for exactly
+// that share of a 12.8 k-cycle tile.  Here a wave's MFMA stream never stops for an epilogue.
+// Staging by asm LDS-DMA (see lds_dma16): it frees the 28 staging VGPRs the 16 carried |k|^2 need, and removes
+// the ds_write pass; one raw s_barrier per tile.
+template <int KS>
+__global__ __launch_bounds__(256, 2) void global_match_f32_pipe_kernel(const char *__restrict__ qpack,
+                                                                       const char *__restrict__ bpack,
+                                                                       const int *__restrict__ meta, int n_ids,
+                                                                       int nQT, int S, long N_pad,
+                                                                       unsigned *__restrict__ keys, int block_map)
+{
+    constexpr int NG = (KS + 3) / 4;
+    constexpr size_t TILE_BYTES = bank_tile_bytes(NG);  // whole KiB
+    constexpr size_t QBLK_BYTES = query_block_bytes(NG);
+    constexpr int PIECES = (int)(TILE_BYTES / 1024);
+    constexpr int NW = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x TILE_BYTES
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+
+    const int b = blockIdx.x;
+    int qt, s;
+    if (block_map == 0) {
+        const int xcd = b & 7;
+        const int idx = b >> 3;
+        qt = idx % nQT;
+        s = xcd + 8 * (idx / nQT);
+    } else if (block_map == 1) {
+        qt = b % nQT;
+        s = b / nQT;
+    } else {
+        s = b % S;
+        qt = b / S;
+    }
+    const int T = meta[META_T];
+    const int t0 = (int)((long)s * T / S);
+    const int t1 = (int)((long)(s + 1) * T / S);
+    if (t0 >= t1) return;
+
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+    auto stage_dma = [&](int t, int slot) __attribute__((always_inline)) {
+        const char *g = bpack + (size_t)t * TILE_BYTES + (size_t)lane * 16;
+        const unsigned l = smem_base + (unsigned)slot * (unsigned)TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < (PIECES + NW - 1) / NW; ++i) {
+            const int pc = wave + i * NW;  // wave-uniform
+            if (pc < PIECES) lds_dma16(g + (size_t)pc * 1024, l + (unsigned)pc * 1024u);
+        }
+    };
+    stage_dma(t0, 0);
+
+    f32x4 q0[NG], q1[NG];
+    float xs0, xs1;
+    {
+        const char *qb0 = qpack + (size_t)(qt * (QT / QB) + wave * 2) * QBLK_BYTES;
+        const char *qb1 = qb0 + QBLK_BYTES;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            q0[g] = *(const f32x4 *)(qb0 + ((size_t)(g * 2 + h) * QB + l31) * 16);
+            q1[g] = *(const f32x4 *)(qb1 + ((size_t)(g * 2 + h) * QB + l31) * 16);
+        }
+        xs0 = *(const float *)(qb0 + (size_t)NG * 2 * QB * 16 + l31 * 4);
+        xs1 = *(const float *)(qb1 + (size_t)NG * 2 * QB * 16 + l31 * 4);
+    }
+    const long qbase = (long)qt * QT + wave * 64 + l31;
+    // the compiler waits for the query operand HERE (its counted vmcnt waits must not sink into the tile loop,
+    // where they would drain the LDS-DMA it does not know about)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) asm volatile("" : "+v"(q0[g]), "+v"(q1[g]));
+    asm volatile("" : "+v"(xs0), "+v"(xs1));
+
+    int o = 0;
+    while (meta[META_SEG + o + 1] <= t0) ++o;  // object owning tile t0
+    int seg_end = meta[META_SEG + o + 1];
+    float m0a, m0b, m1a, m1b;  // two running minima per query block: short dependency chains
+    m0a = m0b = m1a = m1b = MANET_WRONG_LABEL_PADDING_DISTANCE;
+    auto flush = [&](int obj) {
+        const float v0 = min3p(m0a, m0b, m0b), v1 = min3p(m1a, m1b, m1b);
+        const float a = min3p(v0, v0, __shfl_xor(v0, 32));
+        const float c = min3p(v1, v1, __shfl_xor(v1, 32));
+        if (h == 0) {
+            atomicMin(keys + (size_t)obj * N_pad + qbase, key_of(a));
+            atomicMin(keys + (size_t)obj * N_pad + qbase + 32, key_of(c));
+        }
+    };
+
+    // pending = rows 32-63 of the previous tile: still in c10 / c11, their |k|^2 in yp[]; "nothing pending" is
+    // expressed by values that cannot win (c = 0, |k|^2 = 1e20 -> d = 1e20)
+    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+    float yp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yp[r] = MANET_WRONG_LABEL_PADDING_DISTANCE;
+    // the reference's d = (xs + ys) - 2 mm with its two roundings (IntVOS.py:39), then the running minimum
+#define MANET_REDUCE(ca_, cb_, y_, r_)                                                             \
+    {                                                                                              \
+        const float da_ = fmaf(-2.0f, ca_[r_], xs0 + (y_));                                        \
+        const float db_ = fmaf(-2.0f, cb_[r_], xs1 + (y_));                                        \
+        if ((r_) & 1) {                                                                            \
+            m0b = min3p(m0b, da_, da_);                                                            \
+            m1b = min3p(m1b, db_, db_);                                                            \
+        } else {                                                                                   \
+            m0a = min3p(m0a, da_, da_);                                                            \
+            m1a = min3p(m1a, db_, db_);                                                            \
+        }                                                                                          \
+    }
+    auto settle = [&]() __attribute__((always_inline)) {  // reduce what is pending, serially (object boundary, end)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) MANET_REDUCE(c10, c11, yp[r], r);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yp[r] = MANET_WRONG_LABEL_PADDING_DISTANCE;
+        c10 = f32x16{0};
+        c11 = f32x16{0};
+    };
+
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        // this wave's pieces of tile t have landed (issued one tile ago); the barrier publishes the tile and tells
+        // us that every wave is done with the other buffer (tile t-1: fragments consumed, |k|^2 copied to yp)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < t1) stage_dma(t + 1, buf ^ 1);  // in flight during this tile's 200 MFMAs
+        if (t >= seg_end) {  // wave-uniform: crossed into the next object's rows
+            settle();
+            flush(o);
+            m0a = m0b = m1a = m1b = MANET_WRONG_LABEL_PADDING_DISTANCE;
+            do { ++o; seg_end = meta[META_SEG + o + 1]; } while (t >= seg_end);
+        }
+        const char *tb = smem + (size_t)buf * TILE_BYTES;
+        const f32x4 *A = (const f32x4 *)tb;
+        const float *ysl = (const float *)(tb + (size_t)NG * 2 * BT * 16);
+        // ---- phase A: rows 0-31 of tile t on the matrix pipe, rows 32-63 of tile t-1 on the VALU
+        c00 = f32x16{0};
+        c01 = f32x16{0};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const f32x4 a0 = A[(g * 2 + h) * BT + l31];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (g * 4 + j < KS) {  // compile-time: k-steps beyond C are all-zero, skip them
+                    c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], q0[g][j], c00, 0, 0, 0);
+                    c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], q1[g][j], c01, 0, 0, 0);
+                }
+            }
+            // the 16 pending registers spread over the NG fragment groups
+#pragma unroll
+            for (int r = (g * 16) / NG; r < ((g + 1) * 16) / NG; ++r) MANET_REDUCE(c10, c11, yp[r], r);
+        }
+        // |k|^2 of rows 32-63 of THIS tile, for the next tile's phase A (register r = row 32 + (r&3) + 8(r>>2) + 4h)
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            const f32x4 y1 = *(const f32x4 *)(ysl + 32 + 8 * tq + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yp[4 * tq + i] = y1[i];
+        }
+        // ---- phase B: rows 32-63 of tile t on the matrix pipe, rows 0-31 of tile t on the VALU
+        c10 = f32x16{0};
+        c11 = f32x16{0};
+        f32x4 y0v[4];
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) y0v[tq] = *(const f32x4 *)(ysl + 8 * tq + 4 * h);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const f32x4 a1 = A[(g * 2 + h) * BT + 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (g * 4 + j < KS) {
+                    c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], q0[g][j], c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], q1[g][j], c11, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = (g * 16) / NG; r < ((g + 1) * 16) / NG; ++r) MANET_REDUCE(c00, c01, y0v[r >> 2][r & 3], r);
+        }
+    }
+    settle();
+#undef MANET_REDUCE
+    flush(o);
+}
+
+// ---------------------------------------------------------------------------------------------
 // main kernel, bf16 operands (MANET_COMPUTE_BF16 / _BF16X3): one workgroup = 512 queries x one bank
 // split, 8 waves.  Same decomposition as the f32 kernel (swapped operands, object-pure 64-row tiles,
 // lane-local running min, atomicMin across splits); the contraction is v_mfma_f32_32x32x16_bf16 with fp32
@@ -1481,6 +1673,19 @@ void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int 
     manet_profile_record(st, false);
 }
 
+template <int KS>
+void launch_main_f32_pipe(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S, long N_pad,
+                          unsigned *keys, hipStream_t st)
+{
+    size_t lds = 2 * bank_tile_bytes((KS + 3) / 4);
+    (void)hipFuncSetAttribute((const void *)global_match_f32_pipe_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    manet_profile_record(st, true);
+    hipLaunchKernelGGL((global_match_f32_pipe_kernel<KS>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack, bpack, meta,
+                       n_ids, nQT, S, N_pad, keys, manet_tune_get(MANET_TUNE_BLOCK_MAP, 0));
+    manet_profile_record(st, false);
+}
+
 template <int KSB, bool X3, int TPS, bool DMA>
 void launch_main_bf16_v(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S, long N_pad,
                         unsigned *keys, int young_prio, hipStream_t st)
@@ -1718,15 +1923,18 @@ int manet_global_match_prepared_ex(const void *query, int emb_dtype, int64_t q_s
         }
 #undef MANET_GB_CASE
     } else {
+        const bool pipe = !manet_tune_get(MANET_TUNE_F32_UNPIPED, 0);  // tuning: 1 = the un-pipelined k = 1 kernel
 #define MANET_GM_CASE(KS_)                                                                                    \
     case KS_:                                                                                                 \
-        if (k_nn == 1) launch_main_f32<KS_, 1>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st); \
+        if (k_nn == 1 && pipe) launch_main_f32_pipe<KS_>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); \
+        else if (k_nn == 1) launch_main_f32<KS_, 1>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st); \
         else launch_main_f32<KS_, MANET_MAX_KNN>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st); \
         break;
     switch (pick_ks(C)) {
         MANET_GM_CASE(16) MANET_GM_CASE(50) MANET_GM_CASE(52)
     default:
-        if (k_nn == 1) launch_main_f32<64, 1>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st);
+        if (k_nn == 1 && pipe) launch_main_f32_pipe<64>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st);
+        else if (k_nn == 1) launch_main_f32<64, 1>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st);
         else launch_main_f32<64, MANET_MAX_KNN>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st);
         break;
     }
