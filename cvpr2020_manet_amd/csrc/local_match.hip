@@ -393,11 +393,17 @@ __host__ __device__ constexpr int lf_cc(int d)
 }
 __host__ __device__ constexpr int lf_lab_rows(int d) { return 2 * (lf_sy(d) - 1) + 4 + 2 * (lf_nd(d) - 1); }
 __host__ __device__ constexpr int lf_lab_cols(int d) { return 2 * (LF_SX - 1) + 4 + 4 * d; }
+// phase 2 volume: [dy][cell of S][dx], dx contiguous, cell stride an ODD number of float4 -- a pixel's four taps are
+// ds_read_b128 of 4 window columns each, and the 16 cells of a row of S land on 64 distinct banks
+__host__ __device__ constexpr int lf_vs(int d) { return 4 * (((2 * d + 1 + 3) / 4) | 1); }
+__host__ __device__ constexpr int lf_npix(int d) { return (2 * (lf_sy(d) - 1) + 4) * (2 * (LF_SX - 1) + 4); }  // pixels of a tile, upper bound
+constexpr int LF_NIP = 8;  // object ids per pass of the per-pixel phase
 __host__ __device__ constexpr size_t lf_lds_bytes(int d)
 {
     size_t stage = 2 * (size_t)lf_cc(d) * (lf_yplane(d) + lf_xplane(d)) * 4;
-    size_t vol = (size_t)lf_nd(d) * (2 * d + 1) * lf_sy(d) * LF_SX * 4 + (((size_t)lf_lab_rows(d) * lf_lab_cols(d) + 15) & ~(size_t)15) +
-                 (size_t)(2 * (lf_sy(d) - 1) + 4) * (2 * (LF_SX - 1) + 4) * NI * 4;  // + per-pixel partial minima
+    size_t vol = (size_t)lf_nd(d) * lf_sy(d) * LF_SX * lf_vs(d) * 4 + (((size_t)lf_lab_rows(d) * lf_lab_cols(d) + 15) & ~(size_t)15) +
+                 (size_t)lf_npix(d) * (LF_NIP + 1) * 4 +                        // per-(id, pixel) minima + the "no id" row
+                 (size_t)(2 * (lf_sy(d) - 1) + 4 + 2 * (LF_SX - 1) + 4) * 16;  // bilinear row / column tables
     return stage > vol ? stage : vol;
 }
 // padded pooled plane [HPAD][WS]: image pixel (py, px) at (d + py, d + px)
@@ -594,15 +600,25 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     __syncthreads();
 
     // ---- phase 2: normalised volume of S and the labels around the tile into LDS -----------------
-    float *V = smem;                                           // [ND][P][SY][16]
-    unsigned char *L = (unsigned char *)(V + ND * P * SY * LF_SX);  // [lab_rows][lab_cols], 255 = matches no id
+    constexpr int VS = lf_vs(D), NPS = lf_npix(D);
+    float *V = smem;                                                 // [ND][SY * 16][VS]
+    unsigned char *L = (unsigned char *)(V + ND * SY * LF_SX * VS);  // [lab_rows][lab_cols], 255 = matches no id
     if (active) {
+        float *vp0 = V + ((dyi * SY + ry) * LF_SX + COLS * g) * VS + dx_lo;
 #pragma unroll
-        for (int dx = 0; dx < PA; ++dx) {
-            if (dx < ndx) {
-                float *vp = V + ((dyi * P + dx_lo + dx) * SY + ry) * LF_SX + COLS * g;
+        for (int j = 0; j < COLS; ++j) {
 #pragma unroll
-                for (int j = 0; j < COLS; ++j) vp[j] = manet_normalize_dist(acc[j][dx]);
+            for (int d4 = 0; d4 < PA; d4 += 4) {
+                if (LF_PH % 4 == 0 && d4 + 3 < PA && d4 + 3 < ndx) {
+                    f32x4 t;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t[i] = manet_normalize_dist(acc[j][d4 + i]);
+                    *(f32x4 *)(vp0 + j * VS + d4) = t;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (d4 + i < PA && d4 + i < ndx) vp0[j * VS + d4 + i] = manet_normalize_dist(acc[j][d4 + i]);
+                }
             }
         }
     }
@@ -627,46 +643,63 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         int lab = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? labels[(long)yy * w + xx] : 0;
         L[r * lcols + c] = (lab >= 0 && lab < MANET_MAX_IDS) ? (unsigned char)lab : (unsigned char)255;
     }
-    __syncthreads();
+    // per-(id, pixel) minima [LF_NIP + 1][NPS] (row LF_NIP collects the candidates whose label is not an id of this
+    // pass), then the separable bilinear tables: tap offsets into V and the two weights, per pixel row / column
+    unsigned *M2 = (unsigned *)(L + (((size_t)lf_lab_rows(D) * lf_lab_cols(D) + 15) & ~(size_t)15));
+    struct Tap {
+        int o0, o1;
+        float l0, l1;
+    };
+    Tap *RT = (Tap *)(M2 + (LF_NIP + 1) * NPS), *CT = RT + (2 * TY + 4);
+    if (tid < ny) {
+        const Bilin cy = bilin_coeff(ya + tid, hp, h);
+        RT[tid] = Tap{(cy.i0 - a) * LF_SX * VS, (cy.i1 - a) * LF_SX * VS, cy.l0, cy.l1};
+    } else if (tid >= 64 && tid < 64 + nx) {
+        const Bilin cx = bilin_coeff(xa + tid - 64, wp, w);
+        CT[tid - 64] = Tap{(cx.i0 - b0) * VS, (cx.i1 - b0) * VS, cx.l0, cx.l1};
+    }
     const int nd_here = (P - dy0) < ND ? (P - dy0) : ND;  // window rows this workgroup really owns
-    // work item = (pixel, window row): every lane busy whatever the tile's pixel count; the rows' partial minima
-    // meet in LDS (atomic min on the float bits: all candidates lie in [0, 1], start value 1.0 = "no match")
-    unsigned *M2 = (unsigned *)(L + (((size_t)lf_lab_rows(D) * lf_lab_cols(D) + 15) & ~(size_t)15));  // [npix][NI]
+    // work item = (pixel, window row): every lane busy whatever the tile's pixel count.  The item walks its window
+    // row four columns at a time (four b128 taps), and every candidate goes to its (id, pixel) slot by an LDS
+    // atomic min on the float bits -- all candidates lie in [0, 1], start value 1.0 = "no match" (IntVOS.py:429-432:
+    // where(label == id, dist, 1) then min) -- instead of a compare/select/min per id in registers.
     const int npix = ny * nx;
-    for (int o0 = 0; o0 < n_ids; o0 += NI) {
-        for (int e = tid; e < npix * NI; e += NT) M2[e] = 0x3f800000u;
+    const float inv_npix = 1.0f / (float)npix, inv_nx = 1.0f / (float)nx;  // exact quotients below: see DESIGN 3.4
+    for (int o0 = 0; o0 < n_ids; o0 += LF_NIP) {
+        for (int e = tid; e < (LF_NIP + 1) * NPS; e += NT) M2[e] = 0x3f800000u;
         __syncthreads();
         for (int item = tid; item < ((abl & 2) ? 0 : npix * nd_here); item += NT) {
-            const int by = item / npix, pix = item - by * npix;
-            const int py = pix / nx, pxx = pix - py * nx;
-            const Bilin cy = bilin_coeff(ya + py, hp, h), cx = bilin_coeff(xa + pxx, wp, w);
-            const int r0 = (cy.i0 - a) * LF_SX, r1 = (cy.i1 - a) * LF_SX, q0 = cx.i0 - b0, q1 = cx.i1 - b0;
-            float m[NI];
-#pragma unroll
-            for (int k = 0; k < NI; ++k) m[k] = INFINITY;
+            const int by = (int)(((float)item + 0.5f) * inv_npix), pix = item - by * npix;
+            const int py = (int)(((float)pix + 0.5f) * inv_nx), pxx = pix - py * nx;
+            const Tap r = RT[py], c = CT[pxx];
+            const float *vb = V + by * (SY * LF_SX * VS);
+            const float *p00 = vb + r.o0 + c.o0, *p01 = vb + r.o0 + c.o1, *p10 = vb + r.o1 + c.o0, *p11 = vb + r.o1 + c.o1;
             const unsigned char *lrow = L + (py + 2 * by) * lcols + pxx;
-            const float *vp = V + (by * P) * SY * LF_SX;
-#pragma unroll 5
-            for (int bx = 0; bx < P; ++bx) {
-                const int lab = lrow[2 * bx];
-                const float *pl = vp + bx * SY * LF_SX;
-                const float v = cy.l0 * (cx.l0 * pl[r0 + q0] + cx.l1 * pl[r0 + q1]) +
-                                cy.l1 * (cx.l0 * pl[r1 + q0] + cx.l1 * pl[r1 + q1]);
+            unsigned *mrow = M2 + pix;
 #pragma unroll
-                for (int k = 0; k < NI; ++k) m[k] = fminf(m[k], (lab == o0 + k) ? v : 1.0f);
+            for (int q = 0; q < (P + 3) / 4; ++q) {
+                const f32x4 t00 = *(const f32x4 *)(p00 + 4 * q), t01 = *(const f32x4 *)(p01 + 4 * q);
+                const f32x4 t10 = *(const f32x4 *)(p10 + 4 * q), t11 = *(const f32x4 *)(p11 + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int bx = 4 * q + i;
+                    if (bx < P) {
+                        const float v = r.l0 * (c.l0 * t00[i] + c.l1 * t01[i]) + r.l1 * (c.l0 * t10[i] + c.l1 * t11[i]);
+                        unsigned idx = (unsigned)lrow[2 * bx] - (unsigned)o0;
+                        idx = idx < (unsigned)LF_NIP ? idx : (unsigned)LF_NIP;
+                        atomicMin(mrow + idx * NPS, __float_as_uint(v));
+                    }
+                }
             }
-#pragma unroll
-            for (int k = 0; k < NI; ++k)
-                if (o0 + k < n_ids) atomicMin(M2 + pix * NI + k, __float_as_uint(m[k]));
         }
         __syncthreads();
-        for (int e = tid; e < npix * NI; e += NT) {
-            const int pix = e / NI, k = e - pix * NI;
-            if (o0 + k >= n_ids) continue;
+        const int nk = (n_ids - o0) < LF_NIP ? (n_ids - o0) : LF_NIP;
+        for (int e = tid; e < npix * nk; e += NT) {
+            const int pix = e / nk, k = e - pix * nk;
             const int py = pix / nx, pxx = pix - py * nx;
             float *o = out + ((long)(ya + py) * w + (xa + pxx)) * n_ids + o0 + k;
-            if (NDG == 1) *o = __uint_as_float(M2[e]);
-            else atomicMin((unsigned *)o, M2[e]);  // several workgroups per tile: `out` was pre-set to 1.0
+            if (NDG == 1) *o = __uint_as_float(M2[k * NPS + pix]);
+            else atomicMin((unsigned *)o, M2[k * NPS + pix]);  // several workgroups per tile: `out` was pre-set to 1.0
         }
         __syncthreads();
     }
