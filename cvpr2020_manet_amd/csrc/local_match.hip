@@ -18,6 +18,7 @@
 //                       waves split the window rows, partial minima meet in LDS
 //   local_upsample_kernel  only for the stand-alone local_pairwise_distances2 API
 #include "manet_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(256, 2) void local_dist_kernel(const float *__restr
             const int l = dy * P + dx;
             if (pooled_out) {
                 float *o = out + ((long)l * H + py) * W + pxa;
-                if (pxa < W) o[0] = manet_normalize_dist(acc0[dx]);
-                if (pxa + 1 < W) o[1] = manet_normalize_dist(acc1[dx]);
+                if (pxa < W) o[0] = manet_normalize_dist_local(acc0[dx]);
+                if (pxa + 1 < W) o[1] = manet_normalize_dist_local(acc1[dx]);
             } else {
                 if (pxa < W) out[((long)py * W + pxa) * (P * P) + l] = acc0[dx];
                 if (pxa + 1 < W) out[((long)py * W + pxa + 1) * (P * P) + l] = acc1[dx];
@@ -255,6 +256,22 @@ __device__ __forceinline__ Bilin bilin_coeff(int dst, int in_size, int out_size)
     b.l1 = src - (float)a;
     b.l0 = 1.0f - b.l1;
     return b;
+}
+// smallest dst in [0, out_size] whose i0 is >= target (i0 is monotone in dst): an estimate from the inverse map,
+// settled with the forward expression itself -- a couple of evaluations instead of a scan over the tile
+__device__ __forceinline__ int bilin_first(int target, int in_size, int out_size)
+{
+    if (target <= 0) return 0;
+    if (target > in_size - 1) return out_size;
+    const float scale = (out_size > 1) ? (float)(in_size - 1) / (float)(out_size - 1) : 0.0f;  // as bilin_coeff
+    if (scale == 0.0f) return out_size;
+    // i0(dst) of bilin_coeff is min((int)(scale * dst), in_size - 1); target <= in_size - 1 here, so the clamp never
+    // decides the comparison
+    int y = (int)((float)target * (1.0f / scale));
+    y = y < 0 ? 0 : (y > out_size ? out_size : y);
+    while (y > 0 && (int)(scale * (float)(y - 1)) >= target) --y;
+    while (y < out_size && (int)(scale * (float)y) < target) ++y;
+    return y;
 }
 __device__ __forceinline__ float bilin_sample(const float *__restrict__ pl, int wp, const Bilin &by,
                                               const Bilin &bx)
@@ -378,7 +395,10 @@ __host__ __device__ constexpr int lf_sy(int d) { return lf_slots(d) / lf_nd(d) >
 constexpr int LF_SX = 16;  // columns of S
 __host__ __device__ constexpr int lf_cw(int d)  // halo row stride (every thread reads whole vectors: room for the over-read)
 {
-    return lf_cols(d) == 4 && lf_dxs(d) == 2 ? 40 : ((LF_SX + 2 * d + 3) & ~3);
+    // COLS = 4 halves: 40 columns are needed; 48 = 16 (mod 64 banks) makes the four (row, dy) slots of a b128 lane
+    // group land on disjoint banks (r2 PMC at stride 40: SQ_LDS_BANK_CONFLICT = 40 % of SQ_LDS_IDX_ACTIVE; a
+    // window read cost 10 LDS cycles instead of 4)
+    return lf_cols(d) == 4 && lf_dxs(d) == 2 ? 48 : ((LF_SX + 2 * d + 3) & ~3);
 }
 __host__ __device__ constexpr int lf_yr(int d) { return lf_sy(d) + lf_nd(d) - 1; }                // halo rows
 __host__ __device__ constexpr int lf_yplane(int d) { return lf_yr(d) * lf_cw(d); }
@@ -433,11 +453,17 @@ template <typename SRC>  // float, or bf16 as raw 16-bit words (the producer's s
 __global__ void lf_pool_pad_kernel(const SRC *__restrict__ a, long a_sy, long a_sx, long a_sc,
                                    const SRC *__restrict__ b, long b_sy, long b_sx, long b_sc, int C, int hp, int wp,
                                    int d, int HPAD, int WS, float *__restrict__ ap, float *__restrict__ bp,
-                                   float *__restrict__ out_init, long n_out)
+                                   float *__restrict__ out_init, long n_out, int *__restrict__ tab, int TY, int TX,
+                                   int nty, int ntx, int h, int w)
 {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long plane = (long)HPAD * WS;
     if (out_init && i < n_out) out_init[i] = 1.0f;  // the launcher checked n_out <= plane * C
+    // tile table of the fused kernel: tile row t owns the full-resolution rows [tab[t], tab[t+1]) (those whose upper
+    // bilinear source row i0 lies in [t TY, (t+1) TY)), tile column t the columns [tab[nty+1+t], tab[nty+2+t]).
+    // Computed here once instead of by every workgroup (four divisions and two scans on its critical path).
+    if (i <= nty) tab[i] = bilin_first((int)i * TY, hp, h);
+    else if (i <= nty + 1 + ntx) tab[i] = bilin_first((int)(i - nty - 1) * TX, wp, w);
     if (i >= plane * C) return;
     int c = (int)(i / plane);
     int rem = (int)(i - (long)c * plane);
@@ -454,11 +480,21 @@ __global__ void lf_pool_pad_kernel(const SRC *__restrict__ a, long a_sy, long a_
     bp[i] = vb;
 }
 
+// Phase timeline of the fused kernel (development aid, off by default): build with
+// `make -C cvpr2020_manet_amd/csrc EXTRA=-DMANET_LF_TIMELINE`, run tools/local_timeline.py on the GPU box.
+#ifdef MANET_LF_TIMELINE
+__device__ unsigned long long lf_dbg[8192 * 8];
+extern "C" int manet_dbg_read(unsigned long long *host, size_t n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(lf_dbg), n * 8); }
+#define LF_T(k) if (threadIdx.x == 0) lf_dbg[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64();
+#else
+#define LF_T(k)
+#endif
 template <int D>
 __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__restrict__ curp,
                                                                const float *__restrict__ prevp, int WS, long PS,
                                                                const int *__restrict__ labels, int h, int w, int C,
-                                                               int n_ids, float *__restrict__ out, int abl)
+                                                               int n_ids, float *__restrict__ out,
+                                                               const int *__restrict__ tab, int abl)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int P = 2 * D + 1, NT = lf_nt(D), ND = lf_nd(D), NDG = lf_ndg(D), SY = lf_sy(D), TY = SY - 1;
@@ -470,6 +506,7 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     constexpr int KY = (CC * NVY + NT - 1) / NT, KX = (CC * NVX + NT - 1) / NT;  // float4 per thread per stage
     float *smem = (float *)smem_raw;
     const int tid = threadIdx.x;
+    LF_T(0)
     const int hp = h / 2, wp = w / 2;
     const int a = blockIdx.y * TY, b0 = blockIdx.x * TX;  // pooled origin of S
     const int dy0 = blockIdx.z * ND;                       // first window row of this workgroup
@@ -496,9 +533,8 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         xgo[k] = (D + a + r) * WS + D + b0 + 4 * q;
         xlo[k] = CC * yplane + c * xplane + r * LF_SX + 4 * q;
     }
-    // two register sets: a stage's loads are issued TWO compute phases before its LDS store (one phase is shorter
-    // than the L2 / Infinity-Cache latency of the pooled planes, which the previous launch has only just written)
-    f32x4 ryA[KY], rxA[KX], ryB[KY], rxB[KX];
+    // a stage's global loads are issued one full phase (arithmetic of a stage) before its LDS stores
+    f32x4 ryA[KY], rxA[KX];
     auto load_regs = [&](f32x4 (&ry_)[KY], f32x4 (&rx_)[KX], int c0) __attribute__((always_inline)) {  // unconditional, clamped
 #pragma unroll
         for (int k = 0; k < KY; ++k) {
@@ -524,82 +560,149 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
             if (xch[k] >= 0) *(f32x4 *)(st + xlo[k]) = (c0 + xch[k] < C) ? rx_[k] : zero;
     };
 
+    // lane -> (column group, slot): the window half is the thread index's TOP bit, so a wave's lanes read the same half
+    // (with lf_cw's row stride that keeps every b128 lane group of the window reads conflict-free)
     const int g = tid % NG;
-    const int xh = (tid / NG) % DXS;                 // which half of the window columns
-    const int dyi = (tid / (NG * DXS)) % ND;
-    const int ry = (tid / (NG * DXS)) / ND;
+    constexpr bool XH_TOP = COLS == 4;  // (b64 reads of the COLS = 2 kernels: 32-lane groups, the interleaved order measured better)
+    const int xh = XH_TOP ? tid / (NT / DXS) : (tid / NG) % DXS;  // which half of the window columns
+    const int slot = XH_TOP ? (tid % (NT / DXS)) / NG : tid / (NG * DXS);
+    const int dyi = slot % ND;
+    const int ry = slot / ND;
     const bool active = ry < SY;
     const int dx_lo = xh * LF_PH;
     const int ndx = (xh == DXS - 1) ? P - dx_lo : LF_PH;  // window columns this thread really owns (<= PA)
     constexpr int WN = (COLS + PA - 1 + COLS - 1) / COLS * COLS;  // window floats read per channel (whole vectors)
-    float acc[COLS][PA];  // sums beyond ndx accumulate whatever follows in the row and are never stored
+    // Running sums, held as PAIRS of neighbouring window positions k = dx + j (k even first): one v_pk_add_f32 and one
+    // v_pk_fma_f32 do two (x - y)^2 steps.  A wave issues a VALU instruction every ~5 cycles whatever its width
+    // (tools/ubench/valu_rate.hip: v_fma_f32 5.3, v_pk_fma_f32 5.5 ticks per instruction per wave, flat from 1 to 4 waves
+    // per SIMD), so at the 2 waves per SIMD this kernel runs at, packed math is twice the arithmetic per issue slot.
+    // The packed operands must be even-aligned register pairs, which window pairs starting at even k are (they come out
+    // of b64 / b128 LDS reads); column j's range k = j .. j+PA-1 is covered by the aligned pairs around it, so up to
+    // one lane per end accumulates a neighbour that is never stored.  Every stored sum is the same ascending chain of
+    // fma(d, d, acc), d = x - y, as local_dist_kernel's and the oracle's.
+    constexpr int NP = (PA + 2) / 2;  // pairs per column
+    f32x2 accp[COLS][NP];             // sum (j, dx) = accp[j][(dx + (j & 1)) >> 1][(dx + j) & 1]
+#define LF_ACC(j_, dx_) accp[j_][((dx_) + ((j_) & 1)) >> 1][((dx_) + (j_)) & 1]
 #pragma unroll
     for (int j = 0; j < COLS; ++j)
 #pragma unroll
-        for (int i = 0; i < PA; ++i) acc[j][i] = 0.0f;
+        for (int i = 0; i < NP; ++i) accp[j][i] = f32x2{0.0f, 0.0f};
 
+    // One channel's operands: the thread's COLS current-frame values and its WN-wide slice of the previous frame's row
+    struct Chan {
+        f32x2 win[WN / 2];
+        float xv[COLS];
+    };
     auto compute = [&](int buf_) __attribute__((always_inline)) {
         if (active && !(abl & 1)) {
-        const float *ys = smem + (long)buf_ * buf_floats;
-        const float *xs = ys + CC * yplane;
-        constexpr int UNR = COLS * PA <= 16 ? 4 : 2;  // small windows: more channels' LDS reads in flight
-#pragma unroll UNR
-        for (int c = 0; c < CC; ++c) {
-            const float *yrow = ys + c * yplane + (ry + dyi) * CW + COLS * g + dx_lo;
-            const float *xrow = xs + c * xplane + ry * LF_SX + COLS * g;
-            float win[WN], xv[COLS];
+        const float *ys = smem + (long)buf_ * buf_floats + (ry + dyi) * CW + COLS * g + dx_lo;
+        const float *xs = smem + (long)buf_ * buf_floats + CC * yplane + ry * LF_SX + COLS * g;
+        auto fetch = [&](Chan &W, int c) __attribute__((always_inline)) {
+            const float *yrow = ys + c * yplane;
+            const float *xrow = xs + c * xplane;
             if constexpr (COLS == 2) {
-                const float2 t = *(const float2 *)xrow;
-                xv[0] = t.x;
-                xv[1] = t.y;
+                const f32x2 t = *(const f32x2 *)xrow;
+                W.xv[0] = t[0];
+                W.xv[1] = t[1];
 #pragma unroll
-                for (int i = 0; i < WN / 2; ++i) {
-                    const float2 u = *(const float2 *)(yrow + 2 * i);
-                    win[2 * i] = u.x;
-                    win[2 * i + 1] = u.y;
-                }
+                for (int i = 0; i < WN / 2; ++i) W.win[i] = *(const f32x2 *)(yrow + 2 * i);
             } else {
                 const f32x4 t = *(const f32x4 *)xrow;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xv[j] = t[j];
+                for (int j = 0; j < 4; ++j) W.xv[j] = t[j];
 #pragma unroll
                 for (int i = 0; i < WN / 4; ++i) {
                     const f32x4 u = *(const f32x4 *)(yrow + 4 * i);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) win[4 * i + j] = u[j];
+                    W.win[2 * i] = f32x2{u[0], u[1]};
+                    W.win[2 * i + 1] = f32x2{u[2], u[3]};
                 }
             }
+        };
+        auto fma_chan = [&](const Chan &U) __attribute__((always_inline)) {
 #pragma unroll
-            for (int dx = 0; dx < PA; ++dx) {
+            for (int j = 0; j < COLS; ++j) {
+                const f32x2 xx = {U.xv[j], U.xv[j]};
 #pragma unroll
-                for (int j = 0; j < COLS; ++j) {
-                    const float dd = xv[j] - win[dx + j];
-                    acc[j][dx] = fmaf(dd, dd, acc[j][dx]);
+                for (int i = 0; i < NP; ++i) {
+                    const int kp = (j >> 1) + i;  // window pair (2 kp, 2 kp + 1)
+                    if (2 * kp <= j + PA - 1) {
+                        const f32x2 dd = xx - U.win[kp];
+                        accp[j][i] = __builtin_elementwise_fma(dd, dd, accp[j][i]);
+                    }
                 }
+            }
+        };
+        if constexpr (COLS == 2 || true) {
+            // the channel loop rotated by hand: channel c+1's LDS reads are issued before channel c's arithmetic
+            Chan W0, W1;  // loop-carried: the loop stays rolled, or the compiler hoists every channel's reads and spills
+            fetch(W0, 0);
+            int c = 0;
+#pragma unroll 1
+            for (; c + 2 < CC; c += 2) {  // branch-free body (a conditional fetch costs a register shuffle per trip)
+                fetch(W1, c + 1);
+                fma_chan(W0);
+                fetch(W0, c + 2);
+                fma_chan(W1);
+            }
+            if (CC % 2 == 0) {
+                fetch(W1, c + 1);
+                fma_chan(W0);
+                fma_chan(W1);
+            } else {
+                fma_chan(W0);
+            }
+        } else {  // wide windows: the arithmetic of one channel covers the reads of the next in an unrolled pair
+#pragma unroll 2
+            for (int c = 0; c < CC; ++c) {
+                Chan W;
+                fetch(W, c);
+                fma_chan(W);
             }
         }
     }
     };
     load_regs(ryA, rxA, 0);
     store_lds(ryA, rxA, 0, 0);
-    if (CC < C) load_regs(ryB, rxB, CC);
+    if (CC < C) load_regs(ryA, rxA, CC);
     __syncthreads();
-    for (int c0 = 0; c0 < C; c0 += 2 * CC) {
-        // stage c0 is in LDS buffer 0, set B holds stage c0 + CC
-        if (c0 + 2 * CC < C) load_regs(ryA, rxA, c0 + 2 * CC);
-        compute(0);
-        if (c0 + CC >= C) break;
-        store_lds(ryB, rxB, 1, c0 + CC);
-        __syncthreads();
-        // stage c0 + CC is in LDS buffer 1, set A holds stage c0 + 2 CC
-        if (c0 + 3 * CC < C) load_regs(ryB, rxB, c0 + 3 * CC);
-        compute(1);
-        if (c0 + 2 * CC < C) store_lds(ryA, rxA, 0, c0 + 2 * CC);
+    LF_T(1)
+    // full-resolution pixels of this tile: rows with i0(y) in [a, a+TY), columns with j0(x) in [b0, b0+TX) -- the
+    // pooling pass left the ranges in `tab`
+    const int ya = tab[blockIdx.y], yb = tab[blockIdx.y + 1];
+    const int xa = tab[gridDim.y + 1 + blockIdx.x], xb = tab[gridDim.y + 2 + blockIdx.x];
+    const int ny = yb - ya, nx = xb - xa;
+    if (ny > 2 * TY + 4 || nx > 2 * TX + 4) __builtin_trap();  // cannot happen (ratio (hp-1)/(h-1) < 1/2): fail loudly, never overrun L
+    // the previous frame's labels around the tile: rows ya + 2(dy0 - D) .., columns xa - 2D ..; outside the image = 0
+    // (zero padding, IntVOS.py:400).  Loaded NOW (behind the first two stages' loads, under the first stage's arithmetic), used after phase 1: they come
+    // from HBM (nobody has touched them this frame) and would otherwise cost a full miss latency between the phases
+    constexpr int KL = (lf_lab_rows(D) * lf_lab_cols(D) + NT - 1) / NT;
+    const int lrows = ny + 2 * (ND - 1), lcols = nx + 4 * D;
+    const int ly0 = ya + 2 * (dy0 - D), lx0 = xa - 2 * D;
+    int labr[KL];
+#pragma unroll
+    for (int k = 0; k < KL; ++k) {
+        const int e = tid + NT * k;
+        const int r = e / lcols, c = e - r * lcols;
+        const int yy = ly0 + r, xx = lx0 + c;
+        const int yc = yy < 0 ? 0 : (yy < h ? yy : h - 1), xc = xx < 0 ? 0 : (xx < w ? xx : w - 1);
+        int idx = yc * w + xc;
+        asm volatile("" : "+v"(idx));  // the compiler must not turn the clamp back into a branch around the load:
+        const int v = labels[idx];     // unconditional loads issue back to back, a branchy one waits vmcnt(0) each time
+        labr[k] = (yy == yc && xx == xc && !(abl & 8)) ? v : 0;
+    }
+    // stage s is in LDS buffer s & 1; the registers hold stage s + 1 (loaded one phase ago).  Its LDS stores go out
+    // FIRST -- the other buffer is free, its last readers passed the barrier -- then the loads of stage s + 2, then the
+    // arithmetic: stores and loads run under the arithmetic, one barrier per stage.
+    for (int c0 = 0, st_i = 0; c0 < ((abl & 16) ? 0 : C); c0 += CC, ++st_i) {
+        if (c0 + CC < C) {
+            store_lds(ryA, rxA, (st_i & 1) ^ 1, c0 + CC);
+            if (c0 + 2 * CC < C) load_regs(ryA, rxA, c0 + 2 * CC);
+        }
+        compute(st_i & 1);
         __syncthreads();
     }
-    __syncthreads();
 
-    // ---- phase 2: normalised volume of S and the labels around the tile into LDS -----------------
+    LF_T(2)
     constexpr int VS = lf_vs(D), NPS = lf_npix(D);
     float *V = smem;                                                 // [ND][SY * 16][VS]
     unsigned char *L = (unsigned char *)(V + ND * SY * LF_SX * VS);  // [lab_rows][lab_cols], 255 = matches no id
@@ -612,36 +715,23 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
                 if (LF_PH % 4 == 0 && d4 + 3 < PA && d4 + 3 < ndx) {
                     f32x4 t;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) t[i] = manet_normalize_dist(acc[j][d4 + i]);
+                    for (int i = 0; i < 4; ++i) t[i] = (abl & 4) ? LF_ACC(j, d4 + i) : manet_normalize_dist_local(LF_ACC(j, d4 + i));
                     *(f32x4 *)(vp0 + j * VS + d4) = t;
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (d4 + i < PA && d4 + i < ndx) vp0[j * VS + d4 + i] = manet_normalize_dist(acc[j][d4 + i]);
+                        if (d4 + i < PA && d4 + i < ndx) vp0[j * VS + d4 + i] = manet_normalize_dist_local(LF_ACC(j, d4 + i));
                 }
             }
         }
     }
-    // full-resolution pixels of this tile: rows with i0(y) in [a, a+TY), columns with j0(x) in [b0, b0+TX).
-    // i0(y) <= y/2, so the rows start at 2a or a little later (wave-uniform scans, a few iterations)
-    int ya = 2 * a, yb;
-    while (ya < h && bilin_coeff(ya, hp, h).i0 < a) ++ya;
-    yb = ya;
-    while (yb < h && bilin_coeff(yb, hp, h).i0 < a + TY) ++yb;
-    int xa = 2 * b0, xb;
-    while (xa < w && bilin_coeff(xa, wp, w).i0 < b0) ++xa;
-    xb = xa;
-    while (xb < w && bilin_coeff(xb, wp, w).i0 < b0 + TX) ++xb;
-    const int ny = yb - ya, nx = xb - xa;
-    if (ny > 2 * TY + 4 || nx > 2 * TX + 4) __builtin_trap();  // cannot happen (ratio (hp-1)/(h-1) < 1/2): fail loudly, never overrun L
-    // labels: rows ya + 2(dy0 - D) .. , columns xa - 2D .. ; outside the image = 0 (zero padding, IntVOS.py:400)
-    const int lrows = ny + 2 * (ND - 1), lcols = nx + 4 * D;
-    const int ly0 = ya + 2 * (dy0 - D), lx0 = xa - 2 * D;
-    for (int e = tid; e < lrows * lcols; e += NT) {
-        const int r = e / lcols, c = e - r * lcols;
-        const int yy = ly0 + r, xx = lx0 + c;
-        int lab = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? labels[(long)yy * w + xx] : 0;
-        L[r * lcols + c] = (lab >= 0 && lab < MANET_MAX_IDS) ? (unsigned char)lab : (unsigned char)255;
+    LF_T(3)
+#pragma unroll
+    for (int k = 0; k < KL; ++k) {
+        const int e = tid + NT * k;
+        // one pass over the ids (n_ids <= LF_NIP): store the M2 row directly -- the id, or LF_NIP for "no id of this pass"
+        const int lmax = n_ids <= LF_NIP ? LF_NIP : 255;
+        if (e < lrows * lcols) L[e] = (labr[k] >= 0 && labr[k] < (n_ids <= LF_NIP ? n_ids : MANET_MAX_IDS)) ? (unsigned char)labr[k] : (unsigned char)lmax;
     }
     // per-(id, pixel) minima [LF_NIP + 1][NPS] (row LF_NIP collects the candidates whose label is not an id of this
     // pass), then the separable bilinear tables: tap offsets into V and the two weights, per pixel row / column
@@ -666,34 +756,54 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     const int npix = ny * nx;
     const float inv_npix = 1.0f / (float)npix, inv_nx = 1.0f / (float)nx;  // exact quotients below: see DESIGN 3.4
     for (int o0 = 0; o0 < n_ids; o0 += LF_NIP) {
-        for (int e = tid; e < (LF_NIP + 1) * NPS; e += NT) M2[e] = 0x3f800000u;
+        const int nk = (n_ids - o0) < LF_NIP ? (n_ids - o0) : LF_NIP;
+        for (int e = tid; e < nk * NPS; e += NT) M2[e] = 0x3f800000u;  // the rows that are read back
         __syncthreads();
-        for (int item = tid; item < ((abl & 2) ? 0 : npix * nd_here); item += NT) {
-            const int by = (int)(((float)item + 0.5f) * inv_npix), pix = item - by * npix;
-            const int py = (int)(((float)pix + 0.5f) * inv_nx), pxx = pix - py * nx;
-            const Tap r = RT[py], c = CT[pxx];
-            const float *vb = V + by * (SY * LF_SX * VS);
-            const float *p00 = vb + r.o0 + c.o0, *p01 = vb + r.o0 + c.o1, *p10 = vb + r.o1 + c.o0, *p11 = vb + r.o1 + c.o1;
-            const unsigned char *lrow = L + (py + 2 * by) * lcols + pxx;
-            unsigned *mrow = M2 + pix;
+        LF_T(4)
+        // n_ids <= LF_NIP (one pass): the label byte, clamped to LF_NIP, IS the row of M2
+        auto items = [&](auto single_pass) __attribute__((always_inline)) {
+            constexpr bool SINGLE = decltype(single_pass)::value;
+            for (int item = tid; item < ((abl & 2) ? 0 : npix * nd_here); item += NT) {
+                const int by = (int)(((float)item + 0.5f) * inv_npix), pix = item - by * npix;
+                const int py = (int)(((float)pix + 0.5f) * inv_nx), pxx = pix - py * nx;
+                const Tap r = RT[py], c = CT[pxx];
+                const float *vb = V + by * (SY * LF_SX * VS);
+                const float *p00 = vb + r.o0 + c.o0, *p01 = vb + r.o0 + c.o1, *p10 = vb + r.o1 + c.o0, *p11 = vb + r.o1 + c.o1;
+                const unsigned char *lrow = L + (py + 2 * by) * lcols + pxx;
+                unsigned *mrow = M2 + pix;
+                const f32x2 cl0 = {c.l0, c.l0}, cl1 = {c.l1, c.l1}, rl0 = {r.l0, r.l0}, rl1 = {r.l1, r.l1};
 #pragma unroll
-            for (int q = 0; q < (P + 3) / 4; ++q) {
-                const f32x4 t00 = *(const f32x4 *)(p00 + 4 * q), t01 = *(const f32x4 *)(p01 + 4 * q);
-                const f32x4 t10 = *(const f32x4 *)(p10 + 4 * q), t11 = *(const f32x4 *)(p11 + 4 * q);
+                for (int q = 0; q < (P + 3) / 4; ++q) {
+                    const f32x4 t00 = *(const f32x4 *)(p00 + 4 * q), t01 = *(const f32x4 *)(p01 + 4 * q);
+                    const f32x4 t10 = *(const f32x4 *)(p10 + 4 * q), t11 = *(const f32x4 *)(p11 + 4 * q);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int bx = 4 * q + i;
-                    if (bx < P) {
-                        const float v = r.l0 * (c.l0 * t00[i] + c.l1 * t01[i]) + r.l1 * (c.l0 * t10[i] + c.l1 * t11[i]);
-                        unsigned idx = (unsigned)lrow[2 * bx] - (unsigned)o0;
-                        idx = idx < (unsigned)LF_NIP ? idx : (unsigned)LF_NIP;
-                        atomicMin(mrow + idx * NPS, __float_as_uint(v));
+                    for (int i = 0; i < 4; i += 2) {
+                        if (4 * q + i >= P) continue;
+                        // two window columns per packed op; per element the expression of bilin_sample / the oracle:
+                        // l0y (l0x v00 + l1x v01) + l1y (l0x v10 + l1x v11)
+                        const f32x2 a00 = {t00[i], t00[i + 1]}, a01 = {t01[i], t01[i + 1]};
+                        const f32x2 a10 = {t10[i], t10[i + 1]}, a11 = {t11[i], t11[i + 1]};
+                        const f32x2 v2 = rl0 * (cl0 * a00 + cl1 * a01) + rl1 * (cl0 * a10 + cl1 * a11);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int bx = 4 * q + i + e;
+                            if (bx < P) {
+                                unsigned idx = (unsigned)lrow[2 * bx];
+                                if (!SINGLE) {
+                                    idx -= (unsigned)o0;
+                                    idx = idx < (unsigned)LF_NIP ? idx : (unsigned)LF_NIP;
+                                }
+                                atomicMin(mrow + idx * NPS, __float_as_uint(v2[e]));
+                            }
+                        }
                     }
                 }
             }
-        }
+        };
+        if (n_ids <= LF_NIP) items(std::true_type{});
+        else items(std::false_type{});
         __syncthreads();
-        const int nk = (n_ids - o0) < LF_NIP ? (n_ids - o0) : LF_NIP;
+        LF_T(5)
         for (int e = tid; e < npix * nk; e += NT) {
             const int pix = e / nk, k = e - pix * nk;
             const int py = pix / nx, pxx = pix - py * nx;
@@ -702,12 +812,13 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
             else atomicMin((unsigned *)o, M2[k * NPS + pix]);  // several workgroups per tile: `out` was pre-set to 1.0
         }
         __syncthreads();
+        LF_T(6)
     }
 }
 
 template <int D>
 static void launch_fused_d(hipStream_t st, const float *ap, const float *bp, const PoolPad &G, const int *labels, int h,
-                           int w, int C, int n_ids, float *out)
+                           int w, int C, int n_ids, float *out, const int *tab)
 {
     constexpr int TY = lf_sy(D) - 1, TX = LF_SX - 1;
     // i0 runs over 0..hp-1 (the last value only for the last row); tiles cover all of them
@@ -715,7 +826,7 @@ static void launch_fused_d(hipStream_t st, const float *ap, const float *bp, con
     const size_t lds = lf_lds_bytes(D);
     (void)hipFuncSetAttribute((const void *)local_fused_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(local_fused_kernel<D>, grid, dim3(lf_nt(D)), lds, st, ap, bp, G.WS, G.plane, labels, h, w, C, n_ids,
-                       out, manet_tune_get(MANET_TUNE_ABLATION, 0));
+                       out, tab, manet_tune_get(MANET_TUNE_ABLATION, 0));
 }
 
 __global__ void fill_f32_kernel(float *__restrict__ p, float v, long n)
@@ -726,10 +837,12 @@ __global__ void fill_f32_kernel(float *__restrict__ p, float v, long n)
 // `pooled`: room for the two padded pooled frames (2 * C * lf_pool_pad().plane floats)
 static void launch_fused(int d, hipStream_t st, const void *cur, long c_sy, long c_sx, long c_sc, const void *prev,
                          long p_sy, long p_sx, long p_sc, int emb_dtype, const int *labels, int h, int w, int C, int n_ids,
-                         float *out, float *pooled)
+                         float *out, float *pooled, int *tab)
 {
     const PoolPad G = lf_pool_pad(h, w, d);
     float *ap = pooled, *bp = pooled + G.plane * C;
+    const int TY = lf_sy(d) - 1, TX = LF_SX - 1;
+    const int nty = (G.hp + TY - 1) / TY, ntx = (G.wp + TX - 1) / TX;  // the fused kernel's grid
     {
         long n = G.plane * C;
         // partial minima of several workgroups per tile meet by atomicMin: `out` starts from the "no match" value,
@@ -747,13 +860,13 @@ static void launch_fused(int d, hipStream_t st, const void *cur, long c_sy, long
         if (emb_dtype == MANET_EMB_BF16)
             hipLaunchKernelGGL(lf_pool_pad_kernel<unsigned short>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                (const unsigned short *)cur, c_sy, c_sx, c_sc, (const unsigned short *)prev, p_sy, p_sx, p_sc, C,
-                               G.hp, G.wp, d, G.HPAD, G.WS, ap, bp, init, n_out);
+                               G.hp, G.wp, d, G.HPAD, G.WS, ap, bp, init, n_out, tab, TY, TX, nty, ntx, h, w);
         else
             hipLaunchKernelGGL(lf_pool_pad_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                (const float *)cur, c_sy, c_sx, c_sc, (const float *)prev, p_sy, p_sx, p_sc, C, G.hp, G.wp, d,
-                               G.HPAD, G.WS, ap, bp, init, n_out);
+                               G.HPAD, G.WS, ap, bp, init, n_out, tab, TY, TX, nty, ntx, h, w);
     }
-#define MANET_LF_CASE(D_) case D_: launch_fused_d<D_>(st, ap, bp, G, labels, h, w, C, n_ids, out); break;
+#define MANET_LF_CASE(D_) case D_: launch_fused_d<D_>(st, ap, bp, G, labels, h, w, C, n_ids, out, tab); break;
     switch (d) {
         MANET_LF_CASE(0) MANET_LF_CASE(1) MANET_LF_CASE(2) MANET_LF_CASE(3) MANET_LF_CASE(4) MANET_LF_CASE(5)
         MANET_LF_CASE(6) MANET_LF_CASE(7) MANET_LF_CASE(8) MANET_LF_CASE(9) MANET_LF_CASE(10) MANET_LF_CASE(11)
@@ -780,7 +893,9 @@ LocalLayout local_layout(int h, int w, int C, int d, int downsample)
     L.off_ap = 0;
     L.off_bp = manet_align_up(pooled, 256);
     L.off_vol = L.off_bp + manet_align_up(pooled, 256);
-    L.total = manet_align_up(L.off_vol + plane * L.PP * sizeof(float), 256);
+    // the volume region doubles as the fused path's tile table (first pixel row / column of every tile)
+    size_t vol = plane * L.PP * sizeof(float), tab = (size_t)(L.hp + L.wp + 4) * sizeof(int);
+    L.total = manet_align_up(L.off_vol + (vol > tab ? vol : tab), 256);
     return L;
 }
 
@@ -1005,7 +1120,8 @@ int manet_local_match_ex(const void *prev_v, int64_t p_sy, int64_t p_sx, int64_t
     if (downsample && !manet_tune_get(MANET_TUNE_LOCAL_UNFUSED, 0)) {  // the live configuration: pooling pass + fused kernel
         manet_profile_record(st, true, 1);
         launch_fused(max_distance, st, cur_v, (long)c_sy, (long)c_sx, (long)c_sc, prev_v, (long)p_sy, (long)p_sx, (long)p_sc,
-                     emb_dtype, prev_labels, h, w, C, n_ids, out, (float *)((char *)workspace + L.off_ap));
+                     emb_dtype, prev_labels, h, w, C, n_ids, out, (float *)((char *)workspace + L.off_ap),
+                     (int *)((char *)workspace + L.off_vol));
         manet_profile_record(st, false, 1);
         return manet_check_launch("manet_local_match_f32");
     }

@@ -8,6 +8,7 @@
 #include "manet_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -43,5 +44,15 @@ static inline size_t manet_align_up(size_t x, size_t a) { return (x + a - 1) / a
 __device__ __forceinline__ float manet_normalize_dist(float x)
 {
     float s = 1.0f / (1.0f + expf(-x));
+    return (s - 0.5f) * 2.0f;
+}
+// The local-window kernels' form: hardware exp2 / reciprocal (1 ulp each) instead of libm expf and an IEEE divide --
+// 6 instructions instead of ~25 per window entry (the fused kernel normalises (2d+1)^2 entries per pooled pixel:
+// 4.3 us of its 56 at d=12).  Exact where it matters: x = 0 -> 0, x = inf -> 1.  |error| <= 3e-7 absolute; the
+// reference's own torch.sigmoid is no closer to the real value.  Every local kernel uses this one, so the fused
+// and the materialised-volume paths stay bit-identical with each other.
+__device__ __forceinline__ float manet_normalize_dist_local(float x)
+{
+    float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
     return (s - 0.5f) * 2.0f;
 }

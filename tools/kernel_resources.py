@@ -13,7 +13,7 @@ def main():
     src = sys.argv[1]
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-           "-fno-fast-math", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "cvpr2020_manet_amd", "csrc"),
+           "-fno-fast-math", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "cvpr2020_manet_amd", "csrc"),
            "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"]
     err = subprocess.run(cmd, capture_output=True, text=True).stderr
     cur = None
