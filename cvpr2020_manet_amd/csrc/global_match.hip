@@ -459,21 +459,6 @@ __device__ __forceinline__ float float_of(unsigned k)
     return __uint_as_float(u);
 }
 
-// LDS-DMA of one 1 KiB piece: lane l's 16 bytes at `gsrc` land at LDS byte address lds_dst + 16 l.
-// Issued from inline asm on purpose: hipcc cannot tell the DMA's LDS destination from the ds_reads of the
-// OTHER staging buffer and would drain vmcnt(0) in front of them, which serialises the prefetch (r1).
-// Hidden in asm, the compiler does not count these loads; the kernel does (one s_waitcnt vmcnt(0) per
-// step, right before the barrier that publishes the buffer).  M0 (the DMA's LDS base) is saved/restored
-// inside the statement (cdna_hip_programming.md 5.7).
-__device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
-
 // NaN-propagating minimum (v_minimum3_f32 on gfx950): torch.min semantics, and -- unlike fminf on an MFMA
 // result -- needs no canonicalising v_max in front of it.
 __device__ __forceinline__ float min3p(float m, float a, float b)

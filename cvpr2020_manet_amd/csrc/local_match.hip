@@ -403,13 +403,16 @@ __host__ __device__ constexpr int lf_cw(int d)  // halo row stride (every thread
 __host__ __device__ constexpr int lf_yr(int d) { return lf_sy(d) + lf_nd(d) - 1; }                // halo rows
 __host__ __device__ constexpr int lf_yplane(int d) { return lf_yr(d) * lf_cw(d); }
 __host__ __device__ constexpr int lf_xplane(int d) { return lf_sy(d) * LF_SX; }
-// channels per LDS stage: two stages <= 64 KiB, <= 12 float4 in flight per thread
+// channels per LDS stage: two stages <= 128 KiB (the phase-2 volume needs as much at the wide windows anyway)
 __host__ __device__ constexpr int lf_cc(int d)
 {
-    int by_lds = 65536 / (8 * (lf_yplane(d) + lf_xplane(d)));
-    int by_regs = 12 * lf_nt(d) / ((lf_yplane(d) + lf_xplane(d)) / 4);
-    int cc = by_lds < by_regs ? by_lds : by_regs;
+    int cc = 131072 / (8 * (lf_yplane(d) + lf_xplane(d)));
     return cc < 2 ? 2 : (cc > 25 ? 25 : cc);
+}
+// floats of one stage image, padded to whole 1 KiB LDS-DMA pieces
+__host__ __device__ constexpr int lf_stage_floats(int d)
+{
+    return (lf_cc(d) * (lf_yplane(d) + lf_xplane(d)) / 4 + 63) / 64 * 256;
 }
 __host__ __device__ constexpr int lf_lab_rows(int d) { return 2 * (lf_sy(d) - 1) + 4 + 2 * (lf_nd(d) - 1); }
 __host__ __device__ constexpr int lf_lab_cols(int d) { return 2 * (LF_SX - 1) + 4 + 4 * d; }
@@ -420,7 +423,7 @@ __host__ __device__ constexpr int lf_npix(int d) { return (2 * (lf_sy(d) - 1) + 
 constexpr int LF_NIP = 8;  // object ids per pass of the per-pixel phase
 __host__ __device__ constexpr size_t lf_lds_bytes(int d)
 {
-    size_t stage = 2 * (size_t)lf_cc(d) * (lf_yplane(d) + lf_xplane(d)) * 4;
+    size_t stage = 2 * (size_t)lf_stage_floats(d) * 4;
     size_t vol = (size_t)lf_nd(d) * lf_sy(d) * LF_SX * lf_vs(d) * 4 + (((size_t)lf_lab_rows(d) * lf_lab_cols(d) + 15) & ~(size_t)15) +
                  (size_t)lf_npix(d) * (LF_NIP + 1) * 4 +                        // per-(id, pixel) minima + the "no id" row
                  (size_t)(2 * (lf_sy(d) - 1) + 4 + 2 * (LF_SX - 1) + 4) * 16;  // bilinear row / column tables
@@ -501,9 +504,11 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     constexpr int TX = LF_SX - 1, CW = lf_cw(D), YR = lf_yr(D), CC = lf_cc(D), COLS = lf_cols(D), NG = LF_SX / COLS;
     constexpr int DXS = lf_dxs(D), PA = lf_pa(D), LF_PH = lf_ph(D);
     constexpr int yplane = YR * CW, xplane = SY * LF_SX;
-    constexpr int buf_floats = CC * (yplane + xplane);
     constexpr int NVY = yplane / 4, NVX = xplane / 4;          // float4 per channel
-    constexpr int KY = (CC * NVY + NT - 1) / NT, KX = (CC * NVX + NT - 1) / NT;  // float4 per thread per stage
+    constexpr int NITEM = CC * (NVY + NVX);                    // float4 per stage
+    constexpr int NPIECE = (NITEM + 63) / 64;                  // 1 KiB LDS-DMA pieces per stage
+    constexpr int NWV = NT / 64, KD = (NPIECE + NWV - 1) / NWV;  // pieces per wave
+    constexpr int buf_floats = lf_stage_floats(D);             // = NPIECE * 256
     float *smem = (float *)smem_raw;
     const int tid = threadIdx.x;
     LF_T(0)
@@ -512,52 +517,46 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     const int dy0 = blockIdx.z * ND;                       // first window row of this workgroup
 
     // ---- phase 1: distances on S for window rows dy0 .. dy0+ND-1 ---------------------------------
-    // staging map (fixed for the whole kernel): this thread's float4 items of a stage -- channel offset inside
-    // the stage, element offset inside a padded plane, float offset inside the LDS stage
-    int ych[KY], ygo[KY], ylo[KY], xch[KX], xgo[KX], xlo[KX];
+    // Staging by LDS-DMA (lds_dma16: 64 lanes x 16 bytes land in 1 KiB of LDS, no VGPR hop, no ds_write): a stage is
+    // NPIECE such pieces, dealt round-robin to the waves.  The stage image is [CC][YR][CW] previous-frame halo rows then
+    // [CC][SY][16] current-frame rows; a lane's 16 bytes of piece p are float4 number 64 p + lane of that image.  Its
+    // source address for stage 0 is computed once (below); every later stage is a uniform step of CC planes.
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem_raw);
+    const float *src[KD];
+    int sch[KD];  // the item's channel inside the stage (the last stage may run past C: clamped there)
 #pragma unroll
-    for (int k = 0; k < KY; ++k) {
-        const int i = tid + NT * k;
-        const int c = i / NVY, v = i - c * NVY;
-        const int r = v / (CW / 4), q = v - r * (CW / 4);
-        ych[k] = (i < CC * NVY) ? c : -1;
-        ygo[k] = (a + dy0 + r) * WS + b0 + 4 * q;  // padded coordinates: image row a - D + dy0 + r sits at row a + dy0 + r
-        ylo[k] = c * yplane + r * CW + 4 * q;
-    }
-#pragma unroll
-    for (int k = 0; k < KX; ++k) {
-        const int i = tid + NT * k;
-        const int c = i / NVX, v = i - c * NVX;
-        const int r = v / 4, q = v - r * 4;
-        xch[k] = (i < CC * NVX) ? c : -1;
-        xgo[k] = (D + a + r) * WS + D + b0 + 4 * q;
-        xlo[k] = CC * yplane + c * xplane + r * LF_SX + 4 * q;
-    }
-    // a stage's global loads are issued one full phase (arithmetic of a stage) before its LDS stores
-    f32x4 ryA[KY], rxA[KX];
-    auto load_regs = [&](f32x4 (&ry_)[KY], f32x4 (&rx_)[KX], int c0) __attribute__((always_inline)) {  // unconditional, clamped
-#pragma unroll
-        for (int k = 0; k < KY; ++k) {
-            int ch = c0 + (ych[k] < 0 ? 0 : ych[k]);
-            ch = ch < C ? ch : C - 1;
-            ry_[k] = *(const f32x4 *)(prevp + (long)ch * PS + ygo[k]);
+    for (int k = 0; k < KD; ++k) {
+        int i = (k * NWV + wave) * 64 + lane;
+        i = i < NITEM ? i : NITEM - 1;  // the tail of the last piece lands in the padding of the stage image
+        if (i < CC * NVY) {
+            const int c = i / NVY, v = i - c * NVY;
+            const int r = v / (CW / 4), q = v - r * (CW / 4);
+            // padded coordinates: image row a - D + dy0 + r sits at plane row a + dy0 + r
+            src[k] = prevp + (long)c * PS + (a + dy0 + r) * WS + b0 + 4 * q;
+            sch[k] = c;
+        } else {
+            const int j = i - CC * NVY;
+            const int c = j / NVX, v = j - c * NVX;
+            const int r = v / 4, q = v - r * 4;
+            src[k] = curp + (long)c * PS + (D + a + r) * WS + D + b0 + 4 * q;
+            sch[k] = c;
         }
+    }
+    auto stage_dma = [&](int c0, int buf) __attribute__((always_inline)) {
+        const bool tail = c0 + CC > C;  // uniform
 #pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            int ch = c0 + (xch[k] < 0 ? 0 : xch[k]);
-            ch = ch < C ? ch : C - 1;
-            rx_[k] = *(const f32x4 *)(curp + (long)ch * PS + xgo[k]);
+        for (int k = 0; k < KD; ++k) {
+            if (k * NWV + wave < NPIECE) {  // wave-uniform
+                const float *g_ = src[k] + (long)c0 * PS;
+                if (tail) {
+                    const int over = c0 + sch[k] - (C - 1);
+                    if (over > 0) g_ -= (long)over * PS;  // channels past C re-read plane C-1; the arithmetic skips them
+                }
+                lds_dma16(g_, smem_base + (unsigned)buf * (unsigned)(buf_floats * 4) + (unsigned)(k * NWV + wave) * 1024u);
+            }
         }
-    };
-    auto store_lds = [&](const f32x4 (&ry_)[KY], const f32x4 (&rx_)[KX], int buf, int c0) __attribute__((always_inline)) {
-        float *st = smem + (long)buf * buf_floats;  // channels beyond C: x = y = 0 (they add 0)
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < KY; ++k)
-            if (ych[k] >= 0) *(f32x4 *)(st + ylo[k]) = (c0 + ych[k] < C) ? ry_[k] : zero;
-#pragma unroll
-        for (int k = 0; k < KX; ++k)
-            if (xch[k] >= 0) *(f32x4 *)(st + xlo[k]) = (c0 + xch[k] < C) ? rx_[k] : zero;
     };
 
     // lane -> (column group, slot): the window half is the thread index's TOP bit, so a wave's lanes read the same half
@@ -593,7 +592,7 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         f32x2 win[WN / 2];
         float xv[COLS];
     };
-    auto compute = [&](int buf_) __attribute__((always_inline)) {
+    auto compute = [&](int buf_, int nch) __attribute__((always_inline)) {
         if (active && !(abl & 1)) {
         const float *ys = smem + (long)buf_ * buf_floats + (ry + dyi) * CW + COLS * g + dx_lo;
         const float *xs = smem + (long)buf_ * buf_floats + CC * yplane + ry * LF_SX + COLS * g;
@@ -638,13 +637,13 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
             fetch(W0, 0);
             int c = 0;
 #pragma unroll 1
-            for (; c + 2 < CC; c += 2) {  // branch-free body (a conditional fetch costs a register shuffle per trip)
+            for (; c + 2 < nch; c += 2) {  // branch-free body (a conditional fetch costs a register shuffle per trip)
                 fetch(W1, c + 1);
                 fma_chan(W0);
                 fetch(W0, c + 2);
                 fma_chan(W1);
             }
-            if (CC % 2 == 0) {
+            if (c + 1 < nch) {
                 fetch(W1, c + 1);
                 fma_chan(W0);
                 fma_chan(W1);
@@ -653,7 +652,7 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
             }
         } else {  // wide windows: the arithmetic of one channel covers the reads of the next in an unrolled pair
 #pragma unroll 2
-            for (int c = 0; c < CC; ++c) {
+            for (int c = 0; c < nch; ++c) {
                 Chan W;
                 fetch(W, c);
                 fma_chan(W);
@@ -661,9 +660,8 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         }
     }
     };
-    load_regs(ryA, rxA, 0);
-    store_lds(ryA, rxA, 0, 0);
-    if (CC < C) load_regs(ryA, rxA, CC);
+    stage_dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     LF_T(1)
     // full-resolution pixels of this tile: rows with i0(y) in [a, a+TY), columns with j0(x) in [b0, b0+TX) -- the
@@ -690,15 +688,13 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         const int v = labels[idx];     // unconditional loads issue back to back, a branchy one waits vmcnt(0) each time
         labr[k] = (yy == yc && xx == xc && !(abl & 8)) ? v : 0;
     }
-    // stage s is in LDS buffer s & 1; the registers hold stage s + 1 (loaded one phase ago).  Its LDS stores go out
-    // FIRST -- the other buffer is free, its last readers passed the barrier -- then the loads of stage s + 2, then the
-    // arithmetic: stores and loads run under the arithmetic, one barrier per stage.
+    // stage s is in LDS buffer s & 1.  The DMA of stage s + 1 into the other buffer (free: its last readers passed the
+    // barrier) is issued first and runs under the arithmetic of stage s; the wave waits for its own pieces (vmcnt --
+    // the DMA is hidden from the compiler's counters, this is the only wait on it) and the barrier publishes them.
     for (int c0 = 0, st_i = 0; c0 < ((abl & 16) ? 0 : C); c0 += CC, ++st_i) {
-        if (c0 + CC < C) {
-            store_lds(ryA, rxA, (st_i & 1) ^ 1, c0 + CC);
-            if (c0 + 2 * CC < C) load_regs(ryA, rxA, c0 + 2 * CC);
-        }
-        compute(st_i & 1);
+        if (c0 + CC < C) stage_dma(c0 + CC, (st_i & 1) ^ 1);
+        compute(st_i & 1, (C - c0) < CC ? (C - c0) : CC);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 

@@ -46,6 +46,21 @@ __device__ __forceinline__ float manet_normalize_dist(float x)
     float s = 1.0f / (1.0f + expf(-x));
     return (s - 0.5f) * 2.0f;
 }
+// LDS-DMA of one 1 KiB piece: lane l's 16 bytes at `gsrc` land at LDS byte address lds_dst + 16 l.
+// Issued from inline asm on purpose: hipcc cannot tell the DMA's LDS destination from the ds_reads of the
+// OTHER staging buffer and would drain vmcnt(0) in front of them, which serialises the prefetch (r1).
+// Hidden in asm, the compiler does not count these loads; the kernel does (one s_waitcnt vmcnt(0) per
+// step, right before the barrier that publishes the buffer).  M0 (the DMA's LDS base) is saved/restored
+// inside the statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
 // The local-window kernels' form: hardware exp2 / reciprocal (1 ulp each) instead of libm expf and an IEEE divide --
 // 6 instructions instead of ~25 per window entry (the fused kernel normalises (2d+1)^2 entries per pooled pixel:
 // 4.3 us of its 56 at d=12).  Exact where it matters: x = 0 -> 0, x = inf -> 1.  |error| <= 3e-7 absolute; the

@@ -16,8 +16,9 @@ def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     for (d, nid, dt) in ((4, 4, torch.bfloat16), (12, 2, torch.float32)):
         h, w, C = 120, 214, 100
-        prev = torch.randn(h, w, C, device=dev).to(dt)
-        cur = torch.randn(h, w, C, device=dev).to(dt)
+        # [C, h, w] storage viewed as [h, w, C]: what IntVOS hands over (x.permute(1, 2, 0) of the encoder's NCHW output)
+        prev = torch.randn(C, h, w, device=dev).to(dt).permute(1, 2, 0)
+        cur = torch.randn(C, h, w, device=dev).to(dt).permute(1, 2, 0)
         lab = torch.randint(0, nid, (h, w), device=dev, dtype=torch.int32)
         for _ in range(5):
             ops.local_match(prev, cur, lab, nid, d, True)

@@ -12,7 +12,7 @@ dev = torch.device('cuda:0')
 torch.manual_seed(0)
 for (d, nid, dt) in ((4, 4, torch.bfloat16), (12, 2, torch.float32)):
     h, w, C = 120, 214, 100
-    prev = torch.randn(h, w, C, device=dev).to(dt); cur = torch.randn(h, w, C, device=dev).to(dt)
+    prev = torch.randn(C, h, w, device=dev).to(dt).permute(1, 2, 0); cur = torch.randn(C, h, w, device=dev).to(dt).permute(1, 2, 0)
     lab = torch.randint(0, nid, (h, w), device=dev, dtype=torch.int32)
     for _ in range(5):
         ops.local_match(prev, cur, lab, nid, d, True)
