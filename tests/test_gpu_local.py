@@ -174,3 +174,34 @@ def test_correlation_tied_to_reference_distance(ops):
                         assert abs(xs[y, x] + ys[yy, xx] - 2 * C * corr[0, dy * P + dx, y, x] - r) < 1e-4 * max(1.0, r)
                     else:
                         assert corr[0, dy * P + dx, y, x] == 0.0
+
+
+@pytest.mark.parametrize("d", range(13))
+def test_fused_kernel_every_window_size(ops, oracle, d):
+    """Every instantiation of the fused kernel (d = 0..12: different thread maps, window halves, LDS strides, 1-5
+    workgroups per tile) on a grid with several tile rows AND columns, ragged edges, C spanning several LDS stages with a
+    partial last one, more ids than one per-pixel pass holds, labels outside [0, n_ids): against the oracle within the
+    local tolerance, and bit for bit against the three-launch path over the materialised volume (tuning key 4)."""
+    from cvpr2020_manet_amd import _lib
+    rng = np.random.default_rng(4200 + d)
+    for (C, h, w, n_ids) in ((58, 53, 71, 11), (7, 9, 100, 2)):
+        prev = (np.maximum(rng.standard_normal((C, h, w)), 0) * 0.2).astype(np.float32)
+        cur = (np.maximum(rng.standard_normal((C, h, w)), 0) * 0.2).astype(np.float32)
+        lab = rng.integers(-1, n_ids + 1, size=(h, w, 1)).astype(np.int32)
+        p, c, l = chw_view(prev), chw_view(cur), dev(lab)
+        got = ops.local_match(p, c, l, n_ids, d)
+        want = oracle.local_match(np.transpose(prev, (1, 2, 0)), np.transpose(cur, (1, 2, 0)), lab, n_ids, d,
+                                  downsample=True).reshape(h, w, n_ids)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+        lib = _lib.load()
+        _lib.check(lib.manet_tune_set(4, 1), "manet_tune_set")  # MANET_TUNE_LOCAL_UNFUSED
+        try:
+            unfused = ops.local_match(p, c, l, n_ids, d)
+        finally:
+            _lib.check(lib.manet_tune_set(4, 0), "manet_tune_set")
+        assert torch.equal(got, unfused)
+        # 2-byte embeddings: the pooling pass reads bf16, everything after it is the same fp32 arithmetic
+        pb, cb = p.to(torch.bfloat16), c.to(torch.bfloat16)
+        got_b = ops.local_match(pb, cb, l, n_ids, d)
+        ref_b = ops.local_match(pb.float(), cb.float(), l, n_ids, d)
+        assert torch.equal(got_b, ref_b)
