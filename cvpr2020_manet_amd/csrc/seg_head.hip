@@ -9,64 +9,136 @@
 //   out[b][c][y][x] = relu( (sum_{ky,kx} in[b][c][y+ky-3][x+kx-3] * w[c][ky][kx] + bias[c]) * scale[c] + shift[c] )
 // with zero padding, scale = gamma / sqrt(var + eps), shift = beta - mean * scale (BatchNorm in eval mode).
 //
-// Workgroup = one (b, c) plane tile of 16 x 64 outputs; the (16+6) x (64+6) input tile is staged in LDS
-// (row-contiguous global reads), each thread produces 4 adjacent outputs of one row from a 7 x 10 window
-// (10 LDS floats feed 28 FMAs per kernel row); the 49 weights are wave-uniform (scalar loads).
+// r2 kernel.  The op is 49 FMAs per output on a pure stream (2 x 4 B per element): at [3,256,120,214] that is
+// 158 MB (20 us at 8 TB/s) and 15 M scalar wave-FMAs (~28 us at the measured v_fma_f32 rate) -- the r1 kernel (one
+// output row x 4 columns per thread, scalar FMAs, 16 x 64 tiles) took 58 us.  Here:
+//  * a thread owns 2 rows x 8 columns; its running sums are VERTICAL pairs (out[y][x], out[y+1][x]), so every tap is one
+//    v_pk_fma_f32 with the tap weight broadcast: half the VALU instructions (a wave issues one VALU instruction per
+//    ~2.5 ns whatever its width: tools/ubench/valu_rate.hip);
+//  * the packed operand must be an aligned register pair holding (in[r][x], in[r+1][x]): the input tile is kept in LDS
+//    twice, rows interleaved in pairs starting at even rows (E) and at odd rows (O); a kernel row ky reads pair
+//    (2t + ky, 2t + ky + 1) from E or O by parity, 14 columns = 7 ds_read_b128 for 56 packed FMAs;
+//  * workgroup = 60 x 64 outputs (halo amplification 1.2x instead of 1.5x), 256 threads, 39 KB LDS -> 4 per CU;
+//  * `relu_in`: max(x, 0) applied while staging, so the caller can drop the separate ReLU pass after the preceding
+//    1x1 convolution (IntVOS.py:503-505: relu2 of the previous block) -- one HBM round trip less per block.
+// Tap order (ky outer, kx inner, fmaf chain per output) is the r1 kernel's and the oracle's: bit-identical.
 #include "manet_common.h"
 
 namespace {
 
 constexpr int DW_K = 7, DW_R = 3;
-constexpr int DW_TY = 16, DW_TX = 64;
-constexpr int DW_LW = 72;  // LDS row stride (>= DW_TX + 6, multiple of 4)
+constexpr int DW_TY = 60, DW_TX = 64;      // 60 rows: 480p's 120 and 720p's 180 grid rows tile exactly; 33 row pairs of LDS
+// LDS columns: image columns x0-4 .. x0+67 (even start: aligned float2 loads) = 72, padded to 74: the row-pair stride
+// 148 floats = 20 (mod 64 banks) puts the four (row pair, column group) quads of a ds_read_b128 lane group on disjoint
+// banks (stride 144: 4-way conflicts on every window read)
+constexpr int DW_LW = 74;
+constexpr int DW_NP = (DW_TY + 2 * DW_R) / 2;  // 35 row pairs per image (rows y0-3 .. y0+66)
+constexpr int DW_IMG = DW_NP * DW_LW * 2;    // floats per interleaved image
 
-__global__ __launch_bounds__(256) void dwconv7x7_bn_relu_kernel(const float *__restrict__ in, int C, int h, int w,
-                                                                const float *__restrict__ weight,
-                                                                const float *__restrict__ bias,
-                                                                const float *__restrict__ scale,
-                                                                const float *__restrict__ shift, int relu,
-                                                                float *__restrict__ out)
+// FAST: w even (every aligned column pair is inside or outside the image as a whole, rows are 8-byte aligned)
+template <bool FAST>
+__global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *__restrict__ in, int C, int h, int w,
+                                                                   const float *__restrict__ weight,
+                                                                   const float *__restrict__ bias,
+                                                                   const float *__restrict__ scale,
+                                                                   const float *__restrict__ shift, int relu,
+                                                                   int relu_in, float *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) float tile[(DW_TY + 2 * DW_R) * DW_LW];
+    // E: element (r, col) at ((r >> 1) * LW + col) * 2 + (r & 1), r = row - (y0 - 3); O: the same for r - 1
+    __shared__ __attribute__((aligned(16))) float tile[2 * DW_IMG];
     const int plane_id = blockIdx.z;  // b * C + c
     const int c = plane_id % C;
     const int x0 = blockIdx.x * DW_TX, y0 = blockIdx.y * DW_TY;
     const float *src = in + (long)plane_id * h * w;
     const int tid = threadIdx.x;
-    for (int i = tid; i < (DW_TY + 2 * DW_R) * (DW_TX + 2 * DW_R); i += 256) {
-        int r = i / (DW_TX + 2 * DW_R), col = i - r * (DW_TX + 2 * DW_R);
-        int yy = y0 - DW_R + r, xx = x0 - DW_R + col;
-        tile[r * DW_LW + col] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? src[(long)yy * w + xx] : 0.0f;
+    // staging item = (row pair p, column pair q): rows 2p, 2p+1, 2p+2 of the tile, two columns -- one b128 store into E
+    // (rows 2p, 2p+1) and one into O (rows 2p+1, 2p+2).  Branch-free: clamped addresses, values selected afterwards.
+    constexpr int NQ = 36, NITEM = DW_NP * NQ, KI = (NITEM + 255) / 256;  // 36 column pairs = image columns x0-4 .. x0+67
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+        const int i = tid + 256 * k;
+        const int p = i / NQ, q = i - p * NQ;
+        const int xx = x0 - 4 + 2 * q;
+        f32x2 rv[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int yy = y0 - DW_R + 2 * p + e;
+            const int yc = yy < 0 ? 0 : (yy < h ? yy : h - 1);
+            if (FAST) {
+                const int xc = xx < 0 ? 0 : (xx < w ? xx : w - 2);
+                int idx = yc * w + xc;
+                asm volatile("" : "+v"(idx));  // keep the clamp a clamp: no branch, no vmcnt(0) per element
+                const f32x2 t = *(const f32x2 *)(src + idx);
+                const bool ok = (yy == yc) && (xx == xc) && i < NITEM;
+                rv[e] = ok ? t : f32x2{0.0f, 0.0f};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int xj = xx + j, xc = xj < 0 ? 0 : (xj < w ? xj : w - 1);
+                    int idx = yc * w + xc;
+                    asm volatile("" : "+v"(idx));
+                    const float t = src[idx];
+                    rv[e][j] = ((yy == yc) && (xj == xc) && i < NITEM) ? t : 0.0f;
+                }
+            }
+            if (relu_in) rv[e] = __builtin_elementwise_max(rv[e], f32x2{0.0f, 0.0f});
+        }
+        if (i < NITEM) {
+            float *d = tile + (p * DW_LW + 2 * q) * 2;
+            *(f32x4 *)d = f32x4{rv[0][0], rv[1][0], rv[0][1], rv[1][1]};
+            *(f32x4 *)(d + DW_IMG) = f32x4{rv[1][0], rv[2][0], rv[1][1], rv[2][1]};
+        }
     }
     __syncthreads();
-    const int ty = tid >> 4, tg = tid & 15;  // output row, group of 4 columns
+    const int t = tid >> 3, tg = tid & 7;  // output row pair (2t, 2t+1), group of 8 columns
+    if (t >= DW_TY / 2) return;            // (no barrier below)
     const float *wk = weight + (long)c * DW_K * DW_K;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    f32x2 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x2{0.0f, 0.0f};
 #pragma unroll
     for (int ky = 0; ky < DW_K; ++ky) {
-        const float *row = tile + (ty + ky) * DW_LW + 4 * tg;
-        f32x4 v0 = *(const f32x4 *)row, v1 = *(const f32x4 *)(row + 4);
-        float v8 = row[8], v9 = row[9];
-        float win[10] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3], v8, v9};
+        // input rows (2t + ky, 2t + ky + 1): pair t + ky/2 of E (ky even) or pair t + (ky-1)/2 of O (ky odd); output
+        // column 8 tg + j, tap kx reads LDS column 8 tg + j + kx + 1 (LDS column 0 is image column x0 - 4)
+        const float *row = tile + ((ky & 1) ? DW_IMG : 0) + ((t + (ky >> 1)) * DW_LW + 8 * tg) * 2;
+        // (ties the reads of this kernel row behind the previous row's arithmetic: the fully unrolled loop otherwise
+        // holds all the reads in flight and the register count halves the occupancy)
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])::"memory");
+        f32x2 win[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 u = *(const f32x4 *)(row + 4 * i);
+            win[2 * i] = f32x2{u[0], u[1]};
+            win[2 * i + 1] = f32x2{u[2], u[3]};
+        }
 #pragma unroll
         for (int kx = 0; kx < DW_K; ++kx) {
             const float wv = wk[ky * DW_K + kx];
-            a0 = fmaf(win[kx], wv, a0);
-            a1 = fmaf(win[kx + 1], wv, a1);
-            a2 = fmaf(win[kx + 2], wv, a2);
-            a3 = fmaf(win[kx + 3], wv, a3);
+            const f32x2 w2 = {wv, wv};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_elementwise_fma(win[kx + j + 1], w2, acc[j]);
         }
     }
-    const int y = y0 + ty, x = x0 + 4 * tg;
-    if (y >= h) return;
     const float bc = bias ? bias[c] : 0.0f, sc = scale ? scale[c] : 1.0f, sh = shift ? shift[c] : 0.0f;
-    float r[4] = {a0, a1, a2, a3};
-    float *dst = out + (long)plane_id * h * w + (long)y * w + x;
+    const int x = x0 + 8 * tg;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (x + j < w) {
-            float v = fmaf(r[j] + bc, sc, sh);
-            dst[j] = relu ? fmaxf(v, 0.0f) : v;
+    for (int e = 0; e < 2; ++e) {
+        const int y = y0 + 2 * t + e;
+        if (y >= h) continue;
+        float *dst = out + (long)plane_id * h * w + (long)y * w + x;
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float o = fmaf(acc[j][e] + bc, sc, sh);
+            r[j] = relu ? fmaxf(o, 0.0f) : o;
+        }
+        if (x + 7 < w && (((size_t)dst & 15) == 0)) {
+            *(f32x4 *)dst = f32x4{r[0], r[1], r[2], r[3]};
+            *(f32x4 *)(dst + 4) = f32x4{r[4], r[5], r[6], r[7]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (x + j < w) dst[j] = r[j];
         }
     }
 }
@@ -77,10 +149,22 @@ extern "C" int manet_dwconv7x7_bn_relu_f32(const float *in, int B, int C, int h,
                                            const float *bias, const float *bn_scale, const float *bn_shift, int relu,
                                            float *out, manet_stream_t stream)
 {
+    return manet_dwconv7x7_bn_relu_ex(in, B, C, h, w, weight, bias, bn_scale, bn_shift, relu, 0, out, stream);
+}
+
+// relu_in != 0: the input is read through max(x, 0) (the preceding block's ReLU folded into this pass)
+extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, int w, const float *weight,
+                                          const float *bias, const float *bn_scale, const float *bn_shift, int relu,
+                                          int relu_in, float *out, manet_stream_t stream)
+{
     if (!in || !weight || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || (long)B * C > 65535)
         return manet_set_error(MANET_E_INVALID, "bad arguments (B*C must be <= 65535)");
     dim3 grid((unsigned)((w + DW_TX - 1) / DW_TX), (unsigned)((h + DW_TY - 1) / DW_TY), (unsigned)(B * C));
-    hipLaunchKernelGGL(dwconv7x7_bn_relu_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, C, h, w, weight, bias,
-                       bn_scale, bn_shift, relu, out);
+    if (w % 2 == 0 && w >= 2 && ((size_t)in & 7) == 0)
+        hipLaunchKernelGGL(dwconv7x7_bn_relu_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, C, h, w, weight,
+                           bias, bn_scale, bn_shift, relu, relu_in, out);
+    else
+        hipLaunchKernelGGL(dwconv7x7_bn_relu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, C, h, w, weight,
+                           bias, bn_scale, bn_shift, relu, relu_in, out);
     return manet_check_launch("manet_dwconv7x7_bn_relu_f32");
 }

@@ -210,36 +210,56 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         return (not self.training and x.is_cuda and not torch.is_grad_enabled()
                 and self.conv1.kernel_size == (7, 7) and x.dtype == torch.float32)
 
-    def _folded_conv2(self):
-        """conv2 with eval-mode bn2 folded into its weights: bn2(conv2(x)) == conv2'(x)"""
-        scale, shift = ops.fold_bn(self.bn2)
-        w = self.conv2.weight * scale[:, None, None, None]
-        b = self.conv2.bias * scale + shift if self.conv2.bias is not None else shift
-        return w, b
+    def _folded(self, cs=0):
+        """Inference constants of the block, computed once and reused until a parameter or running statistic changes
+        (r2 trace of examples/propagate_clip.py: re-folding both BatchNorms per call was 52 of the 76 kernel launches
+        of a propagated frame).  Returns (scale1, shift1) of eval-mode bn1 and conv2 with eval-mode bn2 folded into
+        its weights -- bn2(conv2(x)) == conv2'(x) -- the latter also split at input channel `cs` (forward_shared)."""
+        src = [self.bn1.weight, self.bn1.bias, self.bn1.running_mean, self.bn1.running_var, self.bn2.weight,
+               self.bn2.bias, self.bn2.running_mean, self.bn2.running_var, self.conv2.weight, self.conv2.bias]
+        key = (cs,) + tuple((t.data_ptr(), t._version) if t is not None else None for t in src)
+        hit = getattr(self, "_fold_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        with torch.no_grad():
+            scale1, shift1 = ops.fold_bn(self.bn1)
+            scale2, shift2 = ops.fold_bn(self.bn2)
+            w2 = (self.conv2.weight.detach().float() * scale2[:, None, None, None]).contiguous()
+            b2 = (self.conv2.bias.detach().float() * scale2 + shift2 if self.conv2.bias is not None else shift2).contiguous()
+            val = {"scale1": scale1.contiguous(), "shift1": shift1.contiguous(), "w2": w2, "b2": b2,
+                   "w2_shared": w2[:, :cs].contiguous(), "w2_object": w2[:, cs:].contiguous()}
+        object.__setattr__(self, "_fold_cache", (key, val))  # plain attribute: not a buffer, not in the state dict
+        return val
 
-    def forward(self, x):
+    def forward(self, x, relu_in=False, defer_relu=False):
+        """relu_in / defer_relu (inference fast path only, used by DynamicSegHead): the block's last ReLU is left to the
+        NEXT block, whose fused depthwise kernel reads its input through max(x, 0) -- one elementwise pass over the
+        activation less per block, same values."""
         if self._fast(x):
-            x = ops.dwconv7x7_bn_relu(x, self.conv1.weight, self.conv1.bias, self.bn1)
-            w, b = self._folded_conv2()
-            return F.conv2d(x, w, b).relu_()
+            k = self._folded()
+            x = ops.dwconv7x7_bn_relu(x, self.conv1.weight, self.conv1.bias, scale=k["scale1"], shift=k["shift1"],
+                                      relu_in=relu_in)
+            y = F.conv2d(x, k["w2"], k["b2"])
+            return y if defer_relu else y.relu_()
+        assert not relu_in and not defer_relu
         x = self.relu1(self.bn1(self.conv1(x)))
         x = self.relu2(self.bn2(self.conv2(x)))
         return x
 
-    def forward_shared(self, shared, per_object):
+    def forward_shared(self, shared, per_object, defer_relu=False):
         """The block applied to cat([shared repeated n times, per_object], 1) without building that tensor
         (IntVOS.py:665-670 repeats the C-channel embedding once per object): the depthwise stage and the
         1x1 stage are linear in the channel groups, so the shared group is processed once.
         shared [1, Cs, h, w], per_object [n, Cp, h, w], Cs + Cp == in_dim."""
         cs = shared.shape[1]
-        scale, shift = ops.fold_bn(self.bn1)
+        k = self._folded(cs)
+        scale, shift = k["scale1"], k["shift1"]
         w1, b1 = self.conv1.weight, self.conv1.bias
         s1 = ops.dwconv7x7_bn_relu(shared, w1[:cs], b1[:cs], scale=scale[:cs], shift=shift[:cs])
         p1 = ops.dwconv7x7_bn_relu(per_object, w1[cs:], b1[cs:], scale=scale[cs:], shift=shift[cs:])
-        w2, b2 = self._folded_conv2()
-        y = F.conv2d(p1, w2[:, cs:], b2)
-        y += F.conv2d(s1, w2[:, :cs])  # broadcast over the objects
-        return y.relu_()
+        y = F.conv2d(p1, k["w2_object"], k["b2"])
+        y += F.conv2d(s1, k["w2_shared"])  # broadcast over the objects
+        return y if defer_relu else y.relu_()
 
 
 class DynamicSegHead(nn.Module):  # reference IntVOS.py:509-525
@@ -254,12 +274,21 @@ class DynamicSegHead(nn.Module):  # reference IntVOS.py:509-525
         self.conv = nn.Conv2d(embed_dim, 1, 1, 1)
         nn.init.kaiming_normal_(self.conv.weight, mode="fan_out", nonlinearity="relu")
 
+    def _tail(self, x):
+        """layers 2-4 + the 1x1 output conv on the inference fast path; x = layer1's output BEFORE its last ReLU
+        (each block's ReLU is applied by the next block's fused depthwise kernel as it reads)"""
+        x = self.layer2(x, relu_in=True, defer_relu=True)
+        x = self.layer3(x, relu_in=True, defer_relu=True)
+        return self.conv(self.layer4(x, relu_in=True))
+
     def forward(self, x):
+        if self.layer1._fast(x):
+            return self._tail(self.layer1(x, defer_relu=True))
         return self.conv(self.layer4(self.layer3(self.layer2(self.layer1(x)))))
 
     def forward_shared(self, shared, per_object):
         """forward(cat([shared.repeat(n,1,1,1), per_object], 1)) without materialising the input"""
-        return self.conv(self.layer4(self.layer3(self.layer2(self.layer1.forward_shared(shared, per_object)))))
+        return self._tail(self.layer1.forward_shared(shared, per_object, defer_relu=True))
 
 
 def _run_head(head, embedding_chw, per_object):

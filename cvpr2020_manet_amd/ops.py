@@ -411,11 +411,12 @@ def fold_bn(bn):
     return scale, b - bn.running_mean.detach().float() * scale
 
 
-def dwconv7x7_bn_relu(x, weight, bias=None, bn=None, relu=True, scale=None, shift=None):
+def dwconv7x7_bn_relu(x, weight, bias=None, bn=None, relu=True, scale=None, shift=None, relu_in=False):
     """Depthwise 7x7 conv (padding 3) + bias + eval-mode BatchNorm + ReLU in one HIP kernel
     (IntVOS.py:491-493,500-502: conv1 -> bn1 -> relu1 of _split_separable_conv2d).
     x [B, C, h, w] fp32; weight [C, 1, 7, 7]; bn: an nn.BatchNorm2d in eval mode, or explicit per-channel
-    `scale` / `shift` (fold_bn), or neither."""
+    `scale` / `shift` (fold_bn), or neither.  relu_in: read the input through max(x, 0) (the preceding block's
+    relu2 folded into this pass)."""
     _refuse_autograd("dwconv7x7_bn_relu", x, weight, bias, scale, shift)  # callers use it under no_grad only
     lib = _lib.load()
     _need_gpu(x, "x")
@@ -431,10 +432,10 @@ def dwconv7x7_bn_relu(x, weight, bias=None, bn=None, relu=True, scale=None, shif
     bz = None if bias is None else bias.detach().float().contiguous()
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
-        rc = lib.manet_dwconv7x7_bn_relu_f32(x.data_ptr(), B, C, h, w, wt.data_ptr(),
-                                             None if bz is None else bz.data_ptr(),
-                                             None if scale is None else scale.data_ptr(),
-                                             None if shift is None else shift.data_ptr(), int(bool(relu)),
-                                             out.data_ptr(), _stream_ptr(x.device))
-    _lib.check(rc, "manet_dwconv7x7_bn_relu_f32")
+        rc = lib.manet_dwconv7x7_bn_relu_ex(x.data_ptr(), B, C, h, w, wt.data_ptr(),
+                                            None if bz is None else bz.data_ptr(),
+                                            None if scale is None else scale.data_ptr(),
+                                            None if shift is None else shift.data_ptr(), int(bool(relu)),
+                                            int(bool(relu_in)), out.data_ptr(), _stream_ptr(x.device))
+    _lib.check(rc, "manet_dwconv7x7_bn_relu_ex")
     return out

@@ -225,6 +225,12 @@ int manet_upsample_argmax(const float *logits, int n_ids, int h, int w, int H, i
 int manet_dwconv7x7_bn_relu_f32(const float *in, int B, int C, int h, int w, const float *weight,
                                 const float *bias, const float *bn_scale, const float *bn_shift, int relu,
                                 float *out, manet_stream_t stream);
+/* The same with relu_in: when non-zero the input is read through max(x, 0) -- relu2 of the PRECEDING
+ * _split_separable_conv2d (networks/IntVOS.py:503-505) folded into this pass, so the caller can leave that block's
+ * 1x1 convolution output un-rectified and save one elementwise pass over the activation. */
+int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, int w, const float *weight,
+                               const float *bias, const float *bn_scale, const float *bn_shift, int relu,
+                               int relu_in, float *out, manet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Training path: what torch.autograd does for the reference's pure-PyTorch path
