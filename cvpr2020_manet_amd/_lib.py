@@ -36,6 +36,7 @@ SIGNATURES = {
     "manet_correlation_out_dims": (_i, [_i, _i, _i, _i, _i, _i, _i, _ip, _ip, _ip]),
     "manet_upsample_argmax": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "manet_dwconv7x7_bn_relu_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "manet_relu_conv1x1_c1_f32": (_i, [_vp, _i, _i, ctypes.c_long, _vp, _vp, _i, _vp, _vp]),
     "manet_dwconv7x7_bn_relu_ex": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "manet_profile_begin": (_i, [_i]),
     "manet_tune_set": (_i, [_i, _i]),

@@ -143,7 +143,84 @@ __global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *
     }
 }
 
+// DynamicSegHead's output layer (IntVOS.py:519,525: conv = Conv2d(embed_dim, 1, 1) applied to layer4's ReLU output):
+//   out[b][p] = bias + sum_c w[c] * max(in[b][c][p], 0)
+// a pure stream over the [B][C][HW] activation (79 MB at [3,256,120,214]: 10 us at 8 TB/s).  The framework runs it as
+// clamp (22 us) + two layout transposes (31 us) + an implicit-GEMM with N = 1 (19 us).  Here: a workgroup owns 256 pixels
+// (64 lanes x float4), its 4 waves split the channels; 8 independent float4 loads in flight per lane; the waves' partial
+// sums meet in LDS.  Per output the sum is ((w0 + w1) + (w2 + w3)) of four ascending fmaf chains.
+constexpr int RC_WAVES = 4;
+__global__ __launch_bounds__(64 * RC_WAVES) void relu_conv1x1_c1_kernel(const float *__restrict__ in, int C, long HW,
+                                                                       const float *__restrict__ weight,
+                                                                       const float *__restrict__ bias, int relu_in,
+                                                                       float *__restrict__ out)
+{
+    __shared__ f32x4 part[RC_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const long p0 = ((long)blockIdx.x * 64 + lane) * 4;
+    const bool vec = (HW % 4 == 0) && p0 + 3 < HW;  // rows of whole float4 (16-byte aligned planes)
+    const float *src = in + (long)b * C * HW;
+    const int cper = (C + RC_WAVES - 1) / RC_WAVES, c0 = wave * cper, c1 = (c0 + cper < C) ? c0 + cper : C;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (vec) {
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4 *)(src + (long)(c + u) * HW + p0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float wv = weight[c + u];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(relu_in ? fmaxf(v[u][j], 0.0f) : v[u][j], wv, acc[j]);
+            }
+        }
+        for (; c < c1; ++c) {
+            const f32x4 v = *(const f32x4 *)(src + (long)c * HW + p0);
+            const float wv = weight[c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(relu_in ? fmaxf(v[j], 0.0f) : v[j], wv, acc[j]);
+        }
+    } else {
+        for (int c = c0; c < c1; ++c) {
+            const float wv = weight[c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (p0 + j < HW) {
+                    const float v = src[(long)c * HW + p0 + j];
+                    acc[j] = fmaf(relu_in ? fmaxf(v, 0.0f) : v, wv, acc[j]);
+                }
+            }
+        }
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        const f32x4 s01 = part[0][lane] + part[1][lane], s23 = part[2][lane] + part[3][lane];
+        const float bz = bias ? bias[0] : 0.0f;
+        const f32x4 r = (s01 + s23) + f32x4{bz, bz, bz, bz};
+        float *dst = out + (long)b * HW + p0;
+        if (vec) *(f32x4 *)dst = r;
+        else
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (p0 + j < HW) dst[j] = r[j];
+    }
+}
+
 }  // namespace
+
+extern "C" int manet_relu_conv1x1_c1_f32(const float *in, int B, int C, long HW, const float *weight, const float *bias,
+                                         int relu_in, float *out, manet_stream_t stream)
+{
+    if (!in || !weight || !out || B <= 0 || C <= 0 || HW <= 0 || B > 65535)
+        return manet_set_error(MANET_E_INVALID, "bad arguments");
+    dim3 grid((unsigned)((HW + 255) / 256), (unsigned)B);
+    hipLaunchKernelGGL(relu_conv1x1_c1_kernel, grid, dim3(64 * RC_WAVES), 0, (hipStream_t)stream, in, C, HW, weight, bias,
+                       relu_in, out);
+    return manet_check_launch("manet_relu_conv1x1_c1_f32");
+}
 
 extern "C" int manet_dwconv7x7_bn_relu_f32(const float *in, int B, int C, int h, int w, const float *weight,
                                            const float *bias, const float *bn_scale, const float *bn_shift, int relu,

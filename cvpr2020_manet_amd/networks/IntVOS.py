@@ -279,6 +279,9 @@ class DynamicSegHead(nn.Module):  # reference IntVOS.py:509-525
         (each block's ReLU is applied by the next block's fused depthwise kernel as it reads)"""
         x = self.layer2(x, relu_in=True, defer_relu=True)
         x = self.layer3(x, relu_in=True, defer_relu=True)
+        if self.conv.kernel_size == (1, 1) and self.conv.out_channels == 1:
+            # output layer fused with layer4's ReLU: one pass over the activation (ops.relu_conv1x1_c1)
+            return ops.relu_conv1x1_c1(self.layer4(x, relu_in=True, defer_relu=True), self.conv.weight, self.conv.bias)
         return self.conv(self.layer4(x, relu_in=True))
 
     def forward(self, x):

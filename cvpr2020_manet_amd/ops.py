@@ -439,3 +439,23 @@ def dwconv7x7_bn_relu(x, weight, bias=None, bn=None, relu=True, scale=None, shif
                                             int(bool(relu_in)), out.data_ptr(), _stream_ptr(x.device))
     _lib.check(rc, "manet_dwconv7x7_bn_relu_ex")
     return out
+
+
+def relu_conv1x1_c1(x, weight, bias=None, relu_in=True):
+    """DynamicSegHead's output layer in one pass over the activation (IntVOS.py:519,525): Conv2d(C, 1, 1) applied to
+    max(x, 0) (relu_in) or to x.  x [B, C, h, w] fp32, weight [1, C, 1, 1], bias [1] or None -> [B, 1, h, w]."""
+    _refuse_autograd("relu_conv1x1_c1", x, weight, bias)
+    lib = _lib.load()
+    _need_gpu(x, "x")
+    x = x.float().contiguous()
+    B, C, h, w = x.shape
+    if weight.numel() != C:
+        raise ValueError("weight must be [1, C, 1, 1]")
+    wt = weight.detach().float().contiguous()
+    bz = None if bias is None else bias.detach().float().contiguous()
+    out = torch.empty((B, 1, h, w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.manet_relu_conv1x1_c1_f32(x.data_ptr(), B, C, h * w, wt.data_ptr(), None if bz is None else bz.data_ptr(),
+                                           int(bool(relu_in)), out.data_ptr(), _stream_ptr(x.device))
+    _lib.check(rc, "manet_relu_conv1x1_c1_f32")
+    return out

@@ -25,6 +25,7 @@
  *                             and correlation_cuda.backward (correlation_cuda.cc:89-167)
  *   manet_upsample_argmax     test.py:253-255 + networks/IntVOS.py:598-599
  *   manet_dwconv7x7_bn_relu_f32  networks/IntVOS.py:491-493,500-502
+ *   manet_relu_conv1x1_c1_f32    networks/IntVOS.py:519,525
  *
  * NaN inputs (outside the reference's contract, documented deviation): the global match propagates a NaN
  * distance to the output like torch.min does, but a NaN bank row poisons only its own object (in the reference
@@ -231,6 +232,12 @@ int manet_dwconv7x7_bn_relu_f32(const float *in, int B, int C, int h, int w, con
 int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, int w, const float *weight,
                                const float *bias, const float *bn_scale, const float *bn_shift, int relu,
                                int relu_in, float *out, manet_stream_t stream);
+
+/* DynamicSegHead's output layer, fused (networks/IntVOS.py:519,525: Conv2d(embed_dim, 1, kernel 1) on layer4's ReLU
+ * output): out[b][p] = bias[0] + sum_c weight[c] * (relu_in ? max(in[b][c][p], 0) : in[b][c][p]).
+ * in [B][C][HW] fp32 contiguous, weight [C], bias [1] or NULL, out [B][HW]. */
+int manet_relu_conv1x1_c1_f32(const float *in, int B, int C, long HW, const float *weight, const float *bias,
+                              int relu_in, float *out, manet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Training path: what torch.autograd does for the reference's pure-PyTorch path
