@@ -54,36 +54,44 @@ __global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *
     // staging item = (row pair p, column pair q): rows 2p, 2p+1, 2p+2 of the tile, two columns -- one b128 store into E
     // (rows 2p, 2p+1) and one into O (rows 2p+1, 2p+2).  Branch-free: clamped addresses, values selected afterwards.
     constexpr int NQ = 36, NITEM = DW_NP * NQ, KI = (NITEM + 255) / 256;  // 36 column pairs = image columns x0-4 .. x0+67
+    // pass 1: every load of the thread is issued (clamped addresses, no predicate anywhere near them); pass 2 selects,
+    // rectifies and stores.  Written as one loop, hipcc sinks each load into the branch of its select and waits
+    // vmcnt(0) there: 15 serial L2 round trips per thread (r2 trace: this, not the 392 FMAs, was the kernel's time).
+    f32x2 ld[KI][3];
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
         const int i = tid + 256 * k;
         const int p = i / NQ, q = i - p * NQ;
         const int xx = x0 - 4 + 2 * q;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int yc = min(max(y0 - DW_R + 2 * p + e, 0), h - 1);
+            if (FAST) {
+                ld[k][e] = *(const f32x2 *)(src + yc * w + min(max(xx, 0), w - 2));
+            } else {
+                ld[k][e][0] = src[yc * w + min(max(xx, 0), w - 1)];
+                ld[k][e][1] = src[yc * w + min(max(xx + 1, 0), w - 1)];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KI; ++k) asm volatile("" : "+v"(ld[k][0]), "+v"(ld[k][1]), "+v"(ld[k][2]));
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+        const int i = tid + 256 * k;
+        const int p = i / NQ, q = i - p * NQ;
+        const int xx = x0 - 4 + 2 * q;
+        const bool iok = i < NITEM;
         f32x2 rv[3];
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
             const int yy = y0 - DW_R + 2 * p + e;
-            const int yc = yy < 0 ? 0 : (yy < h ? yy : h - 1);
-            if (FAST) {
-                const int xc = xx < 0 ? 0 : (xx < w ? xx : w - 2);
-                int idx = yc * w + xc;
-                asm volatile("" : "+v"(idx));  // keep the clamp a clamp: no branch, no vmcnt(0) per element
-                const f32x2 t = *(const f32x2 *)(src + idx);
-                const bool ok = (yy == yc) && (xx == xc) && i < NITEM;
-                rv[e] = ok ? t : f32x2{0.0f, 0.0f};
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int xj = xx + j, xc = xj < 0 ? 0 : (xj < w ? xj : w - 1);
-                    int idx = yc * w + xc;
-                    asm volatile("" : "+v"(idx));
-                    const float t = src[idx];
-                    rv[e][j] = ((yy == yc) && (xj == xc) && i < NITEM) ? t : 0.0f;
-                }
-            }
+            const bool yok = yy >= 0 && yy < h && iok;
+            rv[e][0] = (yok && xx >= 0 && xx < w) ? ld[k][e][0] : 0.0f;
+            rv[e][1] = (yok && xx + 1 >= 0 && xx + 1 < w) ? ld[k][e][1] : 0.0f;
             if (relu_in) rv[e] = __builtin_elementwise_max(rv[e], f32x2{0.0f, 0.0f});
         }
-        if (i < NITEM) {
+        if (iok) {
             float *d = tile + (p * DW_LW + 2 * q) * 2;
             *(f32x4 *)d = f32x4{rv[0][0], rv[1][0], rv[0][1], rv[1][1]};
             *(f32x4 *)(d + DW_IMG) = f32x4{rv[1][0], rv[2][0], rv[1][1], rv[2][1]};
@@ -132,9 +140,9 @@ __global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *
             const float o = fmaf(acc[j][e] + bc, sc, sh);
             r[j] = relu ? fmaxf(o, 0.0f) : o;
         }
-        if (x + 7 < w && (((size_t)dst & 15) == 0)) {
-            *(f32x4 *)dst = f32x4{r[0], r[1], r[2], r[3]};
-            *(f32x4 *)(dst + 4) = f32x4{r[4], r[5], r[6], r[7]};
+        if (FAST && x + 7 < w) {  // w even, plane 8-byte aligned: float2 stores are always aligned
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) *(f32x2 *)(dst + j) = f32x2{r[j], r[j + 1]};
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -237,7 +245,7 @@ extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, 
     if (!in || !weight || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || (long)B * C > 65535)
         return manet_set_error(MANET_E_INVALID, "bad arguments (B*C must be <= 65535)");
     dim3 grid((unsigned)((w + DW_TX - 1) / DW_TX), (unsigned)((h + DW_TY - 1) / DW_TY), (unsigned)(B * C));
-    if (w % 2 == 0 && w >= 2 && ((size_t)in & 7) == 0)
+    if (w % 2 == 0 && w >= 2 && ((size_t)in & 7) == 0 && ((size_t)out & 7) == 0)
         hipLaunchKernelGGL(dwconv7x7_bn_relu_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, C, h, w, weight,
                            bias, bn_scale, bn_shift, relu, relu_in, out);
     else
