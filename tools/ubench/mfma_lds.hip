@@ -9,7 +9,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int PASSES = 2000;
 
-template <int MODE>  // 3: burst of 7 reads, then 28 MFMAs; 0: no reads; 1: 7 reads per pass into registers nobody uses; 2: 7 reads per pass feeding the next pass
+template <int MODE>  // 4: interleaved reads into AGPRs; 3: burst of 7 reads, then 28 MFMAs; 0: no reads; 1: 7 reads per pass into registers nobody uses; 2: 7 reads per pass feeding the next pass
 __global__ __launch_bounds__(512) void k(float *out, const unsigned *seed)
 {
     __shared__ __attribute__((aligned(16))) unsigned lds[8192];
@@ -40,7 +40,54 @@ __global__ __launch_bounds__(512) void k(float *out, const unsigned *seed)
             for (int kk = 0; kk < 7; ++kk) { u32x4 t = a[kk]; a[kk] = spare[kk]; spare[kk] = t; }
             continue;
         }
-        if (MODE == 4) {  // interleaved, but ds_read_b64 x 2 ... (same bytes, twice the instructions)
+        if (MODE == 8 || MODE == 9) {
+            // 8 = B (query) operands in AccVGPRs, accumulators and fragment reads in ArchVGPRs; 9 = B and fragments in AccVGPRs
+#pragma unroll
+            for (int kk = 0; kk < 7; ++kk) {
+                const unsigned addr = (unsigned)(size_t)(base + ((p + kk) & 7) * 256);
+                if (MODE == 8)
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %6, %1\n\t"
+                                 "v_mfma_f32_32x32x16_bf16 %2, %4, %7, %2\n\tv_mfma_f32_32x32x16_bf16 %3, %4, %8, %3\n\t"
+                                 "ds_read_b128 %4, %9"
+                                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(a[kk])
+                                 : "a"(b[0][kk]), "a"(b[1][kk]), "a"(b[2][kk]), "a"(b[3][kk]), "v"(addr) : "memory");
+                else
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %6, %1\n\t"
+                                 "v_mfma_f32_32x32x16_bf16 %2, %4, %7, %2\n\tv_mfma_f32_32x32x16_bf16 %3, %4, %8, %3\n\t"
+                                 "ds_read_b128 %4, %9"
+                                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+a"(a[kk])
+                                 : "a"(b[0][kk]), "a"(b[1][kk]), "a"(b[2][kk]), "a"(b[3][kk]), "v"(addr) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            continue;
+        }
+        if (MODE == 5 || MODE == 6 || MODE == 7) {
+            // explicit register classes: 5 = accumulators in ArchVGPRs, fragments read into AccVGPRs;
+            // 6 = accumulators in AccVGPRs, fragments read into ArchVGPRs; 7 = accumulators in AccVGPRs, no reads
+#pragma unroll
+            for (int kk = 0; kk < 7; ++kk) {
+                const unsigned addr = (unsigned)(size_t)(base + ((p + kk) & 7) * 256);
+                if (MODE == 5) {
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %6, %1\n\t"
+                                 "v_mfma_f32_32x32x16_bf16 %2, %4, %7, %2\n\tv_mfma_f32_32x32x16_bf16 %3, %4, %8, %3\n\t"
+                                 "ds_read_b128 %4, %9"
+                                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+a"(a[kk])
+                                 : "v"(b[0][kk]), "v"(b[1][kk]), "v"(b[2][kk]), "v"(b[3][kk]), "v"(addr) : "memory");
+                } else if (MODE == 6) {
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %6, %1\n\t"
+                                 "v_mfma_f32_32x32x16_bf16 %2, %4, %7, %2\n\tv_mfma_f32_32x32x16_bf16 %3, %4, %8, %3\n\t"
+                                 "ds_read_b128 %4, %9"
+                                 : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3), "+v"(a[kk])
+                                 : "v"(b[0][kk]), "v"(b[1][kk]), "v"(b[2][kk]), "v"(b[3][kk]), "v"(addr) : "memory");
+                } else {
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %6, %1\n\t"
+                                 "v_mfma_f32_32x32x16_bf16 %2, %4, %7, %2\n\tv_mfma_f32_32x32x16_bf16 %3, %4, %8, %3"
+                                 : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3)
+                                 : "v"(a[kk]), "v"(b[0][kk]), "v"(b[1][kk]), "v"(b[2][kk]), "v"(b[3][kk]));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            continue;
         }
 #pragma unroll
         for (int kk = 0; kk < 7; ++kk) {
@@ -50,6 +97,10 @@ __global__ __launch_bounds__(512) void k(float *out, const unsigned *seed)
             c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kk]), __builtin_bit_cast(bf16x8, b[3][kk]), c3, 0, 0, 0);
             if (MODE == 1) spare[kk] = *(const volatile u32x4 *)(base + ((p + kk) & 7) * 256);
             if (MODE == 2) a[kk] = *(const volatile u32x4 *)(base + ((p + kk) & 7) * 256);
+            if (MODE == 4) {  // the same refill, but the LDS data lands in AccVGPRs (the MFMA reads its A operand from there)
+                const unsigned addr = (unsigned)(size_t)(base + ((p + kk) & 7) * 256);
+                asm volatile("ds_read_b128 %0, %1" : "=a"(a[kk]) : "v"(addr) : "memory");
+            }
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
@@ -64,8 +115,8 @@ int main()
 {
     float *out; unsigned *seed;
     hipMalloc(&out, 4 << 20); hipMalloc(&seed, 1024); hipMemset(seed, 0x11, 1024);
-    const char *names[4] = {"no LDS reads", "7 ds_read_b128 per pass, results unused by MFMA", "7 ds_read_b128 per pass feeding the next pass's A operand", "7 ds_read_b128 in one burst per pass, feeding the next pass"};
-    for (int mode = 0; mode < 4; ++mode)
+    const char *names[10] = {"no LDS reads", "7 ds_read_b128 per pass, results unused by MFMA", "7 ds_read_b128 per pass feeding the next pass's A operand", "7 ds_read_b128 in one burst per pass, feeding the next pass", "7 ds_read_b128 per pass into AccVGPRs, feeding the next pass", "asm: acc in ArchVGPR, 7 reads per pass into AccVGPR", "asm: acc in AccVGPR, 7 reads per pass into ArchVGPR", "asm: acc in AccVGPR, no reads", "asm: B (query) in AccVGPR, acc + 7 reads per pass in ArchVGPR", "asm: B and the 7 reads per pass in AccVGPR, acc in ArchVGPR"};
+    for (int mode = 4; mode < 10; ++mode)
         for (int wps = 1; wps <= 2; ++wps) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             for (int rep = 0; rep < 2; ++rep) {
@@ -74,6 +125,12 @@ int main()
                 if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
                 if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
                 if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
+                if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
+                if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
+                if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
+                if (mode == 7) hipLaunchKernelGGL(k<7>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
+                if (mode == 8) hipLaunchKernelGGL(k<8>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
+                if (mode == 9) hipLaunchKernelGGL(k<9>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
             }
             hipEventRecord(e1, 0); hipDeviceSynchronize();
             float ms = 0; hipEventElapsedTime(&ms, e0, e1);
