@@ -1300,6 +1300,7 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
                                                                         unsigned *__restrict__ keys, int block_map,
                                                                         int young_prio)
 {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     constexpr int NW = 4, TPS = 2, NQB = 4;  // waves, tiles per step, query blocks per wave
     constexpr int UNITS = 2 * KSB;
     constexpr size_t TILE_BYTES = bank_tile_bytes_u(UNITS, false);  // = UNITS KiB
@@ -1347,27 +1348,20 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     stage_dma(t0, 0, true);
     if (t0 + TPS < t1) stage_dma(t0 + TPS, 1, true);
 
-    // The query operand lives in AccVGPRs for the whole kernel (112 of the 128 a wave has at two waves per SIMD):
-    // `global_load_dwordx4 a[..]` from inline asm, read by the MFMAs as srcB straight from there.
-    // tools/ubench/mfma_lds.hip: with every register an ArchVGPR each 1 KiB fragment read costs the matrix pipe about
-    // one MFMA slot (this pass structure: 20.8 ns per MFMA per SIMD = 1.61 PF -- exactly where this kernel stood);
-    // with the B operand in AccVGPRs the same stream, fragment reads included, runs at 15.3 ns (2.19 PF).
-    // The loads are invisible to hipcc's waitcnt bookkeeping: the prologue's vmcnt(0) below covers them, and the
-    // "+a" ties after it keep every MFMA behind that wait.
     u32x4 q[NQB][KSB];
     {
-        // scalar base (wave-uniform) + one 32-bit lane offset: no per-load address VGPRs
         const char *qb = qpack + (size_t)(qt * (QTB / QB) + wave * NQB) * QBLK_BYTES;
-        const unsigned lane_off = (unsigned)((h * QB + l31) * 16);
 #pragma unroll
         for (int j = 0; j < NQB; ++j)
 #pragma unroll
-            for (int k = 0; k < KSB; ++k) {
-                const char *sb = qb + (size_t)j * QBLK_BYTES + (size_t)k * (2 * QB * 16);
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(q[j][k]) : "v"(lane_off), "s"(sb) : "memory");
-            }
+            for (int k = 0; k < KSB; ++k)
+                q[j][k] = *(const u32x4 *)(qb + (size_t)j * QBLK_BYTES + ((size_t)(k * 2 + h) * QB + l31) * 16);
     }
     const long qbase = (long)qt * QTB + wave * (NQB * QB) + l31;
+#pragma unroll
+    for (int j = 0; j < NQB; ++j)
+#pragma unroll
+        for (int k = 0; k < KSB; ++k) asm volatile("" : "+v"(q[j][k]));  // compiler waits for q here
 
     int o = 0;
     while (meta[META_SEG + o + 1] <= t0) ++o;
@@ -1395,85 +1389,59 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
 
     // this lane's fragment offset inside a tile image: unit (2k + h), row rb * 32 + l31
     const unsigned frag_off = (unsigned)((h * BT + l31) * 16);
-    // Register budget at two waves per SIMD: 128 ArchVGPRs + 128 AccVGPRs (hipcc splits the 256 evenly as soon as a
-    // kernel touches AccVGPRs).  AccVGPRs: q (112) + the fragments of k-steps 0..3 (16).  ArchVGPRs: accumulators (64),
-    // the fragments of k-steps 4..6 (12), minima, addresses.  All fragment reads are inline asm (an AccVGPR destination
-    // needs it), so the kernel counts them itself: LDS returns in order, KSB reads are in flight, the wait in front of
-    // k-step k is lgkmcnt(KSB - 1), tied to F[k] so that no MFMA can be scheduled above it.
-    // The MFMAs are inline asm too: it is the only way to pin the register classes (accumulators ArchVGPR -- the minimum
-    // reads them directly --, q AccVGPR, fragments by k-step); left to itself hipcc moves the accumulators to AccVGPRs,
-    // pays two v_accvgpr_read per v_minimum3 and spills q.  Consequence: hipcc's hazard recogniser does not see them,
-    // so the kernel provides the wait states itself -- an 8-pass MFMA's result may be read by the VALU 11 wait states
-    // after issue: one s_nop 10 behind the pass's last MFMA, then the minima in accumulator order (c3, written last, is
-    // read 24 instructions later).  Back-to-back MFMAs on one accumulator are 4 instructions apart.
-    constexpr int FA = (KSB * 4 + NQB * KSB * 4 <= 128) ? KSB : (128 - NQB * KSB * 4) / 4;  // fragments held in AccVGPRs
     u32x4 F[KSB];
-#define MANET_MFMA(k_, b_, c_)                                                                                   \
-    if ((k_) == 0) {                                                                                             \
-        if ((k_) < FA) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c_) : "a"(F[k_]), "a"(b_));            \
-        else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c_) : "v"(F[k_]), "a"(b_));                      \
-    } else {                                                                                                     \
-        if ((k_) < FA) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c_) : "a"(F[k_]), "a"(b_));           \
-        else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c_) : "v"(F[k_]), "a"(b_));                     \
-    }
-#define MANET_LOADF(k_, vaddr_, off_)                                                                          \
-    if ((k_) < FA)                                                                                             \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(F[k_]) : "v"(vaddr_), "n"((off_) + (k_) * (2 * BT * 16)) : "memory"); \
-    else                                                                                                       \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(F[k_]) : "v"(vaddr_), "n"((off_) + (k_) * (2 * BT * 16)) : "memory");
-#define MANET_WAITF(k_)                                                                  \
-    if ((k_) < FA) asm volatile("s_waitcnt lgkmcnt(%1)" : "+a"(F[k_]) : "n"(KSB - 1));   \
-    else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(F[k_]) : "n"(KSB - 1));
-#define MANET_MINS(j_, c_)                                                                         \
-    _Pragma("unroll") for (int r = 0; r < ((ABL & 4) ? 2 : 16); r += 4)                            \
-    {                                                                                              \
-        asm volatile("v_minimum3_f32 %0, %0, %1, %2" : "+v"(ma[j_]) : "v"(c_[r]), "v"(c_[r + 2]));     \
-        asm volatile("v_minimum3_f32 %0, %0, %1, %2" : "+v"(mb[j_]) : "v"(c_[r + 1]), "v"(c_[r + 3])); \
-    }
+#define MANET_BF(x) __builtin_bit_cast(bf16x8_t, x)
+#define MANET_MFMA(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MANET_BF(a_), MANET_BF(b_), c_, 0, 0, 0)
+#define MANET_LOADF(k_, pass_base_) F[k_] = *(const u32x4 *)((pass_base_) + frag_off + (size_t)(k_) * (2 * BT * 16));
     // one pass = 32 bank rows x 128 queries: MFMAs of k-step k from F[k], then F[k] <- k-step k of the pass
     // at `next_base` (a tile's second row block is 32 * 16 bytes behind its first inside every unit)
-#define MANET_PASS(next_vaddr_, next_off_)                                                         \
+#define MANET_PASS(next_base_)                                                                     \
     {                                                                                              \
-        f32x16 c0, c1, c2, c3;                                                                     \
+        f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};                                             \
         _Pragma("unroll") for (int k = 0; k < KSB; ++k)                                            \
         {                                                                                          \
-            if (!(ABL & 8)) { MANET_WAITF(k) }                                                     \
-            MANET_MFMA(k, q[0][k], c0)                                                             \
-            MANET_MFMA(k, q[1][k], c1)                                                             \
-            MANET_MFMA(k, q[2][k], c2)                                                             \
-            MANET_MFMA(k, q[3][k], c3)                                                             \
-            if (!(ABL & 8)) { MANET_LOADF(k, next_vaddr_, next_off_) }                             \
+            MANET_MFMA(F[k], q[0][k], c0);                                                         \
+            MANET_MFMA(F[k], q[1][k], c1);                                                         \
+            MANET_MFMA(F[k], q[2][k], c2);                                                         \
+            MANET_MFMA(F[k], q[3][k], c3);                                                         \
+            if (!(ABL & 8)) MANET_LOADF(k, next_base_);                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); /* 4 MFMA */                        \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* the refill right behind them */  \
         }                                                                                          \
-        asm volatile("s_nop 10" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));                         \
-        MANET_MINS(0, c0) MANET_MINS(1, c1) MANET_MINS(2, c2) MANET_MINS(3, c3)                    \
+        _Pragma("unroll") for (int r = 0; r < ((ABL & 4) ? 2 : 16); r += 4)                        \
+        {                                                                                          \
+            ma[0] = min3p(ma[0], c0[r], c0[r + 2]);                                                \
+            mb[0] = min3p(mb[0], c0[r + 1], c0[r + 3]);                                            \
+            ma[1] = min3p(ma[1], c1[r], c1[r + 2]);                                                \
+            mb[1] = min3p(mb[1], c1[r + 1], c1[r + 3]);                                            \
+            ma[2] = min3p(ma[2], c2[r], c2[r + 2]);                                                \
+            mb[2] = min3p(mb[2], c2[r + 1], c2[r + 3]);                                            \
+            ma[3] = min3p(ma[3], c3[r], c3[r + 2]);                                                \
+            mb[3] = min3p(mb[3], c3[r + 1], c3[r + 3]);                                            \
+        }                                                                                          \
     }
 
     // prologue: steps 0 and 1 in flight; publish step 0, fetch the first pass's fragments
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA pieces of steps 0 / 1 AND the query operand
-#pragma unroll
-    for (int j = 0; j < NQB; ++j)
-#pragma unroll
-        for (int k = 0; k < KSB; ++k) asm volatile("" : "+a"(q[j][k]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const unsigned frag_va = smem_base + frag_off;  // LDS byte address of this lane's fragment slot in buffer 0
 #pragma unroll
-    for (int k = 0; k < KSB; ++k) { MANET_LOADF(k, frag_va, 0) }
+    for (int k = 0; k < KSB; ++k) MANET_LOADF(k, smem);
 
     int buf = 0;
     for (int t = t0; t < t1; t += TPS, buf ^= 1) {
-        const unsigned cur = frag_va + (unsigned)buf * (unsigned)STEP_BYTES;
-        const unsigned nxt = frag_va + (unsigned)(buf ^ 1) * (unsigned)STEP_BYTES;
+        const char *cur = smem + (size_t)buf * STEP_BYTES;
+        const char *nxt = smem + (size_t)(buf ^ 1) * STEP_BYTES;
         const bool has_b = (t + 1 < t1);
         // ---- tile A: rows 0-31 (refill: A rows 32-63), rows 32-63 (refill: B rows 0-31)
         next_object(t);
-        MANET_PASS(cur, 32 * 16);
-        MANET_PASS(cur, (int)TILE_BYTES);
+        MANET_PASS(cur + 32 * 16);
+        MANET_PASS(cur + TILE_BYTES);
         // ---- tile B rows 0-31 (refill: B rows 32-63).  After this pass every fragment of `cur` is in
         // registers.
         if (has_b) {
             next_object(t + 1);
-            MANET_PASS(cur, (int)TILE_BYTES + 32 * 16);
+            MANET_PASS(cur + TILE_BYTES + 32 * 16);
         }
         // ---- this wave's pieces of the next step have landed (issued one step ago) and its reads of `cur`
         // have returned; the barrier publishes the next buffer and frees `cur` for step + 2
@@ -1483,14 +1451,12 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         asm volatile("" ::: "memory");
         if (t + 2 * TPS < t1) stage_dma(t + 2 * TPS, buf);
         // ---- tile B rows 32-63 (refill: first pass of the next step; a stale read if there is none)
-        if (has_b) MANET_PASS(nxt, 0);
+        if (has_b) MANET_PASS(nxt);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the last refills (never consumed) have landed before the wave ends
 #undef MANET_PASS
 #undef MANET_LOADF
-#undef MANET_WAITF
-#undef MANET_MINS
 #undef MANET_MFMA
+#undef MANET_BF
     flush(o);
 }
 

@@ -10,8 +10,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int PASSES = 2000;
 
 template <int MODE>  // 4: interleaved reads into AGPRs; 3: burst of 7 reads, then 28 MFMAs; 0: no reads; 1: 7 reads per pass into registers nobody uses; 2: 7 reads per pass feeding the next pass
-__global__ __launch_bounds__(512) void k(float *out, const unsigned *seed)
+__global__ __launch_bounds__(512) void k(float *out, const unsigned *seed, long long *ticks)
 {
+    const long long tk0 = clock64();
     __shared__ __attribute__((aligned(16))) unsigned lds[8192];
     for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = seed[i & 255] + i;
     __syncthreads();
@@ -109,34 +110,37 @@ __global__ __launch_bounds__(512) void k(float *out, const unsigned *seed)
     for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
     for (int kk = 0; kk < 7; ++kk) s += (float)spare[kk][0];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) ticks[blockIdx.x] = clock64() - tk0;
 }
 
 int main()
 {
-    float *out; unsigned *seed;
+    float *out; unsigned *seed; long long *ticks; hipMalloc(&ticks, 8 * 256);
     hipMalloc(&out, 4 << 20); hipMalloc(&seed, 1024); hipMemset(seed, 0x11, 1024);
     const char *names[10] = {"no LDS reads", "7 ds_read_b128 per pass, results unused by MFMA", "7 ds_read_b128 per pass feeding the next pass's A operand", "7 ds_read_b128 in one burst per pass, feeding the next pass", "7 ds_read_b128 per pass into AccVGPRs, feeding the next pass", "asm: acc in ArchVGPR, 7 reads per pass into AccVGPR", "asm: acc in AccVGPR, 7 reads per pass into ArchVGPR", "asm: acc in AccVGPR, no reads", "asm: B (query) in AccVGPR, acc + 7 reads per pass in ArchVGPR", "asm: B and the 7 reads per pass in AccVGPR, acc in ArchVGPR"};
-    for (int mode = 4; mode < 10; ++mode)
+    for (int mode = 0; mode < 10; ++mode)
         for (int wps = 1; wps <= 2; ++wps) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             for (int rep = 0; rep < 2; ++rep) {
                 if (rep == 1) hipEventRecord(e0, 0);
-                if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
-                if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
-                if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
-                if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
-                if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
-                if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
-                if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
-                if (mode == 7) hipLaunchKernelGGL(k<7>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
-                if (mode == 8) hipLaunchKernelGGL(k<8>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
-                if (mode == 9) hipLaunchKernelGGL(k<9>, dim3(256), dim3(256 * wps), 0, 0, out, seed);
+                if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(256 * wps), 0, 0, out, seed, ticks);
+                if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(256 * wps), 0, 0, out, seed, ticks);
+                if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(256 * wps), 0, 0, out, seed, ticks);
+                if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(256 * wps), 0, 0, out, seed, ticks);
+                if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(256), dim3(256 * wps), 0, 0, out, seed, ticks);
+                if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(256), dim3(256 * wps), 0, 0, out, seed, ticks);
+                if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(256), dim3(256 * wps), 0, 0, out, seed, ticks);
+                if (mode == 7) hipLaunchKernelGGL(k<7>, dim3(256), dim3(256 * wps), 0, 0, out, seed, ticks);
+                if (mode == 8) hipLaunchKernelGGL(k<8>, dim3(256), dim3(256 * wps), 0, 0, out, seed, ticks);
+                if (mode == 9) hipLaunchKernelGGL(k<9>, dim3(256), dim3(256 * wps), 0, 0, out, seed, ticks);
             }
             hipEventRecord(e1, 0); hipDeviceSynchronize();
             float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            long long ht[256]; hipMemcpy(ht, ticks, sizeof(ht), hipMemcpyDeviceToHost);
+            double avgt = 0; for (int i = 0; i < 256; ++i) avgt += ht[i]; avgt /= 256;
             double mfma_per_simd = (double)PASSES * 28 * wps;
             double tf = 256.0 * 4 * mfma_per_simd * 32768.0 / (ms * 1e-3) / 1e12;
-            printf("%-62s waves/SIMD %d: %.3f ms, %.2f ns per MFMA per SIMD, %.0f TFLOP/s\n", names[mode], wps, ms, ms * 1e6 / mfma_per_simd, tf);
+            printf("%-62s waves/SIMD %d: %.3f ms, %.2f ns per MFMA per SIMD, %.0f TFLOP/s; s_memtime %.2f ticks per ns of kernel, %.1f ticks per MFMA per SIMD\n", names[mode], wps, ms, ms * 1e6 / mfma_per_simd, tf, avgt / (ms * 1e6), avgt / mfma_per_simd);
         }
     return 0;
 }
