@@ -66,11 +66,12 @@ __global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
             const int yc = min(max(y0 - DW_R + 2 * p + e, 0), h - 1);
+            // (unsigned element offsets: the loads take the scalar-base + 32-bit-offset form, no 64-bit address VALU)
             if (FAST) {
-                ld[k][e] = *(const f32x2 *)(src + yc * w + min(max(xx, 0), w - 2));
+                ld[k][e] = *(const f32x2 *)(src + (unsigned)(yc * w + min(max(xx, 0), w - 2)));
             } else {
-                ld[k][e][0] = src[yc * w + min(max(xx, 0), w - 1)];
-                ld[k][e][1] = src[yc * w + min(max(xx + 1, 0), w - 1)];
+                ld[k][e][0] = src[(unsigned)(yc * w + min(max(xx, 0), w - 1))];
+                ld[k][e][1] = src[(unsigned)(yc * w + min(max(xx + 1, 0), w - 1))];
             }
         }
     }
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *
     for (int e = 0; e < 2; ++e) {
         const int y = y0 + 2 * t + e;
         if (y >= h) continue;
-        float *dst = out + (long)plane_id * h * w + (long)y * w + x;
+        float *dst = out + (long)plane_id * h * w + (unsigned)(y * w + x);
         float r[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
