@@ -1,0 +1,89 @@
+// How fast can the bf16 matrix pipe go on operands with real entropy?  The MFMA stream of the wide global-match kernel
+// (4 blocks x 7 k-steps per pass, A fragment refilled from LDS every pass) with the LDS holding either constant or random
+// bf16 bit patterns; register placement all-ArchVGPR (the shipped kernel's) or accumulators in AccVGPRs.
+// Reports ns and s_memtime ticks per MFMA per SIMD (ticks / ns = the clock the chip sustained).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int PASSES = 3000;
+
+template <int NB, bool ACC_AGPR>
+__global__ __launch_bounds__(512) void k(float *out, const unsigned *data, long long *ticks)
+{
+    __shared__ __attribute__((aligned(16))) unsigned lds[12288];  // 48 KiB of fragments
+    for (int i = threadIdx.x; i < 12288; i += blockDim.x) lds[i] = data[i];
+    __syncthreads();
+    const long long tk0 = clock64();
+    u32x4 a[7], b[NB][7];
+    const unsigned lane = threadIdx.x & 63;
+    for (int kk = 0; kk < 7; ++kk) {
+        a[kk] = *(const u32x4 *)(lds + lane * 4 + kk * 256);
+        for (int j = 0; j < NB; ++j) b[j][kk] = *(const u32x4 *)(data + 16384 + ((j * 7 + kk) * 64 + lane) * 4);
+    }
+    f32x16 c[NB];
+    for (int j = 0; j < NB; ++j) c[j] = f32x16{0};
+    const unsigned base = (unsigned)(size_t)lds + lane * 16;
+    for (int p = 0; p < PASSES; ++p) {
+        const unsigned addr = base + ((unsigned)(p % 6) * 7168u);
+#pragma unroll
+        for (int kk = 0; kk < 7; ++kk) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (ACC_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c[j]) : "v"(a[kk]), "v"(b[j][kk]));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c[j]) : "v"(a[kk]), "v"(b[j][kk]));
+            }
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[kk]) : "v"(addr), "n"(kk * 1024) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    float s = 0;
+    for (int j = 0; j < NB; ++j) {
+        f32x16 t = c[j];
+        if (ACC_AGPR) asm volatile("" : "+v"(t));
+        for (int i = 0; i < 16; ++i) s += t[i];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) ticks[blockIdx.x] = clock64() - tk0;
+}
+
+template <int NB, bool ACC_AGPR>
+void run(const char *name, int wps, float *out, unsigned *data, long long *ticks)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        if (rep == 1) hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((k<NB, ACC_AGPR>), dim3(256), dim3(256 * wps), 0, 0, out, data, ticks);
+    }
+    hipEventRecord(e1, 0); hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1); ms /= 2;
+    long long ht[256]; hipMemcpy(ht, ticks, sizeof(ht), hipMemcpyDeviceToHost);
+    double avgt = 0; for (int i = 0; i < 256; ++i) avgt += ht[i]; avgt /= 256;
+    double n = (double)PASSES * 7 * NB * wps;
+    printf("%-58s %d wave(s)/SIMD: %.2f ns per MFMA per SIMD = %.0f TFLOP/s; %.2f GHz\n", name, wps, ms * 1e6 / n,
+           256.0 * 4 * n * 32768.0 / (ms * 1e-3) / 1e12, avgt / (ms * 1e6));
+}
+
+int main()
+{
+    float *out; unsigned *data; long long *ticks;
+    hipMalloc(&out, 4 << 20); hipMalloc(&data, 4 * 65536); hipMalloc(&ticks, 8 * 256);
+    unsigned *h = (unsigned *)malloc(4 * 65536);
+    for (int pass = 0; pass < 2; ++pass) {
+        srand(1);
+        for (int i = 0; i < 65536; ++i) {
+            if (pass == 0) h[i] = 0x3f803f80u;  // bf16 1.0, 1.0: no toggling
+            else {  // random bf16 pairs in (-2, 2): sign, 7 random exponent-low bits around 1.0, random mantissa
+                unsigned lo = (rand() & 0x807f) | ((0x3c + (rand() & 3)) << 7 << 0), hi = (rand() & 0x807f) | ((0x3c + (rand() & 3)) << 7);
+                h[i] = (hi << 16) | (lo & 0xffff);
+            }
+        }
+        hipMemcpy(data, h, 4 * 65536, hipMemcpyHostToDevice);
+        printf("---- operands: %s\n", pass == 0 ? "constant (all 1.0)" : "random bf16 in (-2, 2)");
+        run<4, false>("4 blocks, all ArchVGPR (the shipped kernel's placement)", 2, out, data, ticks);
+        run<4, true>("4 blocks, accumulators in AccVGPRs", 2, out, data, ticks);
+        run<4, false>("4 blocks, all ArchVGPR", 1, out, data, ticks);
+    }
+    return 0;
+}
