@@ -115,3 +115,33 @@ def test_output_layer_and_deferred_relu_on_gpu():
         shared = head.forward_shared(x[:1, :16], x[:, 16:])
         lit = head(torch.cat((x[:1, :16].repeat(2, 1, 1, 1), x[:, 16:]), 1))
         torch.testing.assert_close(shared, lit, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_folded_constants_follow_parameter_updates():
+    """The per-block cache of folded BatchNorm constants (r2) must notice in-place parameter / statistic updates,
+    load_state_dict and device moves: same result as an uncached module every time."""
+    import copy
+    import torch
+    from cvpr2020_manet_amd.networks import IntVOS as M
+    torch.manual_seed(5)
+    blk = M._split_separable_conv2d(12, 20).cuda().eval()
+    x = torch.randn(2, 12, 17, 22, device="cuda")
+
+    def literal(b):
+        return b.relu2(b.bn2(b.conv2(b.relu1(b.bn1(b.conv1(x))))))
+
+    with torch.no_grad():
+        for step in range(4):
+            if step == 1:
+                blk.bn1.running_var.mul_(1.7); blk.bn2.weight.add_(0.3)          # in place
+            if step == 2:
+                sd = copy.deepcopy(blk.state_dict())
+                for k in sd:
+                    if sd[k].dtype.is_floating_point:
+                        sd[k] = sd[k] * 0.9 + 0.05
+                blk.load_state_dict(sd)                                          # copy_ into the same storage
+            if step == 3:
+                blk.conv2.weight.data = blk.conv2.weight.data.clone() * 1.1      # new storage
+            torch.testing.assert_close(blk(x), literal(blk), rtol=1e-4, atol=1e-4)
+            torch.testing.assert_close(blk(x), literal(blk), rtol=1e-4, atol=1e-4)  # second call: served from the cache
