@@ -205,3 +205,26 @@ def test_fused_kernel_every_window_size(ops, oracle, d):
         got_b = ops.local_match(pb, cb, l, n_ids, d)
         ref_b = ops.local_match(pb.float(), cb.float(), l, n_ids, d)
         assert torch.equal(got_b, ref_b)
+
+
+def test_full_size_local_cfg5_grid(ops, oracle):
+    """BASELINE cfg5's grid (720p: 180x320, C=100, d=4, 6 ids), 2-byte embeddings as bench.py runs it: the fused kernel
+    against the oracle on the same (bf16-rounded) inputs, and bit for bit against the materialised-volume path."""
+    from cvpr2020_manet_amd import _lib
+    torch.manual_seed(20200614 + 5)
+    C, h, w, d, n_ids = 100, 180, 320, 4, 6
+    prev = (torch.relu(torch.randn(C, h, w, device="cuda")) * 0.1).to(torch.bfloat16)
+    cur = (torch.relu(torch.randn(C, h, w, device="cuda")) * 0.1).to(torch.bfloat16)
+    lab = torch.randint(0, n_ids, (h, w), dtype=torch.int32, device="cuda")
+    got = ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), lab, n_ids, d)
+    pf, cf = prev.float(), cur.float()
+    want = oracle.local_match(pf.permute(1, 2, 0).cpu().numpy(), cf.permute(1, 2, 0).cpu().numpy(),
+                              lab.cpu().numpy().reshape(h, w, 1), n_ids, d, downsample=True).reshape(h, w, n_ids)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    lib = _lib.load()
+    _lib.check(lib.manet_tune_set(4, 1), "manet_tune_set")  # MANET_TUNE_LOCAL_UNFUSED
+    try:
+        unfused = ops.local_match(pf.permute(1, 2, 0), cf.permute(1, 2, 0), lab, n_ids, d)
+    finally:
+        _lib.check(lib.manet_tune_set(4, 0), "manet_tune_set")
+    assert torch.equal(got, unfused)
