@@ -361,21 +361,24 @@ __global__ void local_upsample_kernel(const float *__restrict__ dvol, int h, int
 // Decomposition.  A full-resolution pixel (y, x) reads the pooled volume at rows {i0, i1}, columns {j0, j1}
 // (bilinear, align_corners).  A workgroup owns the pixels whose (i0, j0) falls into a TY x 15 block of the
 // pooled grid; they need the volume on a (TY+1) x 16 block S (a one-sided apron), for every window offset.
-//   phase 1  distances on S: thread = (row of S, window row dy, group of COLS columns), COLS x P running sums
-//            over C; channels staged through LDS in double-buffered chunks; a thread slides its COLS+2d wide
-//            window over the P offsets out of registers.  Same arithmetic and order as local_dist_kernel / the
-//            oracle (ascending fmaf chain of (x - y)^2).
-//   phase 2  the normalised volume of S goes to LDS ([dy][dx][SY][16]), the previous frame's labels around the
-//            tile too (one byte each), and every pixel takes its masked minimum over the window -- the same
-//            expressions in the same order as local_min_kernel / the oracle: bit-identical to r1's path.
+//   phase 1  distances on S: thread = (row of S, window row dy, group of COLS columns[, half of the window columns]);
+//            running sums over C held as packed pairs of neighbouring window positions (v_pk_add_f32 / v_pk_fma_f32);
+//            channels staged through LDS in double-buffered stages by asm LDS-DMA, one barrier per stage; a thread
+//            slides its window over the offsets out of registers, the channel loop rotated by hand.  Per stored sum the
+//            same ascending chain of fma(d, d, acc), d = x - y, as local_dist_kernel and the oracle.
+//   phase 2  the normalised volume of S goes to LDS ([dy][cell][dx], dx contiguous), the previous frame's labels
+//            around the tile too (one byte each, prefetched during phase 1), and every (pixel, window row) item walks
+//            its row four columns at a time: b128 taps, the oracle's bilinear expression on two columns per packed op,
+//            an LDS atomic min on the float bits into the (id, pixel) slot.  Bit-identical to r1's three-launch path
+//            (local_dist_kernel -> local_min_kernel), which shares manet_normalize_dist_local.
 // The pooling pass writes PADDED planes (lf_pool_pad_kernel): a border of the reference's padding value (1e20 for
-// the previous frame, IntVOS.py:287) wide enough that no tile ever leaves the plane, rows a multiple of 16 bytes.
-// Staging is then branch-free: float4 global loads -> ds_write_b128, a handful per thread per stage (r2, first
-// version: one exec-masked scalar load + store per element cost as much as the window arithmetic itself).
+// the previous frame, IntVOS.py:287) wide enough that no tile ever leaves the plane, rows a multiple of 16 bytes --
+// staging is branch-free -- and the tile table (first pixel row / column of every tile).
 // Wide windows (d >= 7) use COLS = 4: window reads are aligned ds_read_b128 and feed 4 x P fma pairs.
 // For d >= 11 the window rows are dealt to NDG workgroups per tile (d=11: 2, d=12: 5); their partial minima meet
 // by atomicMin on the float bits (all candidates lie in [0, 1]; `out` is pre-set to 1.0, the reference's
 // "no match" value, IntVOS.py:429-430).
+// DESIGN.md 3.4 has the measured phase timeline and the VALU-rate analysis.
 __host__ __device__ constexpr int lf_cols(int d) { return d <= 6 ? 2 : 4; }                       // columns per thread
 // d = 3, 4 and d >= 10: a thread owns one HALF of the window columns (d=4: dx 0..3 | 4..8, d=12: 0..11 | 12..24): half
 // the running sums, twice the threads -- two waves per SIMD for the arithmetic (a workgroup per CU is all the grid
