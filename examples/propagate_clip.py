@@ -12,7 +12,7 @@ this exercises the API and measures end-to-end frames/s (matching kernels + PyTo
 
 --graph: one propagated frame (global match against the cached PreparedBank + fused local match + head input
 assembly + DynamicSegHead + mask step) is captured ONCE in a HIP graph and replayed per frame: the host issues
-one graph launch (plus four small device copies into / out of the graph's static buffers) instead of ~45 kernel
+one graph launch (plus five small device copies into / out of the graph's static buffers) instead of ~21 kernel
 launches.  The masks are checked against the eager loop's.
 """
 import argparse
