@@ -172,17 +172,22 @@ MatchLayout match_layout(int64_t N, int C, int n_ids, int compute, int k_nn = 1,
 // workgroups over the `slots` resident workgroup slots is >= 97 % full, with >= 4 tiles per split.
 int pick_splits(int nQT, long T_max, int slots)
 {
+    // Workgroups are dispatched as slots free up; what a split count costs is its last, partial round.  With two
+    // workgroups per CU (slots = 512) a last round that fills at most half the slots leaves its workgroups alone on
+    // their CUs, where they run about twice as fast: it costs half a round (r2 sweep at cfg2, S = 40 / 48 / 56 / 64 / 80:
+    // 4.704 / 4.672 / 4.836 / 4.778 / 4.714 ms -- 48 leaves 0.47 of a round, 40 leaves 0.89).  Every workgroup also
+    // pays a fixed prologue (query operand, first tile), a share that grows with S.
     long cap = T_max / 4 / 8 * 8;
     if (cap < 8) cap = 8;
     if (cap > 256) cap = 256;
+    const bool two_per_cu = slots >= 512;
     int best = 8;
     double best_eff = 0.0;
     for (int S = 8; S <= cap; S += 8) {
-        double rounds = (double)nQT * S / slots;
-        double full = (double)(long)rounds;
-        if (full < rounds) full += 1.0;
-        double eff = rounds / full;
-        if (eff >= 0.97) return S;
+        const double rounds = (double)nQT * S / slots;
+        const double whole = (double)(long)rounds, frac = rounds - whole;
+        const double last = frac <= 0.0 ? 0.0 : ((two_per_cu && frac <= 0.5) ? 0.5 : 1.0);
+        const double eff = rounds / (whole + last) / (1.0 + 0.0003 * S);
         if (eff > best_eff) {
             best_eff = eff;
             best = S;
