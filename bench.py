@@ -13,18 +13,24 @@ after rough_ROI), 1 object (+ background = 2 ids), fp32.
 
 Timed region (exactly K steps + the clip's one-off work): the bank exchange (N > 1), ONE sort/pack
 of the memory bank (it is the same for every frame of the propagation loop, test.py:237-259 -- what
-the drop-in module does through its PreparedBank cache), then K frames, each = query pack + global
-match + fused epilogue + local match.  `--one-shot` re-sorts / re-packs the bank every frame instead
-(r1's definition; the reference recomputes everything per frame).  `--prepacked` also takes the query
-operand images as given (packed when the embeddings were produced).
+the drop-in module does through its PreparedBank cache), then K frames, each = query pack + global match + fused epilogue + local match.  `--one-shot` re-sorts / re-packs the bank every frame through the one-shot API instead (r1's
+definition; the reference recomputes everything per frame) -- the headline line carries that number
+too (`value_one_shot`).  `--prepacked` takes the per-frame operands as given (prepared when the
+embeddings were produced).
+
+The ONE JSON line also carries, at N = 1, the other single-GPU BASELINE configs as `also` legs
+(configs[2] = cfg3 and configs[4] = cfg5, bf16 arithmetic on 2-byte embeddings): ms per step, the
+dominant kernel's HIP-event time and roofline fraction, and their error against the fp32 oracle.
 
 Multi-GPU: `python bench.py --gpus N` starts its own N ranks (one process per GPU, RCCL); frames of
-the clip are sharded, K per rank (weak scaling); the timed region contains the single RCCL
-all-gather that distributes the memory bank + halo frame.  Prints ONE JSON line on rank 0 (contract
-in the task description) with `roofline` and `cpu_baseline` objects.
+the clip are sharded, K per rank (weak scaling; `--scaling strong`: a fixed 64-frame clip, BASELINE
+configs[3]); the timed region contains the single RCCL all-gather that distributes the memory bank +
+halo frame, and the line echoes what the collective saw (`collective`: backend, world, slab bytes,
+all-gather ms).
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import socket
@@ -40,31 +46,263 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-# BASELINE.json configs[1] (+ the reference's default local window, config.py:50)
-H, W, C = 120, 214, 100
-T_BANK = 5
-N_IDS = 2
-LOCAL_D = 12
+C = 100
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide)
+HBM_PEAK_GBS = 8000.0
+
+# BASELINE.json configs (index = --cfg): grid, bank frames, ids, local window (config.py:50 default = 12)
+CONFIGS = {
+    2: dict(H=120, W=214, T=5, n_ids=2, d=12),   # configs[1], the headline
+    3: dict(H=120, W=214, T=5, n_ids=4, d=4),    # configs[2]
+    5: dict(H=180, W=320, T=10, n_ids=6, d=4),   # configs[4]
+}
+MAIN_KERNEL = {"f32": "global_match_f32_pipe_kernel<50>", "bf16": "global_match_bf16_wide_kernel<7, 0>",
+               "bf16x3": "global_match_bf16_kernel<7, true, 1, true>", "bf16r": "global_match_bf16_wide_kernel<7, 0> + refine"}
 
 
-def synth_frame(gen, device, dtype=torch.float32):
-    """C-major embedding as extract_feature produces it (post-ReLU): relu(randn) * 0.1,
-    stored in `dtype` (bf16 configs keep 2-byte embeddings in HBM)."""
-    return (torch.relu(torch.randn(C, H, W, generator=gen, device=device)) * 0.1).to(dtype).contiguous()
+class Workload:
+    """One BASELINE config: synthetic clip of this rank, memory bank, previous-frame labels."""
+
+    def __init__(self, cfg, compute, emb, device, rank=0, world=1, n_local=8, keep_f32=False):
+        c = CONFIGS[cfg]
+        self.cfg, self.compute, self.emb = cfg, compute, emb
+        self.H, self.W, self.T, self.n_ids, self.d = c["H"], c["W"], c["T"], c["n_ids"], c["d"]
+        self.device, self.rank, self.world = device, rank, world
+        self.emb_dtype = torch.bfloat16 if emb == "bf16" else torch.float32
+        gen = torch.Generator(device=device).manual_seed(20200614 + 2 + 1000 * rank)
+        self.n_local = n_local
+        n_res = min(n_local, 8)  # resident frames, cycled: 8 x 10.3 MB (fp32, 480p)
+        f32 = [torch.relu(torch.randn(C, self.H, self.W, generator=gen, device=device)) * 0.1 for _ in range(n_res)]
+        # C-major embeddings as extract_feature produces them (post-ReLU), stored in the producer's type
+        self.local_emb = torch.stack([f.to(self.emb_dtype) for f in f32]).contiguous()
+        self.f32_frames = f32 if keep_f32 else None  # the values before storage rounding (parity of the bf16 legs)
+        self.F_total = world * n_local
+        T, F_total = self.T, self.F_total
+        bank_frames = sorted({int(round(i * (F_total - 1) / max(T - 1, 1))) for i in range(T)})
+        while len(bank_frames) < T:  # tiny clips: duplicate-free fill
+            for f in range(F_total):
+                if f not in bank_frames:
+                    bank_frames.append(f)
+                    break
+            else:
+                break
+        self.bank_frames = sorted(bank_frames)[:T]
+        lab_gen = torch.Generator(device=device).manual_seed(20200614 + 2)
+        self.bank_labels = {f: torch.randint(0, self.n_ids, (self.H, self.W), generator=lab_gen, device=device,
+                                             dtype=torch.int32) for f in self.bank_frames}
+        self.prev_labs = [self.blob_labels(s) for s in range(8)]
+        self.gmap = torch.ones(104, self.H * self.W, self.n_ids, device=device)  # IntVOS.py:617
+
+    def blob_labels(self, shift):
+        """previous-frame labels: one rectangle per object, nearest-resized grid resolution"""
+        H, W = self.H, self.W
+        lab = torch.zeros(H, W, dtype=torch.int32, device=self.device)
+        for o in range(1, self.n_ids):
+            y0 = (15 * o + 3 * shift) % (H - 50)
+            x0 = (40 * o + 5 * shift) % (W - 80)
+            lab[y0:y0 + 45, x0:x0 + 70] = o
+        return lab
+
+    def frame_emb(self, i):  # embedding of local frame i (cycled over the resident ones)
+        return self.local_emb[i % self.local_emb.shape[0]]
+
+    def frame_f32(self, i):
+        return self.f32_frames[i % len(self.f32_frames)]
+
+    def local_bytes(self):
+        """algorithmic bytes of the local stage: both embeddings read once + labels + the [h,w,n_ids] result"""
+        return 2.0 * (2 if self.emb == "bf16" else 4) * C * self.H * self.W + 4.0 * self.H * self.W * (1 + self.n_ids)
+
+    def describe(self, args):
+        M = self.T * self.H * self.W
+        return ("BASELINE configs[%d]: grid %dx%d, C=%d, %d-frame fully-labelled bank (M=%d), %d ids, %s arithmetic, "
+                "%s-stored embeddings; step = query pack%s + global match + fused "
+                "normalise/min-merge + local match d=%d; bank %s"
+                % (self.cfg - 1, self.H, self.W, C, self.T, M, self.n_ids, self.compute, self.emb,
+                   " (done by the producer, untimed)" if args.prepacked else "", self.d,
+                   "re-sorted/re-packed every frame (one-shot API)" if args.one_shot else
+                   "sorted/packed once per clip inside the timed region"))
 
 
-def blob_labels(n_ids, shift, device):
-    """previous-frame labels: one rectangle per object, nearest-resized grid resolution"""
-    lab = torch.zeros(H, W, dtype=torch.int32, device=device)
-    for o in range(1, n_ids):
-        y0 = (15 * o + 3 * shift) % (H - 50)
-        x0 = (40 * o + 5 * shift) % (W - 80)
-        lab[y0:y0 + 45, x0:x0 + 70] = o
-    return lab
+def run_leg(wl, K, Wm, args, lib, use_dist=False, one_shot=False, prepacked=False, overlap=False,
+            ownership="block"):
+    """Warm-up + the timed region of one workload on this rank.  Returns a dict of raw measurements."""
+    from cvpr2020_manet_amd import _lib, clip_parallel, ops
+    device = wl.device
+    my_start, _ = clip_parallel.shard_frames(wl.F_total, wl.world, wl.rank)
+    side = torch.cuda.Stream(device=device) if overlap else None
+    timing = {"collective": None}
+
+    def build_bank(timed):
+        """every rank gets the full bank (+ halo): ONE all-gather over RCCL when world > 1"""
+        if use_dist:
+            n_local = wl.n_local
+            if n_local <= wl.local_emb.shape[0]:
+                owned = wl.local_emb[:n_local]
+            else:
+                # K > 8: frames are cycled; materialise only what the exchange reads
+                class _View:
+                    shape = (n_local, C, wl.H, wl.W)
+                    device = wl.local_emb.device
+                    dtype = wl.local_emb.dtype
+
+                    def __getitem__(self, i):
+                        return wl.frame_emb(i if i >= 0 else n_local + i)
+                owned = _View()
+            extra = None
+            if ownership == "round_robin":  # bank frame j is extracted + shipped by rank j % world (synthetic here)
+                extra = {}
+                for j, f in enumerate(wl.bank_frames):
+                    if j % wl.world == wl.rank and not (my_start <= f < my_start + n_local):
+                        g = torch.Generator(device=device).manual_seed(977 + f)
+                        extra[f] = (torch.relu(torch.randn(C, wl.H, wl.W, generator=g, device=device)) * 0.1).to(wl.emb_dtype)
+                labels = {f: wl.bank_labels[f] for f in wl.bank_frames}
+            else:
+                labels = wl.bank_labels
+            bank_emb, bank_lab, halo = clip_parallel.exchange_bank_and_halo(
+                owned, my_start, wl.bank_frames, labels, wl.F_total, ownership=ownership, extra_embeddings=extra,
+                timing=True)
+            if timed:
+                timing["collective"] = dict(clip_parallel.LAST_EXCHANGE)
+        else:
+            bank_emb = torch.stack([wl.frame_emb(f) for f in wl.bank_frames])
+            bank_lab = torch.stack([wl.bank_labels[f] for f in wl.bank_frames])
+            halo = None
+        # stacked T-frame bank as the API expects it: rows = pixels of all frames (IntVOS.py:203-204)
+        bank_rows = bank_emb.permute(0, 2, 3, 1).reshape(-1, C)
+        return bank_rows, bank_lab.reshape(-1), halo
+
+    packed = None
+    if prepacked:  # the producer's job (SURVEY 8f rank 4): one operand image per resident frame
+        packed = [ops.PackedQuery(f.permute(1, 2, 0), compute=wl.compute) for f in wl.local_emb]
+
+    def prepare(bank_rows, bank_lab):
+        """the clip's one-off: sort + pack the memory bank (None in --one-shot mode)"""
+        return None if one_shot else ops.PreparedBank(bank_rows, bank_lab, wl.n_ids, compute=wl.compute)
+
+    def step(i, bank, bank_rows, bank_lab, halo):
+        cur = wl.frame_emb(i)
+        prev = wl.frame_emb(i - 1) if i > 0 else (halo if halo is not None else wl.frame_emb(0))
+        if side is not None:
+            with torch.cuda.stream(side):
+                l = ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), wl.prev_labs[i % 8], wl.n_ids, wl.d)
+        if bank is None:
+            g = ops.global_match(bank_rows, cur.permute(1, 2, 0), bank_lab, wl.n_ids, normalize=True,
+                                 mem=wl.gmap[i % 104], compute=wl.compute)
+        else:
+            qsrc = packed[i % len(packed)] if packed is not None else cur.permute(1, 2, 0)
+            g = bank.match(qsrc, normalize=True, mem=wl.gmap[i % 104])
+        if side is None:
+            l = ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), wl.prev_labs[i % 8], wl.n_ids, wl.d)
+        return g, l
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up (untimed)
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream(device))  # the synthetic frames were produced on the main stream
+    bank_rows, bank_lab, halo = build_bank(False)
+    bank = prepare(bank_rows, bank_lab)
+    for i in range(Wm):
+        step(i, bank, bank_rows, bank_lab, halo)
+    barrier()
+
+    # timed: the bank exchange + the bank's one-off sort/pack + exactly K frames
+    _lib.check(lib.manet_profile_begin(K), "manet_profile_begin")
+    barrier()
+    t0 = time.perf_counter()
+    bank_rows, bank_lab, halo = build_bank(True)
+    bank = prepare(bank_rows, bank_lab)
+    for i in range(K):
+        step(i, bank, bank_rows, bank_lab, halo)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms, lms = (ctypes.c_float * K)(), (ctypes.c_float * K)()
+    nrec, nloc = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.manet_profile_end2(ms, K, ctypes.byref(nrec), lms, K, ctypes.byref(nloc)), "manet_profile_end2")
+    kern_ms = float(np.mean([ms[i] for i in range(nrec.value)])) if nrec.value else float("nan")
+    local_ms = float(np.mean([lms[i] for i in range(nloc.value)])) if nloc.value else float("nan")
+    return {"elapsed": elapsed, "kern_ms": kern_ms, "local_ms": local_ms, "bank_rows": bank_rows, "bank_lab": bank_lab,
+            "collective": timing["collective"]}
 
 
-def cpu_baseline(bank_rows, bank_lab, cur, prev, prev_lab, gpu_global=None, gpu_local=None, quant_bf16=False):
+def roofline_blocks(wl, kern_ms, local_ms, overlap=False):
+    N, M = wl.H * wl.W, wl.T * wl.H * wl.W
+    flops = 2.0 * N * M * C  # algorithmic flops of one launch (SURVEY.md 8d)
+    achieved = flops / (kern_ms * 1e-3) / 1e12
+    peak = FP32_MFMA_PEAK_TFLOPS if wl.compute == "f32" else BF16_MFMA_PEAK_TFLOPS
+    traffic, traffic_src = read_traffic(wl.cfg, wl.compute)
+    roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": MAIN_KERNEL[wl.compute], "kernel_ms": kern_ms,
+            "algorithmic_flops_per_launch": flops}
+    b = wl.local_bytes()
+    # the HBM-bound stage of the path (SURVEY 8d): HIP events over the local stage's launches
+    local = None if overlap else {"bound": "hbm", "achieved": b / (local_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": b / (local_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                                  "stage_ms": local_ms, "algorithmic_bytes": b, "max_distance": wl.d}
+    return roof, local
+
+
+def _sha(path):
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:12]
+    except OSError:
+        return None
+
+
+def read_traffic(cfg, compute):
+    """HBM/fabric bytes of the dominant kernel: PMC counters cannot be read from inside the run, so the figure comes
+    from the tracked rocprofv3 --pmc capture of THIS command line (profiles/traffic_cfg*.json records where and when
+    it was measured, and the hash of the kernel source it was measured on: `stale` says whether that still is the
+    source of the library that ran here)."""
+    tp = os.path.join(ROOT, "profiles", "traffic_cfg%d_%s.json" % (cfg, compute))
+    if not os.path.exists(tp):
+        return None, None
+    try:
+        tj = json.load(open(tp))
+    except Exception:
+        return None, None
+    src = {k: tj.get(k) for k in ("source", "captured_at", "kernel", "kernel_source_sha")}
+    now = _sha(os.path.join(ROOT, "cvpr2020_manet_amd", "csrc", "global_match.hip"))
+    src["stale"] = None if tj.get("kernel_source_sha") is None else (tj.get("kernel_source_sha") != now)
+    return tj.get("hbm_bytes_per_launch"), src
+
+
+def oracle_sample(wl, bank_rows_f32, bank_lab, cur_f32, budget_s, quant_bf16=False, nq_cap=None):
+    """The CPU oracle's global match on a time-bounded sample of query pixels (cost is linear in them) against the
+    FULL bank.  Returns (raw distances [nq, n_ids], nq, seconds per repetition, repetitions)."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    N = wl.H * wl.W
+    qry = cur_f32.permute(1, 2, 0).reshape(-1, C).cpu().numpy()
+    ref3 = bank_rows_f32.cpu().numpy().reshape(-1, 1, C)
+    lab = bank_lab.cpu().numpy().reshape(-1, 1, 1)
+    last = {}
+
+    def run(nq):
+        q = np.ascontiguousarray(qry[:nq]).reshape(nq, 1, C)
+        t0 = time.perf_counter()
+        last["raw"] = orc.global_match(ref3, q, lab, 1, n_ids=wl.n_ids, test_mode=True, quant_bf16=quant_bf16)
+        return time.perf_counter() - t0
+
+    probe_n = min(N, 8 * cores)
+    per_q = run(probe_n) / probe_n
+    nq = int(min(N, max(probe_n, budget_s / per_q)))
+    nq -= nq % (8 * cores)
+    nq = min(N, max(nq, probe_n))
+    if nq_cap:
+        nq = min(nq, nq_cap)
+    reps = int(max(1, min(30, round(budget_s / max(per_q * nq, 1e-3)))))
+    t = sum(run(nq) for _ in range(reps)) / reps
+    return last["raw"].reshape(nq, wl.n_ids), nq, t, reps
+
+
+def cpu_baseline(wl, bank_rows, bank_lab, gpu_global=None, gpu_local=None):
     """The CPU oracle (a C port of the reference path, kind="port": OpenMP over query blocks, the distance loop
     vectorised across bank rows with AVX-512/AVX2 FMA -- same fmaf chains, bit-identical to the scalar form) on
     the host cores, on a bounded sample of the same frame: a subset of query pixels against the FULL bank for the
@@ -73,34 +311,14 @@ def cpu_baseline(bank_rows, bank_lab, cur, prev, prev_lab, gpu_global=None, gpu_
     GPU results of the same frame are passed in, their max abs deviation is returned as well."""
     from oracle import oracle as orc
     cores = os.cpu_count() or 1
-    cur, prev, bank_rows = cur.float(), prev.float(), bank_rows.float()  # (bf16-stored embeddings widen exactly)
+    N = wl.H * wl.W
+    cur, prev = wl.frame_emb(0).float(), wl.frame_emb(1).float()  # (bf16-stored embeddings widen exactly)
+    raw, nq, t_glob, reps = oracle_sample(wl, bank_rows.float(), bank_lab, cur, 10.0)
     qry = cur.permute(1, 2, 0).cpu().numpy()
-    ref = bank_rows.cpu().numpy()
-    lab = bank_lab.cpu().numpy().reshape(-1, 1, 1)
-    ref3 = ref.reshape(-1, 1, C)
-    N = H * W
-
-    last = {}
-
-    def run(nq):
-        q = np.ascontiguousarray(qry.reshape(-1, C)[:nq]).reshape(nq, 1, C)
-        t0 = time.perf_counter()
-        last["raw"] = orc.global_match(ref3, q, lab, 1, n_ids=N_IDS, test_mode=True, quant_bf16=quant_bf16)
-        return time.perf_counter() - t0
-
-    probe_n = 8 * cores
-    t_probe = run(min(probe_n, N))
-    per_q = t_probe / min(probe_n, N)
-    nq = int(min(N, max(probe_n, 12.0 / per_q)))
-    nq -= nq % (8 * cores) or 0
-    nq = min(N, max(nq, 8 * cores))
-    # ~10-15 s of CPU work: the sample is a whole frame's worth of query pixels (or what fits) repeated
-    reps = int(max(1, min(30, round(10.0 / max(per_q * nq, 1e-3)))))
-    t_glob = sum(run(nq) for _ in range(reps)) / reps
     t0 = time.perf_counter()
     lreps = 0
     while True:
-        loc = orc.local_match(prev.permute(1, 2, 0).cpu().numpy(), qry, prev_lab.cpu().numpy(), N_IDS, LOCAL_D)
+        loc = orc.local_match(prev.permute(1, 2, 0).cpu().numpy(), qry, wl.prev_labs[0].cpu().numpy(), wl.n_ids, wl.d)
         lreps += 1
         if time.perf_counter() - t0 > 3.0 or lreps >= 10:
             break
@@ -111,22 +329,95 @@ def cpu_baseline(bank_rows, bank_lab, cur, prev, prev_lab, gpu_global=None, gpu_
                      "linearly to the frame); local match d=%d: whole frame, %d repetition(s), %.2f s each; "
                      "oracle/manet_oracle.c, OpenMP on %d threads, distance loop vectorised across bank rows "
                      "(AVX-512/AVX2 FMA, bit-identical to the scalar chains)"
-                     % (nq, N, ref.shape[0], reps, t_glob, LOCAL_D, lreps, t_loc, cores)}
+                     % (nq, N, bank_rows.shape[0], reps, t_glob, wl.d, lreps, t_loc, cores)}
     parity = None
     if gpu_global is not None:
-        want, _ = orc.normalize_merge(last["raw"].reshape(-1, N_IDS), None, normalize=True)
+        want, _ = orc.normalize_merge(raw, None, normalize=True)
         got = gpu_global.cpu().numpy()[:nq]
         parity = {"global_map_max_abs_err": float(np.abs(got - want).max()), "global_pixels_checked": int(nq),
-                  "local_map_max_abs_err": float(np.abs(gpu_local.cpu().numpy() - loc.reshape(H, W, N_IDS)).max()),
+                  "local_map_max_abs_err": float(np.abs(gpu_local.cpu().numpy() - loc.reshape(wl.H, wl.W, wl.n_ids)).max()),
                   "reference": "CPU oracle (pinned to reference vectors), same frame, normalised maps"}
     return res, parity
+
+
+def err_stats(got_norm, want_norm):
+    """max / mean abs error of the normalised maps and the fraction of pixels whose arg-min object id differs"""
+    e = np.abs(got_norm - want_norm)
+    flips = float(np.mean(np.argmin(got_norm, axis=1) != np.argmin(want_norm, axis=1)))
+    return float(e.max()), float(e.mean()), flips
+
+
+def bf16_parity(wl, bank_rows, bank_lab, budget_s=4.0):
+    """north_star's bar for the bf16 configs is 'within 1e-3 of the reference PyTorch path on the same inputs'.  Two
+    readings of 'same inputs', both measured here against the fp32 oracle on a sample of frame 0's pixels x the FULL bank:
+      stored    the inputs are the 2-byte embeddings the producer stored (what this leg's kernels read): the oracle runs
+                the reference's fp32 formula on exactly those values (widened) -- bf16 products of bf16 values are exact,
+                only the accumulation order differs
+      unrounded the inputs are the fp32 embeddings BEFORE storage rounding; the GPU paths round them to bf16 themselves
+                (compute='bf16'), split them hi+lo (compute='bf16x3'), or filter in bf16 and re-rank in fp32
+                (compute='bf16r', bit-exact by construction) -- this is the figure a caller with fp32 embeddings sees
+    Figures are on the normalised maps (sigmoid(d)-0.5)*2 in [0,1] (SURVEY 7 'hard parts'); flips = fraction of sampled
+    pixels whose arg-min object id differs from the oracle's."""
+    from cvpr2020_manet_amd import ops
+    from oracle import oracle as orc
+    out = {"reference": "CPU oracle, fp32 formula (pinned to reference vectors); sample of frame 0 x full bank",
+           "tolerance": 1e-3}
+    cur_st = wl.frame_emb(0)
+    # -- stored inputs
+    raw, nq, _, _ = oracle_sample(wl, bank_rows.float(), bank_lab, cur_st.float(), budget_s)
+    want, _ = orc.normalize_merge(raw, None, normalize=True)
+    g = ops.global_match(bank_rows, cur_st.permute(1, 2, 0), bank_lab, wl.n_ids, normalize=True, compute=wl.compute)
+    mx, mean, flips = err_stats(g.cpu().numpy()[:nq], want)
+    out["pixels_checked"] = int(nq)
+    out["stored_inputs"] = {"compute": wl.compute, "err_vs_fp32_oracle_normalised_max": mx,
+                            "err_vs_fp32_oracle_normalised_mean": mean, "argmin_id_flip_fraction": flips}
+    # -- unrounded fp32 inputs
+    if wl.f32_frames is not None:
+        bank_f32 = torch.stack([wl.frame_f32(f) for f in wl.bank_frames]).permute(0, 2, 3, 1).reshape(-1, C)
+        cur_f32 = wl.frame_f32(0)
+        raw, nq2, _, _ = oracle_sample(wl, bank_f32, bank_lab, cur_f32, budget_s, nq_cap=nq)
+        want, _ = orc.normalize_merge(raw, None, normalize=True)
+        un = {}
+        modes = ["bf16", "bf16x3"] + (["bf16r"] if "bf16r" in ops.COMPUTE else [])
+        for mode in modes:
+            g = ops.global_match(bank_f32, cur_f32.permute(1, 2, 0), bank_lab, wl.n_ids, normalize=True, compute=mode)
+            mx, mean, flips = err_stats(g.cpu().numpy()[:nq2], want)
+            un[mode] = {"err_vs_fp32_oracle_normalised_max": mx, "err_vs_fp32_oracle_normalised_mean": mean,
+                        "argmin_id_flip_fraction": flips}
+        out["unrounded_fp32_inputs"] = un
+        out["meets_1e-3"] = {m: bool(v["err_vs_fp32_oracle_normalised_max"] <= 1e-3) for m, v in un.items()}
+    return out
+
+
+def also_leg(cfg, compute, device, lib, args):
+    """A GPU-only leg of another single-GPU BASELINE config (a few steps) + its parity figures."""
+    wl = Workload(cfg, compute, "bf16" if compute != "f32" else "f32", device, n_local=8, keep_f32=True)
+    K, Wm = args.also_steps, 2
+    r = run_leg(wl, K, Wm, args, lib)
+    roof, local = roofline_blocks(wl, r["kern_ms"], r["local_ms"])
+    leg = {"workload": wl.describe(args), "cfg": cfg, "dtype": compute, "steps": K, "warmup": Wm,
+           "value": K / r["elapsed"], "unit": "frames/s", "ms_per_step": r["elapsed"] / K * 1e3,
+           "kernel_ms": r["kern_ms"], "roofline": roof, "local_stage": local}
+    if not args.no_cpu_baseline:
+        from cvpr2020_manet_amd import ops
+        from oracle import oracle as orc
+        leg["parity"] = bf16_parity(wl, r["bank_rows"], r["bank_lab"])
+        l_chk = ops.local_match(wl.frame_emb(1).permute(1, 2, 0), wl.frame_emb(0).permute(1, 2, 0), wl.prev_labs[0],
+                                wl.n_ids, wl.d)
+        loc = orc.local_match(wl.frame_emb(1).float().permute(1, 2, 0).cpu().numpy(),
+                              wl.frame_emb(0).float().permute(1, 2, 0).cpu().numpy(), wl.prev_labs[0].cpu().numpy(),
+                              wl.n_ids, wl.d)
+        leg["parity"]["local_map_max_abs_err"] = float(np.abs(l_chk.cpu().numpy() - loc.reshape(wl.H, wl.W, wl.n_ids)).max())
+    return leg
 
 
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU,
     torch.distributed.run, rendezvous on 127.0.0.1) and relay rank 0's JSON line.  Called BEFORE anything
     in this process touches the GPU -- a process that has initialised HIP must never exec or be the
-    parent that matters; this parent only waits and passes the exit code on."""
+    parent that matters; this parent only waits and passes the exit code on.  (No device-count pre-check
+    here: torch.cuda.device_count() may fall through to hipGetDeviceCount on builds without amdsmi, which
+    would initialise the runtime in the parent; ranks without a device fail loudly by themselves.)"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -143,9 +434,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every CPU-oracle leg (baseline + parity)")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra cfg3 / cfg5 bf16 legs of the N=1 line")
+    ap.add_argument("--also-steps", type=int, default=10)
     ap.add_argument("--tune", type=str, default="", help="experiments only: key=value,... for manet_tune_set")
-    ap.add_argument("--compute", type=str, default="f32", choices=["f32", "bf16", "bf16x3"],
+    ap.add_argument("--compute", type=str, default="f32", choices=["f32", "bf16", "bf16x3", "bf16r"],
                     help="arithmetic of the QK^T contraction (headline = f32, BASELINE configs[1])")
     ap.add_argument("--cfg", type=int, default=2, choices=[2, 3, 5],
                     help="BASELINE config: 2 = 480p T=5 2 ids d=12 (headline); 3 = 480p T=5 4 ids d=4; "
@@ -160,10 +453,15 @@ def main():
                          "stream and clean roofline attribution")
     ap.add_argument("--prepacked", action="store_true",
                     help="query operand images packed when the embeddings were produced (outside the timed region)")
+    ap.add_argument("--scaling", type=str, default="weak", choices=["weak", "strong"],
+                    help="weak: K frames per rank (the driver's contract); strong: a fixed 64-frame clip (BASELINE "
+                         "configs[3]) cut into 64 / N frames per rank (--steps is ignored)")
+    ap.add_argument("--bank-ownership", type=str, default="round_robin", choices=["block", "round_robin"],
+                    help="who ships which bank frame in the all-gather (clip_parallel): round_robin bounds every rank's "
+                         "slab at ceil(T / N) frames")
     args = ap.parse_args()
     if args.emb == "auto":
-        args.emb = "bf16" if args.compute == "bf16" else "f32"
-    emb_dtype = torch.bfloat16 if args.emb == "bf16" else torch.float32
+        args.emb = "bf16" if args.compute in ("bf16", "bf16r") else "f32"
 
     # MANET_BENCH_BACKEND=gloo: dry run of the N>1 flow on fewer GPUs than ranks (ranks share devices)
     backend = os.environ.get("MANET_BENCH_BACKEND", "nccl")
@@ -171,10 +469,6 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # not under a launcher: become the launcher (no GPU call has happened in this process)
-        n_dev = torch.cuda.device_count()  # counting devices does not initialise HIP
-        if backend == "nccl" and n_dev < args.gpus:
-            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (one rank per GPU over RCCL)"
-                             % (args.gpus, n_dev))
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -183,7 +477,10 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the matching path has no CPU fallback")
-    dev_index = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (one rank per GPU over RCCL)" % (world, n_dev))
+    dev_index = local_rank % n_dev
     # MANET_BENCH_FORCE_DIST=1: take the collective code path even with one rank (exercises RCCL on a 1-GPU box)
     use_dist = world > 1 or os.environ.get("MANET_BENCH_FORCE_DIST") == "1"
     if use_dist:
@@ -202,149 +499,33 @@ def main():
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
 
-    from cvpr2020_manet_amd import _lib, clip_parallel, ops
+    from cvpr2020_manet_amd import _lib, ops
     lib = _lib.load()
     for kv in filter(None, args.tune.split(",")):
         k_, v_ = kv.split("=")
         _lib.check(lib.manet_tune_set(int(k_), int(v_)), "manet_tune_set")
 
-    global H, W, T_BANK, N_IDS, LOCAL_D
-    if args.cfg == 3:
-        N_IDS, LOCAL_D = 4, 4
-    elif args.cfg == 5:
-        H, W, T_BANK, N_IDS, LOCAL_D = 180, 320, 10, 6, 4
-    peak = FP32_MFMA_PEAK_TFLOPS if args.compute == "f32" else 2500.0  # dense bf16 MFMA peak (guide)
     K, Wm = args.steps, args.warmup
-    gen = torch.Generator(device=device).manual_seed(20200614 + 2 + 1000 * rank)
-    # this rank's K frames of the clip (synthetic embeddings, resident in HBM) + 1 warm-up halo
-    # (the clip is at least long enough to contain T_BANK distinct annotated frames; only K are timed)
-    n_local = max(K, -(-T_BANK // world))
-    frames = [synth_frame(gen, device, emb_dtype) for _ in range(min(n_local, 8))]  # cycled: 8 x 10.3 MB (fp32)
-    local_emb = torch.stack(frames)  # [f, C, H, W]
-    F_total = world * n_local
-    my_start, _ = clip_parallel.shard_frames(F_total, world, rank)
-    # the bank: T annotated frames spread over the clip; labels uniform over the ids (fully labelled)
-    bank_frames = sorted({int(round(i * (F_total - 1) / max(T_BANK - 1, 1))) for i in range(T_BANK)})
-    while len(bank_frames) < T_BANK:  # tiny clips: duplicate-free fill
-        for f in range(F_total):
-            if f not in bank_frames:
-                bank_frames.append(f)
-                break
-        else:
-            break
-    bank_frames = sorted(bank_frames)[:T_BANK]
-    lab_gen = torch.Generator(device=device).manual_seed(20200614 + 2)
-    bank_labels = {f: torch.randint(0, N_IDS, (H, W), generator=lab_gen, device=device, dtype=torch.int32)
-                   for f in bank_frames}
-
-    def frame_emb(i):  # embedding of local frame i (cycled over the resident ones)
-        return local_emb[i % local_emb.shape[0]]
-
-    def build_bank():
-        """every rank gets the full bank (+ halo): ONE all-gather over RCCL when world > 1"""
-        if use_dist:
-            # the rank's slab needs the embeddings of the bank frames it owns
-            owned = torch.stack([frame_emb(i) for i in range(n_local)]) if n_local <= 8 else None
-            if owned is None:
-                # K > 8: frames are cycled; materialise only what the exchange reads
-                class _View:
-                    shape = (n_local, C, H, W)
-                    device = local_emb.device
-
-                    def __getitem__(self, i):
-                        return frame_emb(i if i >= 0 else n_local + i)
-                owned = _View()
-            bank_emb, bank_lab, halo = clip_parallel.exchange_bank_and_halo(owned, my_start, bank_frames,
-                                                                            bank_labels, F_total)
-        else:
-            bank_emb = torch.stack([frame_emb(f) for f in bank_frames])
-            bank_lab = torch.stack([bank_labels[f] for f in bank_frames])
-            halo = None
-        # stacked T-frame bank as the API expects it: rows = pixels of all frames (IntVOS.py:203-204)
-        bank_rows = bank_emb.permute(0, 2, 3, 1).reshape(-1, C)
-        return bank_rows, bank_lab.reshape(-1), halo
-
-    gmap = torch.ones(104, H * W, N_IDS, device=device)  # IntVOS.py:617
-    prev_labs = [blob_labels(N_IDS, s, device) for s in range(8)]
-    packed = None
-    if args.prepacked:  # the producer's job (SURVEY 8f rank 4): one operand image per resident frame
-        packed = [ops.PackedQuery(f.permute(1, 2, 0), compute=args.compute) for f in frames]
-
-    def prepare(bank_rows, bank_lab):
-        """the clip's one-off: sort + pack the memory bank (None in --one-shot mode)"""
-        return None if args.one_shot else ops.PreparedBank(bank_rows, bank_lab, N_IDS, compute=args.compute)
-
-    # --overlap: the local-window stage needs nothing from the global match; on a second HIP stream its workgroups
-    # fill the CUs the MFMA kernel's last round leaves idle (both streams are joined by the final barrier)
-    side = torch.cuda.Stream(device=device) if args.overlap else None
-
-    def step(i, bank, bank_rows, bank_lab, halo):
-        cur = frame_emb(i)
-        prev = frame_emb(i - 1) if i > 0 else (halo if halo is not None else frame_emb(0))
-        if side is not None:
-            with torch.cuda.stream(side):
-                l = ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), prev_labs[i % 8], N_IDS, LOCAL_D)
-        if bank is None:
-            g = ops.global_match(bank_rows, cur.permute(1, 2, 0), bank_lab, N_IDS, normalize=True,
-                                 mem=gmap[i % 104], compute=args.compute)
-        else:
-            qsrc = packed[i % len(packed)] if packed is not None else cur.permute(1, 2, 0)
-            g = bank.match(qsrc, normalize=True, mem=gmap[i % 104])
-        if side is None:
-            l = ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), prev_labs[i % 8], N_IDS, LOCAL_D)
-        return g, l
-
-    def barrier():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # warm-up (untimed)
-    if side is not None:
-        side.wait_stream(torch.cuda.current_stream(device))  # the synthetic frames were produced on the main stream
-    bank_rows, bank_lab, halo = build_bank()
-    bank = prepare(bank_rows, bank_lab)
-    for i in range(Wm):
-        step(i, bank, bank_rows, bank_lab, halo)
-    barrier()
-
-    # timed: the bank exchange + the bank's one-off sort/pack + exactly K frames
-    _lib.check(lib.manet_profile_begin(K), "manet_profile_begin")
-    barrier()
-    t0 = time.perf_counter()
-    bank_rows, bank_lab, halo = build_bank()
-    bank = prepare(bank_rows, bank_lab)
-    for i in range(K):
-        step(i, bank, bank_rows, bank_lab, halo)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ms, lms = (ctypes.c_float * K)(), (ctypes.c_float * K)()
-    nrec, nloc = ctypes.c_int(0), ctypes.c_int(0)
-    _lib.check(lib.manet_profile_end2(ms, K, ctypes.byref(nrec), lms, K, ctypes.byref(nloc)), "manet_profile_end2")
-    kern_ms = float(np.mean([ms[i] for i in range(nrec.value)])) if nrec.value else float("nan")
-    local_ms = float(np.mean([lms[i] for i in range(nloc.value)])) if nloc.value else float("nan")
-
+    if args.scaling == "strong":
+        K = max(1, 64 // world)
+    T = CONFIGS[args.cfg]["T"]
+    # this rank's K frames of the clip (synthetic embeddings, resident in HBM); the clip is at least long enough to
+    # contain T distinct annotated frames; only K are timed
+    wl = Workload(args.cfg, args.compute, args.emb, device, rank, world, n_local=max(K, -(-T // world)))
+    r = run_leg(wl, K, Wm, args, lib, use_dist=use_dist, one_shot=args.one_shot, prepacked=args.prepacked,
+                overlap=args.overlap, ownership=args.bank_ownership)
+    elapsed = r["elapsed"]
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    line = None
     if rank == 0:
-        N, M = H * W, int(bank_rows.shape[0])
-        assert M == T_BANK * H * W, "bank must hold T_BANK distinct frames"
-        flops = 2.0 * N * M * C  # algorithmic flops of one launch (SURVEY.md 8d)
-        achieved = flops / (kern_ms * 1e-3) / 1e12
-        # HBM/fabric bytes of the dominant kernel come from the tracked rocprofv3 --pmc capture of THIS command line
-        # (PMC counters cannot be read from inside the run); the file records where and when it was measured
-        traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "traffic_cfg%d_%s.json" % (args.cfg, args.compute))
-        if os.path.exists(tp):
-            try:
-                tj = json.load(open(tp))
-                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), {k: tj.get(k) for k in ("source", "captured_at", "kernel")}
-            except Exception:
-                traffic = None
+        bank_rows, bank_lab = r["bank_rows"], r["bank_lab"]
+        M = int(bank_rows.shape[0])
+        assert M == wl.T * wl.H * wl.W, "bank must hold T distinct frames"
+        roof, local = roofline_blocks(wl, r["kern_ms"], r["local_ms"], overlap=args.overlap)
         line = {
             "metric": "propagated frames/sec at 480p, 5-frame memory",
             "value": world * K / elapsed,
@@ -354,45 +535,39 @@ def main():
             "warmup": Wm,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.compute,
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: grid %dx%d, C=%d, %d-frame fully-labelled bank "
-                                   "(M=%d), %d ids, %s arithmetic, %s-stored embeddings; step = query pack%s + global "
-                                   "match + fused normalise/min-merge + local match d=%d; bank %s"
-                                   % (args.cfg - 1, H, W, C, T_BANK, M, N_IDS, args.compute, args.emb,
-                                      " (done by the producer, untimed)" if args.prepacked else "", LOCAL_D,
-                                      "re-sorted/re-packed every frame (one-shot API)" if args.one_shot else
-                                      "sorted/packed once per clip inside the timed region"),
-                       "frames_per_gpu": K, "bank_exchange": "1 RCCL all-gather in the timed region" if world > 1
-                       else "none (1 GPU)"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": {"f32": "global_match_f32_pipe_kernel<50>",
-                                    "bf16": "global_match_bf16_wide_kernel<7, 0>",
-                                    "bf16x3": "global_match_bf16_kernel<7, true, 1, true>"}[args.compute],
-                         "kernel_ms": kern_ms,
-                         "algorithmic_flops_per_launch": flops},
-            # the HBM-bound stage of the path: pooling pass + fused window/min kernel, HIP events over
-            # both launches; algorithmic bytes = both embeddings read once + labels + the [h,w,n_ids] result
-            "local_stage": (lambda b: {"bound": "hbm", "achieved": b / (local_ms * 1e-3) / 1e9, "peak": 8000.0,
-                                       "unit": "GB/s", "frac": b / (local_ms * 1e-3) / 8e12, "stage_ms": local_ms,
-                                       "algorithmic_bytes": b, "max_distance": LOCAL_D})(
-                2.0 * (2 if args.emb == "bf16" else 4) * C * H * W + 4.0 * H * W * (1 + N_IDS)) if not args.overlap else None,
+            "config": {"workload": wl.describe(args), "frames_per_gpu": K,
+                       "clip_frames": world * K,
+                       "bank_exchange": "1 RCCL all-gather in the timed region" if world > 1 else "none (1 GPU)"},
+            "roofline": roof,
+            "local_stage": local,
+            # what the collective of the timed region saw: a real N-rank run shows world == n_gpus and backend nccl
+            "collective": r["collective"] if use_dist else None,
         }
+        if world == 1 and not args.one_shot and not use_dist:
+            # r1's definition next to the headline: the bank re-sorted / re-packed every frame, one-shot API
+            r1s = run_leg(wl, min(K, 10), 2, args, lib, one_shot=True)
+            line["value_one_shot"] = min(K, 10) / r1s["elapsed"]
         if not args.no_cpu_baseline and world == 1:
             # the same frame once more on the GPU (fresh map, outside the timed region) for the parity figures
-            g_chk = ops.global_match(bank_rows, frame_emb(0).permute(1, 2, 0), bank_lab, N_IDS, normalize=True,
+            g_chk = ops.global_match(bank_rows, wl.frame_emb(0).permute(1, 2, 0), bank_lab, wl.n_ids, normalize=True,
                                      compute=args.compute)
-            l_chk = ops.local_match(frame_emb(1).permute(1, 2, 0), frame_emb(0).permute(1, 2, 0), prev_labs[0], N_IDS,
-                                    LOCAL_D)
-            # bf16 arithmetic is checked against the oracle on the bf16-rounded embeddings (its quant_bf16 mode)
-            line["cpu_baseline"], line["parity"] = cpu_baseline(bank_rows, bank_lab, frame_emb(0), frame_emb(1),
-                                                                prev_labs[0], g_chk, l_chk,
-                                                                quant_bf16=(args.compute == "bf16"))
+            l_chk = ops.local_match(wl.frame_emb(1).permute(1, 2, 0), wl.frame_emb(0).permute(1, 2, 0), wl.prev_labs[0],
+                                    wl.n_ids, wl.d)
+            # (bf16 arithmetic on bf16-stored embeddings: the oracle's fp32 formula on the same stored values)
+            line["cpu_baseline"], line["parity"] = cpu_baseline(wl, bank_rows, bank_lab, g_chk, l_chk)
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None  # measured on rank 0 at N=1 only (see the N=1 line)
+        if world == 1 and not use_dist and not args.no_also and args.cfg == 2 and args.compute == "f32":
+            del wl, r, bank_rows, bank_lab
+            torch.cuda.empty_cache()
+            line["also"] = []
+            for cfg_, compute_ in ((3, "bf16"), (5, "bf16")):
+                line["also"].append(also_leg(cfg_, compute_, device, lib, args))
+                torch.cuda.empty_cache()
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

@@ -4,22 +4,35 @@ The reference is single-GPU.  What parallelises in its propagatio
 (test.py:237-259) is the label-independent matching work: the global match of frame t needs only
 (bank, embedding_t, stored map_t) and the local distance volume needs (embedding_t, embedding_t-1).
 So a clip is cut into contiguous frame blocks, one per rank, and the only data every rank lacks is
-  * the memory bank: the embeddings + labels of the annotated frames, which were extracted by
-    whichever ranks own those frames, and
+  * the memory bank: the embeddings + labels of the annotated frames, and
   * a one-frame halo: the embedding of the frame just before the rank's block.
 Both travel in ONE all-gather (`exchange_bank_and_halo`): each rank contributes a fixed-size slab
-  [ bank frames it owns (padded to the largest number any rank owns) | their labels | its last frame ]
+  [ its bank slots | their labels | its last frame ]
 and afterwards every rank holds the full bank and its left neighbour's last frame.  With backend
 "nccl" this is a single ncclAllGather on RCCL; over 7 x ~153 GB/s xGMI links a direct all-gather of
 a slab costs slab_bytes / 153 GB/s (a 480p frame is 10.3 MB -> ~0.07 ms per frame in the slab).
 There is no other collective on the data path; results stay on the rank that computed them.
 
+Who ships which bank frame (`ownership`):
+  "block"        the rank whose frame block contains the annotated frame (it has the embedding anyway).
+                 The slab then holds as many slots as the busiest rank owns -- up to T when the annotations
+                 cluster in one block.
+  "round_robin"  bank frame number j (ascending frame order) is shipped by rank j % world: the slab is
+                 ALWAYS ceil(T / world) slots.  The shipping rank needs that frame's embedding: when it is
+                 not inside its block the caller hands it over in `extra_embeddings` (feature extraction
+                 of the T annotated frames is dealt round-robin as well -- T extra encoder calls per clip
+                 over the whole node, against (T - ceil(T / world)) x 10.3 MB less in every rank's slab).
+
 The same code runs on CPU tensors with the gloo backend (tests/test_clip_parallel.py).
 """
-import math
+import time
 
 import torch
 import torch.distributed as dist
+
+# what the last exchange_bank_and_halo() of this process did (bench.py echoes it in its JSON line so that a run with
+# N ranks is self-evidencing): backend, world size seen by the collective, slab bytes, all-gather time
+LAST_EXCHANGE = {}
 
 
 def shard_frames(num_frames, world_size, rank):
@@ -38,14 +51,20 @@ def owner_of(frame, num_frames, world_size):
     raise ValueError("frame %d outside clip of %d frames" % (frame, num_frames))
 
 
-def bank_slots(bank_frames, num_frames, world_size):
+def bank_slots(bank_frames, num_frames, world_size, ownership="block"):
     """How the annotated (bank) frames map onto the ranks' slabs.
 
     Returns (slots_per_rank, [(rank, slot, frame), ...]) with frames of one rank in ascending order.
     """
     per_rank = [[] for _ in range(world_size)]
-    for f in sorted(bank_frames):
-        per_rank[owner_of(f, num_frames, world_size)].append(f)
+    if ownership == "round_robin":
+        for j, f in enumerate(sorted(bank_frames)):
+            per_rank[j % world_size].append(f)
+    elif ownership == "block":
+        for f in sorted(bank_frames):
+            per_rank[owner_of(f, num_frames, world_size)].append(f)
+    else:
+        raise ValueError("ownership must be 'block' or 'round_robin'")
     slots = max(1, max(len(p) for p in per_rank))
     table = [(r, s, f) for r in range(world_size) for s, f in enumerate(per_rank[r])]
     return slots, table
@@ -65,14 +84,24 @@ def _all_gather_flat(slab, world, group):
     return out
 
 
+def _bytes(t):
+    return t.contiguous().reshape(-1).view(torch.uint8)
+
+
 def exchange_bank_and_halo(local_embeddings, local_start, bank_frames, bank_labels, num_frames,
-                           group=None):
+                           group=None, ownership="block", extra_embeddings=None, timing=False):
     """One all-gather that gives every rank the full memory bank and its halo frame.
 
     local_embeddings  [f_local, C, h, w] float32 or bfloat16 -- this rank's frames (C-major, as extract_feature
-                      produces them, in the producer's storage type), frame i is clip frame local_start + i
+                      produces them, in the producer's storage type), frame i is clip frame local_start + i.
+                      A rank without frames passes an EMPTY [0, C, h, w] tensor of the clip's storage type: its
+                      dtype sizes the slab (every rank's slab must have the same byte count).
     bank_frames       list of clip frame indices that form the memory bank (same on every rank)
-    bank_labels       dict frame -> int32 [h, w] labels, needed only for frames this rank owns
+    bank_labels       dict frame -> int32 [h, w] labels, needed only for the frames this rank ships
+    ownership         "block" | "round_robin" (module docstring)
+    extra_embeddings  dict frame -> [C, h, w]: embeddings of bank frames this rank ships but does not hold in its
+                      block (round_robin)
+    timing            synchronise around the collective and record its wall time in LAST_EXCHANGE
     Returns (bank_emb [T, C, h, w], bank_lab [T, h, w] int32, halo [C, h, w] or None for rank 0),
     bank frames in ascending frame order.  The slab is a byte buffer: embeddings and labels travel bit for bit.
     """
@@ -80,30 +109,62 @@ def exchange_bank_and_halo(local_embeddings, local_start, bank_frames, bank_labe
     rank = dist.get_rank(group)
     f_local, C, h, w = local_embeddings.shape
     dev = local_embeddings.device
-    dt = local_embeddings[0].dtype if f_local > 0 else torch.float32
+    dt = local_embeddings.dtype  # (an empty block still carries the clip's storage type)
     esz = torch.empty((), dtype=dt).element_size()
-    slots, table = bank_slots(bank_frames, num_frames, world)
+    slots, table = bank_slots(bank_frames, num_frames, world, ownership)
     frame_b = C * h * w * esz
     lab_b = h * w * 4
     slab_b = slots * (frame_b + lab_b) + frame_b
-    slab = torch.zeros(slab_b, dtype=torch.uint8, device=dev)
-    for (r, s, f) in table:
-        if r != rank:
-            continue
-        emb = local_embeddings[f - local_start].contiguous().reshape(-1).view(torch.uint8)
-        slab[s * frame_b:(s + 1) * frame_b] = emb
-        lab = bank_labels[f].to(device=dev, dtype=torch.int32).contiguous().reshape(-1).view(torch.uint8)
-        off = slots * frame_b + s * lab_b
-        slab[off:off + lab_b] = lab
-    if f_local > 0:
-        slab[slots * (frame_b + lab_b):] = local_embeddings[f_local - 1].contiguous().reshape(-1).view(torch.uint8)
+    mine = [(s, f) for (r, s, f) in table if r == rank]  # ascending slot order
+
+    def emb_of(f):
+        if extra_embeddings is not None and f in extra_embeddings:
+            e = extra_embeddings[f]
+            if e.dtype != dt:
+                raise ValueError("extra_embeddings[%d] is %s, the clip is stored as %s" % (f, e.dtype, dt))
+            return e
+        if not (local_start <= f < local_start + f_local):
+            raise ValueError("rank %d ships bank frame %d but holds neither it nor an extra embedding" % (rank, f))
+        return local_embeddings[f - local_start]
+
+    # the slab as ONE concatenation of byte views (a single copy kernel on the device)
+    parts = [_bytes(emb_of(f)) for (_, f) in mine]
+    if len(mine) < slots:
+        parts.append(torch.zeros((slots - len(mine)) * frame_b, dtype=torch.uint8, device=dev))
+    parts += [_bytes(bank_labels[f].to(device=dev, dtype=torch.int32)) for (_, f) in mine]
+    if len(mine) < slots:
+        parts.append(torch.zeros((slots - len(mine)) * lab_b, dtype=torch.uint8, device=dev))
+    parts.append(_bytes(local_embeddings[f_local - 1]) if f_local > 0
+                 else torch.zeros(frame_b, dtype=torch.uint8, device=dev))
+    slab = torch.cat(parts)
+    assert slab.numel() == slab_b
+
+    if timing:
+        if slab.is_cuda:
+            torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
     gathered = _all_gather_flat(slab, world, group).view(world, slab_b)
+    if timing:
+        if slab.is_cuda:
+            torch.cuda.synchronize(dev)
+        ag_ms = (time.perf_counter() - t0) * 1e3
+    else:
+        ag_ms = None
+    LAST_EXCHANGE.clear()
+    LAST_EXCHANGE.update({"backend": dist.get_backend(group), "world": world, "slab_bytes": int(slab_b),
+                          "gathered_bytes": int(world * slab_b), "bank_slots_per_rank": int(slots),
+                          "ownership": ownership, "allgather_ms": ag_ms})
+
+    # bank frames in ascending frame order: one index_select over the [world * slots] slot rows of the gathered
+    # buffer (rank stride slab_b, slot stride frame_b / lab_b) -- no per-frame Python copies
     order = sorted(table, key=lambda t: t[2])
-    bank_emb = torch.stack([gathered[r, s * frame_b:(s + 1) * frame_b].view(dt).view(C, h, w)
-                            for (r, s, f) in order])
-    bank_lab = torch.stack([gathered[r, slots * frame_b + s * lab_b:
-                                     slots * frame_b + (s + 1) * lab_b].view(torch.int32).view(h, w)
-                            for (r, s, f) in order])
+    idx = torch.tensor([r * slots + s for (r, s, f) in order], dtype=torch.long, device=gathered.device)
+    emb_rows = torch.as_strided(gathered, (world, slots, frame_b), (slab_b, frame_b, 1))
+    lab_rows = torch.as_strided(gathered, (world, slots, lab_b), (slab_b, lab_b, 1), slots * frame_b)
+    T = len(order)
+    ri, si = idx // slots, idx % slots
+    bank_emb = emb_rows[ri, si].view(dt).view(T, C, h, w)  # (advanced indexing: one gather kernel, contiguous result)
+    bank_lab = lab_rows[ri, si].view(torch.int32).view(T, h, w)
     halo = None
     if rank > 0:
         # left neighbour with at least one frame (ranks can be empty when world > num_frames)
@@ -115,10 +176,10 @@ def exchange_bank_and_halo(local_embeddings, local_start, bank_frames, bank_labe
     return bank_emb, bank_lab, halo
 
 
-def slab_bytes(C, h, w, bank_frames, num_frames, world_size, elem_size=4):
-    """Bytes each rank contributes to the all-gather (for the xGMI cost model in DESIGN.md).  The slab holds
-    as many bank slots as the rank that owns MOST bank frames needs (bank_slots): ceil(T / world) when the
-    annotated frames are spread over the clip, up to T when they cluster in one rank's block -- every rank
-    then ships that many (mostly empty) slots."""
-    slots, _ = bank_slots(bank_frames, num_frames, world_size)
+def slab_bytes(C, h, w, bank_frames, num_frames, world_size, elem_size=4, ownership="block"):
+    """Bytes each rank contributes to the all-gather (for the xGMI cost model in DESIGN.md).  ownership "block": the
+    slab holds as many bank slots as the rank that owns MOST bank frames needs -- ceil(T / world) when the annotated
+    frames are spread over the clip, up to T when they cluster in one rank's block; "round_robin": always
+    ceil(T / world)."""
+    slots, _ = bank_slots(bank_frames, num_frames, world_size, ownership)
     return slots * (C * h * w * elem_size + h * w * 4) + C * h * w * elem_size

@@ -35,6 +35,13 @@ def test_bank_slots():
     assert cp.slab_bytes(100, 120, 214, spread, 64, 8) == 4 * (1 * (100 * 120 * 214 + 120 * 214) + 100 * 120 * 214)
     assert cp.slab_bytes(100, 120, 214, [0, 1, 2, 3, 4], 64, 8) == 4 * (5 * (100 * 120 * 214 + 120 * 214) + 100 * 120 * 214)
     assert cp.slab_bytes(100, 120, 214, spread, 64, 8, elem_size=2) == 2 * 100 * 120 * 214 + 4 * 120 * 214 + 2 * 100 * 120 * 214
+    # round-robin shipping: ceil(T / world) slots wherever the annotations sit
+    slots, table = cp.bank_slots([0, 1, 2, 3, 4], 64, 8, ownership="round_robin")
+    assert slots == 1 and table == [(0, 0, 0), (1, 0, 1), (2, 0, 2), (3, 0, 3), (4, 0, 4)]
+    slots, table = cp.bank_slots([0, 1, 2, 3, 4], 64, 2, ownership="round_robin")
+    assert slots == 3 and [t for t in table if t[0] == 1] == [(1, 0, 1), (1, 1, 3)]
+    assert cp.slab_bytes(100, 120, 214, [0, 1, 2, 3, 4], 64, 8, ownership="round_robin") == \
+        4 * (1 * (100 * 120 * 214 + 120 * 214) + 100 * 120 * 214)
 
 
 def _free_port():
@@ -52,7 +59,7 @@ def _clip(F, C, h, w):
     return emb, lab
 
 
-def _worker(rank, world, port, F, bank_frames, q, bf16=False):
+def _worker(rank, world, port, F, bank_frames, q, bf16=False, ownership="block"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -63,8 +70,21 @@ def _worker(rank, world, port, F, bank_frames, q, bf16=False):
             emb = emb.bfloat16()
         s, e = cp.shard_frames(F, world, rank)
         local = emb[s:e].clone()
-        labels = {f: lab[f] for f in bank_frames if s <= f < e}  # a rank only knows its own frames' labels
-        bank_emb, bank_lab, halo = cp.exchange_bank_and_halo(local, s, bank_frames, labels, F)
+        if ownership == "block":
+            labels = {f: lab[f] for f in bank_frames if s <= f < e}  # a rank only knows its own frames' labels
+            extra = None
+        else:  # bank frame number j is shipped (and was extracted) by rank j % world
+            ship = [f for j, f in enumerate(sorted(bank_frames)) if j % world == rank]
+            labels = {f: lab[f] for f in ship}
+            extra = {f: emb[f].clone() for f in ship if not (s <= f < e)}
+        bank_emb, bank_lab, halo = cp.exchange_bank_and_halo(local, s, bank_frames, labels, F, ownership=ownership,
+                                                             extra_embeddings=extra, timing=(rank == 0))
+        info = cp.LAST_EXCHANGE
+        assert info["world"] == world and info["backend"] == "gloo"
+        assert info["slab_bytes"] == cp.slab_bytes(C, h, w, bank_frames, F, world, elem_size=emb.element_size(),
+                                                   ownership=ownership)
+        if ownership == "round_robin":
+            assert info["bank_slots_per_rank"] == -(-len(bank_frames) // world)
         order = sorted(bank_frames)
         ok = torch.equal(bank_emb, emb[order]) and torch.equal(bank_lab, lab[order])
         if rank == 0 or s == 0:
@@ -76,13 +96,17 @@ def _worker(rank, world, port, F, bank_frames, q, bf16=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,F,bank,bf16", [(2, 8, [0, 2, 5, 6, 7], False), (3, 7, [1, 3], False), (2, 3, [2], False),
-                                               (2, 8, [0, 2, 5, 6, 7], True)])
-def test_exchange_bank_and_halo_gloo(world, F, bank, bf16):
+@pytest.mark.parametrize("world,F,bank,bf16,ownership", [
+    (2, 8, [0, 2, 5, 6, 7], False, "block"), (3, 7, [1, 3], False, "block"), (2, 3, [2], False, "block"),
+    (2, 8, [0, 2, 5, 6, 7], True, "block"),
+    (3, 2, [0, 1], True, "block"),         # world > frames with 2-byte storage: the empty rank must size its slab alike
+    (2, 8, [0, 1, 2, 3, 7], False, "round_robin"),  # clustered annotations: slab stays ceil(T / world) slots
+    (3, 9, [4, 5], True, "round_robin")])
+def test_exchange_bank_and_halo_gloo(world, F, bank, bf16, ownership):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, F, bank, q, bf16)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, F, bank, q, bf16, ownership)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
