@@ -13,8 +13,9 @@ after rough_ROI), 1 object (+ background = 2 ids), fp32.
 
 Timed region (exactly K steps + the clip's one-off work): the bank exchange (N > 1), ONE sort/pack
 of the memory bank (it is the same for every frame of the propagation loop, test.py:237-259 -- what
-the drop-in module does through its PreparedBank cache), then K frames, each = query pack + global
-match + fused epilogue + local match.  `--one-shot` re-sorts / re-packs the bank every frame through
+the drop-in module does through its PreparedBank cache), then K frames, each = frame prepare
+(query operand image + pooled plane from ONE read of the new embedding) + global match + fused
+epilogue + local match (fused window kernel on the two prepared frames).  `--one-shot` re-sorts / re-packs the bank every frame through
 the one-shot API instead (r1's definition; the reference recomputes everything per frame) -- the headline line carries that number
 too (`value_one_shot`).  `--prepacked` takes the per-frame operands as given (prepared when the
 embeddings were produced).
@@ -128,7 +129,7 @@ class Workload:
     def describe(self, args):
         M = self.T * self.H * self.W
         return ("BASELINE configs[%d]: grid %dx%d, C=%d, %d-frame fully-labelled bank (M=%d), %d ids, %s arithmetic, "
-                "%s-stored embeddings; step = query pack%s + global match + fused "
+                "%s-stored embeddings; step = frame prepare (query operand + pooled plane, one read of the embedding)%s + global match + fused "
                 "normalise/min-merge + local match d=%d; bank %s"
                 % (self.cfg - 1, self.H, self.W, C, self.T, M, self.n_ids, self.compute, self.emb,
                    " (done by the producer, untimed)" if args.prepacked else "", self.d,
@@ -184,28 +185,53 @@ def run_leg(wl, K, Wm, args, lib, use_dist=False, one_shot=False, prepacked=Fals
         bank_rows = bank_emb.permute(0, 2, 3, 1).reshape(-1, C)
         return bank_rows, bank_lab.reshape(-1), halo
 
-    packed = None
-    if prepacked:  # the producer's job: one operand image per resident frame
-        packed = [ops.PackedQuery(f.permute(1, 2, 0), compute=wl.compute) for f in wl.local_emb]
+    prepared_all = None
+    if prepacked:  # the producer's job: every resident frame prepared when its embedding was produced
+        prepared_all = ops.prepare_frames(wl.local_emb, compute=wl.compute, max_distance=wl.d)
 
     def prepare(bank_rows, bank_lab):
         """the clip's one-off: sort + pack the memory bank (None in --one-shot mode)"""
         return None if one_shot else ops.PreparedBank(bank_rows, bank_lab, wl.n_ids, compute=wl.compute)
 
+    preset = wl.d >= 11  # the fused local kernel of wide windows wants `out` pre-set to 1.0: rides in the prepare launch
+    state = {"prev": None}
+
+    def first_prev(halo):
+        """the frame before this rank's first one, prepared once per clip (its plane is all the local match needs)"""
+        if one_shot:
+            return
+        if prepared_all is not None and halo is None:
+            state["prev"] = prepared_all[0]
+        else:
+            state["prev"] = ops.prepare_frames(halo if halo is not None else wl.frame_emb(0), compute=wl.compute,
+                                               max_distance=wl.d)
+
     def step(i, bank, bank_rows, bank_lab, halo):
         cur = wl.frame_emb(i)
-        prev = wl.frame_emb(i - 1) if i > 0 else (halo if halo is not None else wl.frame_emb(0))
-        if side is not None:
-            with torch.cuda.stream(side):
-                l = ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), wl.prev_labs[i % 8], wl.n_ids, wl.d)
-        if bank is None:
+        if bank is None:  # --one-shot: the stateless per-call API, everything recomputed per frame (r1's step)
+            prev = wl.frame_emb(i - 1) if i > 0 else (halo if halo is not None else wl.frame_emb(0))
             g = ops.global_match(bank_rows, cur.permute(1, 2, 0), bank_lab, wl.n_ids, normalize=True,
                                  mem=wl.gmap[i % 104], compute=wl.compute)
-        else:
-            qsrc = packed[i % len(packed)] if packed is not None else cur.permute(1, 2, 0)
-            g = bank.match(qsrc, normalize=True, mem=wl.gmap[i % 104])
-        if side is None:
             l = ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), wl.prev_labs[i % 8], wl.n_ids, wl.d)
+            return g, l
+        l_out = torch.empty((wl.H, wl.W, wl.n_ids), dtype=torch.float32, device=device)
+        if prepared_all is not None:
+            fcur, have_preset = prepared_all[i % len(prepared_all)], False
+        else:  # ONE read of the new embedding: query operand image + pooled plane (+ the pre-set of l_out)
+            fcur = ops.prepare_frames(cur, compute=wl.compute, max_distance=wl.d, preset=l_out if preset else None)
+            have_preset = preset
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                l = ops.local_match_frames(state["prev"], fcur, wl.prev_labs[i % 8], wl.n_ids, out=l_out,
+                                           out_is_preset=have_preset)
+        g = bank.match(fcur, normalize=True, mem=wl.gmap[i % 104])
+        if side is None:
+            l = ops.local_match_frames(state["prev"], fcur, wl.prev_labs[i % 8], wl.n_ids, out=l_out,
+                                       out_is_preset=have_preset)
+        else:  # the side stream's reads end before this stream recycles the previous frame's operands
+            torch.cuda.current_stream(device).wait_stream(side)
+        state["prev"] = fcur
         return g, l
 
     def barrier():
@@ -219,30 +245,35 @@ def run_leg(wl, K, Wm, args, lib, use_dist=False, one_shot=False, prepacked=Fals
         side.wait_stream(torch.cuda.current_stream(device))  # the synthetic frames were produced on the main stream
     bank_rows, bank_lab, halo = build_bank(False)
     bank = prepare(bank_rows, bank_lab)
+    first_prev(halo)
     for i in range(Wm):
         step(i, bank, bank_rows, bank_lab, halo)
     barrier()
 
     # timed: the bank exchange + the bank's one-off sort/pack + exactly K frames
-    _lib.check(lib.manet_profile_begin(K), "manet_profile_begin")
+    _lib.check(lib.manet_profile_begin(K + 1), "manet_profile_begin")
     barrier()
     t0 = time.perf_counter()
     bank_rows, bank_lab, halo = build_bank(True)
     bank = prepare(bank_rows, bank_lab)
+    first_prev(halo)
     for i in range(K):
         step(i, bank, bank_rows, bank_lab, halo)
     barrier()
     elapsed = time.perf_counter() - t0
     ms, lms = (ctypes.c_float * K)(), (ctypes.c_float * K)()
     nrec, nloc = ctypes.c_int(0), ctypes.c_int(0)
+    pms, npr = (ctypes.c_float * (K + 1))(), ctypes.c_int(0)
+    _lib.check(lib.manet_profile_read(2, pms, K + 1, ctypes.byref(npr)), "manet_profile_read")
+    prep_ms = float(np.mean([pms[i] for i in range(npr.value)])) if npr.value else None
     _lib.check(lib.manet_profile_end2(ms, K, ctypes.byref(nrec), lms, K, ctypes.byref(nloc)), "manet_profile_end2")
     kern_ms = float(np.mean([ms[i] for i in range(nrec.value)])) if nrec.value else float("nan")
     local_ms = float(np.mean([lms[i] for i in range(nloc.value)])) if nloc.value else float("nan")
-    return {"elapsed": elapsed, "kern_ms": kern_ms, "local_ms": local_ms, "bank_rows": bank_rows, "bank_lab": bank_lab,
-            "collective": timing["collective"]}
+    return {"elapsed": elapsed, "kern_ms": kern_ms, "local_ms": local_ms, "prep_ms": prep_ms, "bank_rows": bank_rows,
+            "bank_lab": bank_lab, "collective": timing["collective"]}
 
 
-def roofline_blocks(wl, kern_ms, local_ms, overlap=False):
+def roofline_blocks(wl, kern_ms, local_ms, overlap=False, prep_ms=None):
     N, M = wl.H * wl.W, wl.T * wl.H * wl.W
     flops = 2.0 * N * M * C  # algorithmic flops of one launch
     achieved = flops / (kern_ms * 1e-3) / 1e12
@@ -255,7 +286,12 @@ def roofline_blocks(wl, kern_ms, local_ms, overlap=False):
     # the HBM-bound stage of the path: HIP events over the local stage's launches
     local = None if overlap else {"bound": "hbm", "achieved": b / (local_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": b / (local_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
-                                  "stage_ms": local_ms, "algorithmic_bytes": b, "max_distance": wl.d}
+                                  "stage_ms": local_ms, "algorithmic_bytes": b, "max_distance": wl.d,
+                                  "launches": "fused window/min kernel only (the pooled planes come out of the frame "
+                                              "prepare launch, which also writes the global match's query operand: "
+                                              "frame_prepare_ms)" if prep_ms is not None else
+                                              "pooling pass + fused kernel (one-shot API)",
+                                  "frame_prepare_ms": prep_ms}
     return roof, local
 
 
@@ -407,7 +443,7 @@ def also_leg(cfg, compute, device, lib, args):
     wl = Workload(cfg, compute, "bf16" if compute != "f32" else "f32", device, n_local=8, keep_f32=True)
     K, Wm = args.also_steps, 2
     r = run_leg(wl, K, Wm, args, lib)
-    roof, local = roofline_blocks(wl, r["kern_ms"], r["local_ms"])
+    roof, local = roofline_blocks(wl, r["kern_ms"], r["local_ms"], prep_ms=r["prep_ms"])
     leg = {"workload": wl.describe(args), "cfg": cfg, "dtype": compute, "steps": K, "warmup": Wm,
            "value": K / r["elapsed"], "unit": "frames/s", "ms_per_step": r["elapsed"] / K * 1e3,
            "kernel_ms": r["kern_ms"], "roofline": roof, "local_stage": local}
@@ -516,6 +552,7 @@ def main():
     from cvpr2020_manet_amd import _lib, ops
     lib = _lib.load()
     for kv in filter(None, args.tune.split(",")):
+        os.environ["MANET_TUNING"] = "1"  # experiments: the setters refuse without the opt-in
         k_, v_ = kv.split("=")
         _lib.check(lib.manet_tune_set(int(k_), int(v_)), "manet_tune_set")
 
@@ -539,7 +576,7 @@ def main():
         bank_rows, bank_lab = r["bank_rows"], r["bank_lab"]
         M = int(bank_rows.shape[0])
         assert M == wl.T * wl.H * wl.W, "bank must hold T distinct frames"
-        roof, local = roofline_blocks(wl, r["kern_ms"], r["local_ms"], overlap=args.overlap)
+        roof, local = roofline_blocks(wl, r["kern_ms"], r["local_ms"], overlap=args.overlap, prep_ms=r["prep_ms"])
         line = {
             "metric": "propagated frames/sec at 480p, 5-frame memory",
             "value": world * K / elapsed,

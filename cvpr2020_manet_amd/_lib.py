@@ -64,12 +64,18 @@ SIGNATURES = {
     "manet_local_match_backward_workspace_bytes": (_i, [_i, _i, _i, _i, _szp]),
     "manet_local_match_backward_f32": (_i, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i, _i, _i,
                                             _i, _i, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "manet_frame_workspace_bytes": (_i, [_i, _i, _i, _i, _i, _szp]),
+    "manet_frame_prepare": (_i, [_vp, _i, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i64,
+                                 ctypes.c_uint32, _vp]),
+    "manet_local_match_frames": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "manet_profile_read": (_i, [_i, ctypes.POINTER(ctypes.c_float), _i, _ip]),
     "manet_correlation_backward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
 }
 
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2
 EMB_F32, EMB_BF16, EMB_PACKED = 0, 1, 2
 EPI_NORMALIZE = 1
+EPI_KEYS_ARMED = 2
 
 _lib = None
 

@@ -30,6 +30,7 @@
 // Numerics of the fp32 path: the MFMA is a k-ascending fmaf chain from 0, d = fmaf(-2, mm, xs+ys);
 // min is exact -- so the result is bit-identical to oracle/manet_oracle.c.
 #include "manet_common.h"
+#include "local_geom.h"
 
 namespace {
 
@@ -319,6 +320,42 @@ __device__ __forceinline__ void split3_bf16(float x, unsigned (&p)[3])
 __device__ __forceinline__ float emb_load(const float *p, long i) { return p[i]; }
 __device__ __forceinline__ float emb_load(const unsigned short *p, long i) { return bf2f(p[i]); }
 
+// One 16-byte unit of a row's operand image (see Geom): `row` = the row's kpad staged values.
+__device__ __forceinline__ f32x4 image_unit_f32(const float *row, int u)
+{
+    const float *p = row + 8 * (u >> 1) + (u & 1);
+    return f32x4{p[0], p[2], p[4], p[6]};
+}
+template <bool IS_QUERY>
+__device__ __forceinline__ uint4 image_unit_bf16(const float *row, int u, int hi_units, int C, float norm)
+{
+    const float scale = IS_QUERY ? -2.0f : 1.0f;  // the query operand is -2q (exact in bf16)
+    const bool lo = u >= hi_units;
+    const int uu = lo ? u - hi_units : u;
+    const int k0 = 16 * (uu >> 1) + 8 * (uu & 1);
+    unsigned e8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = row[k0 + e];
+        unsigned b = f2bf(x);
+        if (lo) b = f2bf(x - bf2f(b));
+        e8[e] = f2bf(scale * bf2f(b));
+    }
+    if (k0 + 8 > C && k0 < C + BF16_SPECIAL) {  // this unit holds norm slots (see Geom)
+        unsigned piece[3];
+        split3_bf16(norm, piece);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = k0 + e - C;  // 0..2: bank norm / query ones, 3..5: bank ones / query norm
+            if (j >= 0 && j < BF16_SPECIAL) {
+                const bool norm_slot = IS_QUERY ? (j >= 3) : (j < 3);
+                e8[e] = lo ? 0u : (norm_slot ? piece[j % 3] : 0x3f80u);
+            }
+        }
+    }
+    return make_uint4(e8[0] | (e8[1] << 16), e8[2] | (e8[3] << 16), e8[4] | (e8[5] << 16), e8[6] | (e8[7] << 16));
+}
+
 // bank (ROWS = 64) and query (ROWS = 32) pack: rows -> MFMA operand image (see Geom).
 // Rows are staged through LDS so that both the global reads (along k for row-major sources, along
 // rows for C-major sources) and the 16-byte image writes are coalesced.  |row|^2 is the k-ascending
@@ -393,42 +430,172 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const SRC *__restrict__ 
     if (compute == MANET_COMPUTE_F32) {
         for (int item = tid; item < units * ROWS; item += 256) {
             int r = item % ROWS, u = item / ROWS;
-            const float *row = rows + r * KP + 8 * (u >> 1) + (u & 1);
-            f32x4 v = {row[0], row[2], row[4], row[6]};
-            *(f32x4 *)(out0 + (r / IMG) * tile_bytes + ((long)u * IMG + r % IMG) * 16) = v;
+            *(f32x4 *)(out0 + (r / IMG) * tile_bytes + ((long)u * IMG + r % IMG) * 16) = image_unit_f32(rows + r * KP, u);
         }
         if (tid < ROWS) *(float *)(out0 + (tid / IMG) * tile_bytes + (long)units * IMG * 16 + (tid % IMG) * 4) = s_norm[tid];
     } else {
         const int hi_units = (compute == MANET_COMPUTE_BF16X3) ? units / 2 : units;
-        const float scale = IS_QUERY ? -2.0f : 1.0f;  // the query operand is -2q (exact in bf16)
         for (int item = tid; item < units * ROWS; item += 256) {
             int r = item % ROWS, u = item / ROWS;
-            const bool lo = u >= hi_units;
-            const int uu = lo ? u - hi_units : u;
-            const int k0 = 16 * (uu >> 1) + 8 * (uu & 1);
-            const float *row = rows + r * KP + k0;
-            unsigned e8[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float x = row[e];
-                unsigned b = f2bf(x);
-                if (lo) b = f2bf(x - bf2f(b));
-                e8[e] = f2bf(scale * bf2f(b));
-            }
-            if (k0 + 8 > C && k0 < C + BF16_SPECIAL) {  // this unit holds norm slots (see Geom)
-                unsigned piece[3];
-                split3_bf16(s_norm[r], piece);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int j = k0 + e - C;  // 0..2: bank norm / query ones, 3..5: bank ones / query norm
-                    if (j >= 0 && j < BF16_SPECIAL) {
-                        const bool norm_slot = IS_QUERY ? (j >= 3) : (j < 3);
-                        e8[e] = lo ? 0u : (norm_slot ? piece[j % 3] : 0x3f80u);
-                    }
-                }
-            }
             *(uint4 *)(out0 + (r / IMG) * tile_bytes + ((long)u * IMG + r % IMG) * 16) =
-                make_uint4(e8[0] | (e8[1] << 16), e8[2] | (e8[3] << 16), e8[4] | (e8[5] << 16), e8[6] | (e8[7] << 16));
+                image_unit_bf16<IS_QUERY>(rows + r * KP, u, hi_units, C, s_norm[r]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-frame prepare (the producer side of the path): ONE read of a frame's C-major embedding
+// writes BOTH per-frame operands of the propagation step --
+//   * the query operand image of the global match (what pack_rows_kernel<32,32> writes), and
+//   * the 2x2-average-pooled plane of the local match, padded with the reference's 1e20 (IntVOS.py:287), plus the
+//     fused local kernel's tile table (what lf_pool_pad_kernel writes; r2 read both full-resolution frames again for
+//     it, every frame: the stage moved 3x its algorithmic bytes) --
+// so a propagated frame reads its embedding from HBM once, and the previous frame's not at all (its plane was made when
+// it was the current frame).  Workgroup = one full-resolution row pair x XC columns, all channels, staged in LDS as
+// [pixel][k] (odd stride: the row-wise and the k-wise accesses are both conflict-free); grid.z = frame of the batch.
+// Blocks behind the data blocks fill the plane's top / bottom border rows, zero the image's padding rows, write the
+// tile table and serve one optional caller fill (the local match's `out` pre-set, IntVOS.py:429-430's 1.0).
+struct FramePrep {
+    const void *emb;
+    long s_f, s_y, s_x, s_c;
+    int h, w, C, compute, units, kpad;
+    char *ws;
+    long ws_stride, qblk_bytes, off_plane, off_tab;
+    int d, hp, wp, HPAD, WS;
+    long PS;
+    int TY, TX, nty, ntx;
+    long N, N_pad;
+    unsigned *fill_ptr;
+    long fill_words;
+    unsigned fill_value;
+    int n_data, nxc;
+};
+template <typename SRC, int XC>
+__global__ __launch_bounds__(256) void frame_prepare_kernel(const FramePrep A)
+{
+    constexpr int PIX = 2 * XC;
+    extern __shared__ __attribute__((aligned(16))) char pack_smem[];
+    const int tid = threadIdx.x;
+    const SRC *src = (const SRC *)A.emb + (long)blockIdx.z * A.s_f;
+    char *ws = A.ws + (long)blockIdx.z * A.ws_stride;
+    float *plane = (float *)(ws + A.off_plane);
+    const int C = A.C, kpad = A.kpad, units = A.units;
+    if ((int)blockIdx.x >= A.n_data) {  // ---- auxiliary blocks
+        const long gid = (long)(blockIdx.x - A.n_data) * 256 + tid, gstride = (long)(gridDim.x - A.n_data) * 256;
+        if (A.d >= 0) {
+            const int rows_b = A.HPAD - A.hp, WS4 = A.WS / 4;
+            const long items = (long)C * rows_b * WS4;
+            const f32x4 pad = {MANET_WRONG_LABEL_PADDING_DISTANCE, MANET_WRONG_LABEL_PADDING_DISTANCE,
+                               MANET_WRONG_LABEL_PADDING_DISTANCE, MANET_WRONG_LABEL_PADDING_DISTANCE};
+            for (long i = gid; i < items; i += gstride) {
+                const int c = (int)(i / ((long)rows_b * WS4));
+                const int rem = (int)(i - (long)c * rows_b * WS4);
+                const int rb = rem / WS4, q = rem - rb * WS4;
+                const int r = rb < A.d ? rb : A.hp + rb;  // rows [0, d) and [d + hp, HPAD)
+                *(f32x4 *)(plane + (long)c * A.PS + (long)r * A.WS + 4 * q) = pad;
+            }
+            int *tab = (int *)(ws + A.off_tab);
+            for (long i = gid; i <= A.nty + 1 + A.ntx; i += gstride)
+                tab[i] = i <= A.nty ? bilin_first((int)i * A.TY, A.hp, A.h) : bilin_first((int)(i - A.nty - 1) * A.TX, A.wp, A.w);
+        }
+        {  // rows N .. N_pad of the image: zero operands (their results are never read)
+            const long tail = A.N_pad - A.N;
+            for (long i = gid; i < tail * units; i += gstride) {
+                const long n = A.N + i % tail;
+                const int u = (int)(i / tail);
+                *(uint4 *)(ws + (n >> 5) * A.qblk_bytes + ((long)u * QB + (n & 31)) * 16) = make_uint4(0, 0, 0, 0);
+            }
+            if (A.compute == MANET_COMPUTE_F32)
+                for (long i = gid; i < tail; i += gstride) {
+                    const long n = A.N + i;
+                    *(float *)(ws + (n >> 5) * A.qblk_bytes + (long)units * QB * 16 + (n & 31) * 4) = 0.0f;
+                }
+        }
+        if (blockIdx.z == 0)
+            for (long i = gid; i < A.fill_words; i += gstride) A.fill_ptr[i] = A.fill_value;
+        return;
+    }
+    // ---- data blocks
+    const int KP = kpad + 1;
+    float *rows = (float *)pack_smem;           // [PIX][KP]
+    float *s_norm = rows + (long)PIX * KP;      // [PIX]
+    const int rp = blockIdx.x / A.nxc, cx = blockIdx.x - rp * A.nxc;
+    const int x0 = cx * XC, y0 = 2 * rp;
+    for (int idx = tid; idx < PIX * C; idx += 256) {  // lanes along x: row segments of the C-major source
+        const int k = idx / PIX, p = idx - k * PIX;
+        const int y = y0 + p / XC, x = x0 + p % XC;
+        rows[p * KP + k] = (y < A.h && x < A.w) ? emb_load(src, (long)y * A.s_y + (long)x * A.s_x + (long)k * A.s_c) : 0.0f;
+    }
+    for (int idx = tid; idx < PIX * (kpad - C); idx += 256) {
+        const int p = idx / (kpad - C), k = C + idx - p * (kpad - C);
+        rows[p * KP + k] = 0.0f;
+    }
+    __syncthreads();
+    if (tid < PIX) {  // |q|^2: the k-ascending fmaf chain of the oracle, as pack_rows_kernel
+        const float *row = rows + tid * KP;
+        float n = 0.0f;
+        if (A.compute == MANET_COMPUTE_BF16) {
+            for (int k = 0; k < C; ++k) {
+                const float x = bf2f(f2bf(row[k]));
+                n = fmaf(x, x, n);
+            }
+        } else {
+            for (int k = 0; k < C; ++k) n = fmaf(row[k], row[k], n);
+        }
+        s_norm[tid] = n;
+    }
+    // pooled plane row d + rp (IntVOS.py:282-284: window summed row-major, times 1/4)
+    if (A.d >= 0 && rp < A.hp) {
+        float *prow = plane + (long)(A.d + rp) * A.WS + A.d + x0 / 2;
+        for (int idx = tid; idx < (XC / 2) * C; idx += 256) {
+            const int c = idx / (XC / 2), px = idx - c * (XC / 2);
+            if (x0 / 2 + px < A.wp) {
+                const float *q = rows + (2 * px) * KP + c;
+                prow[(long)c * A.PS + px] = (((q[0] + q[KP]) + q[XC * KP]) + q[(XC + 1) * KP]) * 0.25f;
+            }
+        }
+        // the row's left / right border columns (the first / last column block of the row pair)
+        if (cx == 0)
+            for (int idx = tid; idx < A.d * C; idx += 256) {
+                const int c = idx / A.d, j = idx - c * A.d;
+                plane[(long)c * A.PS + (long)(A.d + rp) * A.WS + j] = MANET_WRONG_LABEL_PADDING_DISTANCE;
+            }
+        if (cx == A.nxc - 1) {
+            const int r0 = A.d + A.wp, nr = A.WS - r0;
+            for (int idx = tid; idx < nr * C; idx += 256) {
+                const int c = idx / nr, j = idx - c * nr;
+                plane[(long)c * A.PS + (long)(A.d + rp) * A.WS + r0 + j] = MANET_WRONG_LABEL_PADDING_DISTANCE;
+            }
+        }
+    }
+    __syncthreads();
+    // operand image: pixel (y, x) is query row n = y w + x -> block n / 32, row n % 32
+    if (A.compute == MANET_COMPUTE_F32) {
+        for (int item = tid; item < units * PIX; item += 256) {
+            const int p = item % PIX, u = item / PIX;
+            const int y = y0 + p / XC, x = x0 + p % XC;
+            if (y < A.h && x < A.w) {
+                const long n = (long)y * A.w + x;
+                *(f32x4 *)(ws + (n >> 5) * A.qblk_bytes + ((long)u * QB + (n & 31)) * 16) = image_unit_f32(rows + p * KP, u);
+            }
+        }
+        if (tid < PIX) {
+            const int y = y0 + tid / XC, x = x0 + tid % XC;
+            if (y < A.h && x < A.w) {
+                const long n = (long)y * A.w + x;
+                *(float *)(ws + (n >> 5) * A.qblk_bytes + (long)units * QB * 16 + (n & 31) * 4) = s_norm[tid];
+            }
+        }
+    } else {
+        const int hi_units = (A.compute == MANET_COMPUTE_BF16X3) ? units / 2 : units;
+        for (int item = tid; item < units * PIX; item += 256) {
+            const int p = item % PIX, u = item / PIX;
+            const int y = y0 + p / XC, x = x0 + p % XC;
+            if (y < A.h && x < A.w) {
+                const long n = (long)y * A.w + x;
+                *(uint4 *)(ws + (n >> 5) * A.qblk_bytes + ((long)u * QB + (n & 31)) * 16) =
+                    image_unit_bf16<true>(rows + p * KP, u, hi_units, C, s_norm[p]);
+            }
         }
     }
 }
@@ -1466,14 +1633,21 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
 }
 
 // decode + (sigmoid-0.5)*2 (IntVOS.py:611-612) + min-merge with the stored map (IntVOS.py:620-622)
-__global__ void global_finish_kernel(const unsigned *__restrict__ keys, long N, long N_pad, int n_ids,
+// MANET_EPI_KEYS_ARMED: the keys are put back to "no candidate" as they are read (every key, padding rows included), so
+// the next armed call on the same match workspace needs no fill launch
+__global__ void global_finish_kernel(unsigned *__restrict__ keys, long N, long N_pad, int n_ids,
                                      int flags, float *__restrict__ out, float *__restrict__ mem)
 {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((flags & MANET_EPI_KEYS_ARMED) && i >= N * n_ids && i < N_pad * n_ids) {
+        const long j = i - N * n_ids;  // the padding rows' keys: n = N + j / n_ids
+        keys[(size_t)(j % n_ids) * N_pad + N + j / n_ids] = 0xffffffffu;
+    }
     if (i >= N * n_ids) return;
     long n = i / n_ids;
     int o = (int)(i - n * n_ids);
     unsigned k = keys[(size_t)o * N_pad + n];
+    if (flags & MANET_EPI_KEYS_ARMED) keys[(size_t)o * N_pad + n] = 0xffffffffu;
     // an object with no bank row keeps the initial key: padding distance (IntVOS.py:81-83)
     float g = (k == 0xffffffffu) ? MANET_WRONG_LABEL_PADDING_DISTANCE : float_of(k);
     if (flags & MANET_EPI_NORMALIZE) g = manet_normalize_dist(g);
@@ -1748,7 +1922,100 @@ void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int
 
 }  // namespace
 
+ManetFrameLayout manet_frame_layout(int h, int w, int C, int compute, int max_distance)
+{
+    ManetFrameLayout F;
+    const MatchLayout ML = match_layout((int64_t)h * w, C, 1, compute);
+    F.N_pad = ML.N_pad;
+    F.off_image = 0;
+    F.image_bytes = (size_t)(ML.N_pad / QB) * ML.qblk_bytes;
+    F.off_plane = manet_align_up(F.image_bytes, 1024);
+    F.hp = h / 2;
+    F.wp = w / 2;
+    F.HPAD = F.WS = F.TY = F.TX = F.nty = F.ntx = 0;
+    F.PS = 0;
+    F.plane_bytes = F.tab_bytes = 0;
+    if (max_distance >= 0) {
+        const PoolPad G = lf_pool_pad(h, w, max_distance);
+        F.HPAD = G.HPAD;
+        F.WS = G.WS;
+        F.PS = G.plane;
+        F.TY = lf_sy(max_distance) - 1;
+        F.TX = LF_SX - 1;
+        F.nty = (F.hp + F.TY - 1) / F.TY;
+        F.ntx = (F.wp + F.TX - 1) / F.TX;
+        F.plane_bytes = (size_t)G.plane * C * sizeof(float);
+        F.tab_bytes = (size_t)(F.nty + F.ntx + 2) * sizeof(int);
+    }
+    F.off_tab = manet_align_up(F.off_plane + F.plane_bytes, 256);
+    F.total = manet_align_up(F.off_tab + F.tab_bytes, 1024);
+    return F;
+}
+
 extern "C" {
+
+int manet_frame_workspace_bytes(int h, int w, int C, int compute, int max_distance, size_t *bytes)
+{
+    if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
+    if (h <= 0 || w <= 0) return manet_set_error(MANET_E_INVALID, "h=%d w=%d", h, w);
+    int rc = check_common((int64_t)h * w, 0, C, 1, 1, compute);
+    if (rc) return rc;
+    if (max_distance > MANET_MAX_LOCAL_DISTANCE || (max_distance >= 0 && (h < 2 || w < 2)))
+        return manet_set_error(MANET_E_INVALID, "max_distance=%d (supported -1 = no pooled plane, 0..%d; h, w >= 2)",
+                               max_distance, MANET_MAX_LOCAL_DISTANCE);
+    *bytes = manet_frame_layout(h, w, C, compute, max_distance).total;
+    return MANET_OK;
+}
+
+int manet_frame_prepare(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y, int64_t s_x, int64_t s_c, int n_frames,
+                        int h, int w, int C, int compute, int max_distance, void *frames_ws, size_t frame_ws_stride,
+                        void *fill_ptr, int64_t fill_words, uint32_t fill_value, manet_stream_t stream)
+{
+    size_t need = 0;
+    int rc = manet_frame_workspace_bytes(h, w, C, compute, max_distance, &need);
+    if (rc) return rc;
+    if (!emb || !frames_ws || n_frames <= 0 || n_frames > 65535)
+        return manet_set_error(MANET_E_INVALID, "null pointer or n_frames=%d", n_frames);
+    if (frame_ws_stride < need || (frame_ws_stride & 1023))
+        return manet_set_error(MANET_E_WORKSPACE, "frame workspace stride %zu < %zu bytes (or not a multiple of 1024)",
+                               frame_ws_stride, need);
+    if (fill_words < 0 || (fill_words > 0 && !fill_ptr)) return manet_set_error(MANET_E_INVALID, "bad fill request");
+    const ManetFrameLayout F = manet_frame_layout(h, w, C, compute, max_distance);
+    const Geom G = geom_of(C, compute);
+    constexpr int XC = 64;
+    FramePrep A;
+    A.emb = emb;
+    A.s_f = (long)s_f; A.s_y = (long)s_y; A.s_x = (long)s_x; A.s_c = (long)s_c;
+    A.h = h; A.w = w; A.C = C; A.compute = compute; A.units = G.units; A.kpad = G.kpad;
+    A.ws = (char *)frames_ws; A.ws_stride = (long)frame_ws_stride; A.qblk_bytes = (long)G.qblk_bytes;
+    A.off_plane = (long)F.off_plane; A.off_tab = (long)F.off_tab;
+    A.d = max_distance; A.hp = F.hp; A.wp = F.wp; A.HPAD = F.HPAD; A.WS = F.WS; A.PS = F.PS;
+    A.TY = F.TY; A.TX = F.TX; A.nty = F.nty; A.ntx = F.ntx;
+    A.N = (long)h * w; A.N_pad = F.N_pad;
+    A.fill_ptr = (unsigned *)fill_ptr; A.fill_words = (long)fill_words; A.fill_value = fill_value;
+    A.nxc = (w + XC - 1) / XC;
+    A.n_data = ((h + 1) / 2) * A.nxc;
+    long aux_items = (long)(F.N_pad - A.N) * G.units + fill_words + 64;
+    if (max_distance >= 0) aux_items += (long)C * (F.HPAD - F.hp) * (F.WS / 4);
+    long aux = (aux_items + 1023) / 1024;
+    if (aux < 1) aux = 1;
+    if (aux > 256) aux = 256;
+    const size_t lds = (size_t)2 * XC * (G.kpad + 1) * sizeof(float) + 2 * XC * sizeof(float);
+    const dim3 grid((unsigned)(A.n_data + aux), 1, (unsigned)n_frames);
+    hipStream_t st = (hipStream_t)stream;
+    manet_profile_record(st, true, 2);
+    if (emb_dtype == MANET_EMB_F32) {
+        (void)hipFuncSetAttribute((const void *)frame_prepare_kernel<float, XC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((frame_prepare_kernel<float, XC>), grid, dim3(256), lds, st, A);
+    } else if (emb_dtype == MANET_EMB_BF16) {
+        (void)hipFuncSetAttribute((const void *)frame_prepare_kernel<unsigned short, XC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((frame_prepare_kernel<unsigned short, XC>), grid, dim3(256), lds, st, A);
+    } else {
+        return manet_set_error(MANET_E_INVALID, "embedding dtype %d (MANET_EMB_F32 / MANET_EMB_BF16)", emb_dtype);
+    }
+    manet_profile_record(st, false, 2);
+    return manet_check_launch("manet_frame_prepare");
+}
 
 int manet_bank_workspace_bytes(int64_t M0, int C, int n_ids, int compute, size_t *bytes)
 {
@@ -1869,14 +2136,17 @@ int manet_global_match_prepared_ex(const void *query, int emb_dtype, int64_t q_s
     char *mws = (char *)match_ws;
     const int *meta = (const int *)(bws + BL.off_meta);
     unsigned *keys = (unsigned *)(mws + ML.off_keys);
-    // MANET_EMB_PACKED: `query` already is the operand image manet_query_pack wrote (same N, C, compute)
+    // MANET_EMB_PACKED: `query` already is the operand image manet_query_pack / manet_frame_prepare wrote (same N, C,
+    // compute)
     const char *qpack = (const char *)query;
+    const bool armed = (epilogue_flags & MANET_EPI_KEYS_ARMED) && k_nn == 1;
+    if (!armed) epilogue_flags &= ~MANET_EPI_KEYS_ARMED;
     if (emb_dtype != MANET_EMB_PACKED) {
         rc = launch_query_pack(query, emb_dtype, (long)q_stride_n, (long)q_stride_c, (long)N, ML.N_pad, C, ML.G,
                                mws + ML.off_q, keys, n_ids, st);  // also resets the keys
         if (rc) return rc;
         qpack = mws + ML.off_q;
-    } else {
+    } else if (!armed) {
         fill32(keys, 0xffffffffu, (size_t)n_ids * ML.N_pad, st);
     }
     // resident workgroup slots: f32 and plain bf16 (wide kernel) = 2 x 256-thread workgroups per CU,
@@ -1930,10 +2200,10 @@ int manet_global_match_prepared_ex(const void *query, int emb_dtype, int64_t q_s
     }
 #undef MANET_GM_CASE
     }
-    long total = (long)N * n_ids;
+    long total = (long)(armed ? ML.N_pad : N) * n_ids;
     if (k_nn == 1)
         hipLaunchKernelGGL(global_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                           (const unsigned *)keys, (long)N, ML.N_pad, n_ids, epilogue_flags, out, mem_inout);
+                           keys, (long)N, ML.N_pad, n_ids, epilogue_flags, out, mem_inout);
     else
         hipLaunchKernelGGL(global_finish_topk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                            (const float *)topk, S, k_nn, (long)N, ML.N_pad, n_ids, epilogue_flags, out, mem_inout);

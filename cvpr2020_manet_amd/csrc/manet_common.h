@@ -40,6 +40,18 @@ int manet_tune_get(int key, int dflt);
 
 static inline size_t manet_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Per-frame operands written by manet_frame_prepare (csrc/global_match.hip), read by manet_global_match_prepared_ex
+// (the query operand image, at offset 0: a frame workspace IS a MANET_EMB_PACKED query) and by manet_local_match_frames
+// (csrc/local_match.hip: the 2x2-average-pooled plane with its border of the reference's padding value, and the tile
+// table of the fused kernel).  max_distance < 0: no pooled plane (global match only).
+struct ManetFrameLayout {
+    size_t off_image, image_bytes, off_plane, plane_bytes, off_tab, tab_bytes, total;
+    int hp, wp, HPAD, WS, TY, TX, nty, ntx;
+    long PS;     // floats per channel plane (HPAD * WS)
+    long N_pad;  // query rows of the image (N padded to whole query tiles)
+};
+ManetFrameLayout manet_frame_layout(int h, int w, int C, int compute, int max_distance);
+
 // (sigmoid(x) - 0.5) * 2      IntVOS.py:612, :294
 __device__ __forceinline__ float manet_normalize_dist(float x)
 {

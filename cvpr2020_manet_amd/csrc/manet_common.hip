@@ -12,16 +12,18 @@ int manet_set_error(int code, const char *fmt, ...)
     return code;
 }
 
-// ---- opt-in profiling: HIP event pairs around the dominant kernel (channel 0) and the local-window stage
-// (channel 1: pooling pass + fused kernel) -----------------------------------------------------------------
+// ---- opt-in profiling: HIP event pairs around the dominant kernel (channel 0), the local-window stage (channel 1),
+// the per-frame prepare kernel (channel 2) and the exact re-rank of the bf16-filter mode (channel 3) ------------
 #include <mutex>
+#include <stdlib.h>
 #include <vector>
 namespace {
+constexpr int PROF_CH = 4;
 struct ProfState {
     std::mutex mu;
     bool enabled = false;
-    size_t used[2] = {0, 0};  // events used per channel (2 per bracket)
-    std::vector<hipEvent_t> ev[2];
+    size_t used[PROF_CH] = {0, 0, 0, 0};  // events used per channel (2 per bracket)
+    std::vector<hipEvent_t> ev[PROF_CH];
 } g_prof;
 }  // namespace
 
@@ -29,7 +31,7 @@ void manet_profile_record(hipStream_t st, bool start, int channel)
 {
     if (!g_prof.enabled) return;
     std::lock_guard<std::mutex> lk(g_prof.mu);
-    if (!g_prof.enabled || channel < 0 || channel > 1) return;
+    if (!g_prof.enabled || channel < 0 || channel >= PROF_CH) return;
     size_t &used = g_prof.used[channel];
     std::vector<hipEvent_t> &ev = g_prof.ev[channel];
     if (start && used + 2 > ev.size()) return;  // pool exhausted: stop recording
@@ -45,6 +47,11 @@ extern "C" {
 
 int manet_tune_set(int key, int value)
 {
+    // experiments only: the data path reads these knobs, so the "no state between calls" promise of manet_hip.h holds
+    // only while nobody sets them -- refuse unless the process opted in
+    const char *opt = getenv("MANET_TUNING");
+    if (!opt || opt[0] != '1')
+        return manet_set_error(MANET_E_INVALID, "manet_tune_set is for experiments: set MANET_TUNING=1 in the environment");
     if (key < 0 || key >= MANET_TUNE_COUNT) return manet_set_error(MANET_E_INVALID, "tune key %d", key);
     g_tune[key] = value;
     g_tune_set[key] = true;
@@ -55,7 +62,7 @@ int manet_profile_begin(int max_launches)
 {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (max_launches <= 0) return manet_set_error(MANET_E_INVALID, "max_launches=%d", max_launches);
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < PROF_CH; ++c) {
         for (hipEvent_t e : g_prof.ev[c]) (void)hipEventDestroy(e);
         g_prof.ev[c].assign((size_t)max_launches * 2, nullptr);
         for (auto &e : g_prof.ev[c])
@@ -82,6 +89,13 @@ static int profile_collect(int c, float *ms_out, int capacity, int *n_launches)
     return MANET_OK;
 }
 
+int manet_profile_read(int channel, float *ms_out, int capacity, int *n_launches)
+{
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (channel < 0 || channel >= PROF_CH) return manet_set_error(MANET_E_INVALID, "profile channel %d", channel);
+    return profile_collect(channel, ms_out, capacity, n_launches);
+}
+
 int manet_profile_end2(float *ms_out, int capacity, int *n_launches, float *local_ms_out, int local_capacity,
                        int *n_local)
 {
@@ -89,7 +103,7 @@ int manet_profile_end2(float *ms_out, int capacity, int *n_launches, float *loca
     g_prof.enabled = false;
     int rc = profile_collect(0, ms_out, capacity, n_launches);
     if (!rc) rc = profile_collect(1, local_ms_out, local_capacity, n_local);
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < PROF_CH; ++c) {
         for (hipEvent_t e : g_prof.ev[c]) (void)hipEventDestroy(e);
         g_prof.ev[c].clear();
         g_prof.used[c] = 0;

@@ -82,6 +82,17 @@ def _workspace(device, tag, nbytes):
     return ws
 
 
+def _armed_workspace(device, tag, nbytes):
+    """Like _workspace, but the tensor is created FILLED with 0xff bytes and is only ever handed to calls that keep it so
+    (MANET_EPI_KEYS_ARMED: the match keys are re-armed by the epilogue that reads them) -- no per-call fill launch."""
+    key = (device.index, _stream_ptr(device), tag)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.full((int(nbytes * 1.25) + 1024,), 0xff, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
 def _emb(t):
     """embeddings are consumed in the producer's storage: float32, or bfloat16 (2-byte reads end to end,
     SURVEY.md 8f rank 4); anything else is widened to float32"""
@@ -181,13 +192,15 @@ class PreparedBank:
         e.g. for every frame of a clip right after extract_feature: no per-frame pack pass)"""
         import ctypes
         lib = _lib.load()
-        if isinstance(query_embeddings, PackedQuery):
+        armed = False
+        if isinstance(query_embeddings, (PackedQuery, PreparedFrame)):
             pq = query_embeddings
             if pq.C != self.C or pq.compute != self.compute:
-                raise ValueError("PackedQuery was packed for C=%d compute=%d, bank has C=%d compute=%d"
+                raise ValueError("the query operand was packed for C=%d compute=%d, bank has C=%d compute=%d"
                                  % (pq.C, pq.compute, self.C, self.compute))
             _refuse_autograd("PreparedBank.match", mem)
             qry, N, C, q_code, q_s0, q_s1 = pq.image, pq.N, pq.C, _lib.EMB_PACKED, 0, 0
+            armed = k_nearest_neighbors == 1
         else:
             _refuse_autograd("PreparedBank.match", query_embeddings, mem)
             qry, N, C = _flat(query_embeddings, "query_embeddings")
@@ -201,7 +214,7 @@ class PreparedBank:
         _lib.check(lib.manet_match_workspace_bytes(N, self.M0, C, self.n_ids, k_nearest_neighbors,
                                                    self.compute, ctypes.byref(nbytes)),
                    "manet_match_workspace_bytes")
-        ws = _workspace(dev, "match", nbytes.value)
+        ws = _armed_workspace(dev, "match_armed", nbytes.value) if armed else _workspace(dev, "match", nbytes.value)
         if out is None:
             out = torch.empty((N, self.n_ids), dtype=torch.float32, device=dev)
         mem_ptr = None
@@ -210,7 +223,7 @@ class PreparedBank:
             if mem.dtype != torch.float32 or not mem.is_contiguous() or mem.numel() != N * self.n_ids:
                 raise ValueError("mem must be a contiguous float32 tensor of N*n_ids elements")
             mem_ptr = mem.data_ptr()
-        flags = _lib.EPI_NORMALIZE if normalize else 0
+        flags = (_lib.EPI_NORMALIZE if normalize else 0) | (_lib.EPI_KEYS_ARMED if armed else 0)
         with torch.cuda.device(dev):
             rc = lib.manet_global_match_prepared_ex(qry.data_ptr(), q_code, q_s0, q_s1,
                                                     self.ws.data_ptr(), N, self.M0, C, self.n_ids,
@@ -239,6 +252,92 @@ class PackedQuery:
                                       self.image.data_ptr(), self.image.numel(), _stream_ptr(qry.device))
         _lib.check(rc, "manet_query_pack")
         self.device = qry.device
+
+
+class PreparedFrame:
+    """The per-frame operands of ONE frame (manet_frame_prepare): the query operand image of the global match and, when
+    `max_distance` >= 0, the padded 2x2-pooled plane (+ tile table) of the local match -- made from one read of the
+    embedding, once per frame: a propagated frame then needs no pack pass and no pooling pass, and the previous frame's
+    embedding is not read at all (its plane was made when it was the current frame, test.py:259)."""
+
+    def __init__(self, ws, h, w, C, compute, max_distance, keep=None):
+        self.ws, self.h, self.w, self.C, self.compute, self.max_distance = ws, h, w, C, compute, max_distance
+        self.N = h * w
+        self.image = ws  # the operand image sits at the start of the frame workspace (a MANET_EMB_PACKED query)
+        self.device = ws.device
+        self.keep = keep  # whatever must stay alive with this object (the identity-keyed caches key on storage pointers)
+
+
+def frame_workspace_bytes(h, w, C, compute="f32", max_distance=-1):
+    import ctypes
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(_lib.load().manet_frame_workspace_bytes(h, w, C, COMPUTE[compute], max_distance, ctypes.byref(nbytes)),
+               "manet_frame_workspace_bytes")
+    return nbytes.value
+
+
+def prepare_frames(embeddings, compute="f32", max_distance=-1, preset=None, preset_value=1.0):
+    """manet_frame_prepare on `embeddings` = [C, h, w] (one frame) or [B, C, h, w] (extract_feature's batch,
+    IntVOS.py:578-581) in float32 / bfloat16 storage, any strides: ONE launch for the whole batch.  Returns a
+    PreparedFrame (one frame) or a list of them.  `preset`: an optional contiguous float32 tensor set to `preset_value`
+    by the same launch (the next local match's `out`, see local_match_frames)."""
+    lib = _lib.load()
+    _need_gpu(embeddings, "embeddings")
+    _refuse_autograd("prepare_frames", embeddings)
+    emb = _emb(embeddings)
+    single = emb.dim() == 3
+    if single:
+        emb = emb.unsqueeze(0)
+    if emb.dim() != 4:
+        raise ValueError("embeddings must be [C, h, w] or [B, C, h, w]")
+    B, C, h, w = emb.shape
+    if B == 0:
+        return []
+    cmp_ = COMPUTE[compute]
+    per = frame_workspace_bytes(h, w, C, compute, max_distance)
+    ws = torch.empty((B, per), dtype=torch.uint8, device=emb.device)
+    fill_ptr, fill_words, fill_bits = None, 0, 0
+    if preset is not None:
+        _need_gpu(preset, "preset")
+        if preset.dtype != torch.float32 or not preset.is_contiguous():
+            raise ValueError("preset must be a contiguous float32 tensor")
+        import struct
+        fill_ptr, fill_words = preset.data_ptr(), preset.numel()
+        fill_bits = struct.unpack("<I", struct.pack("<f", float(preset_value)))[0]
+    with torch.cuda.device(emb.device):
+        rc = lib.manet_frame_prepare(emb.data_ptr(), _emb_code(emb), emb.stride(0), emb.stride(2), emb.stride(3),
+                                     emb.stride(1), B, h, w, C, cmp_, max_distance, ws.data_ptr(), per, fill_ptr,
+                                     fill_words, fill_bits, _stream_ptr(emb.device))
+    _lib.check(rc, "manet_frame_prepare")
+    frames = [PreparedFrame(ws[i], h, w, C, cmp_, max_distance) for i in range(B)]
+    return frames[0] if single else frames
+
+
+def local_match_frames(prev_frame, cur_frame, prev_frame_labels, n_ids, out=None, out_is_preset=False):
+    """local_previous_frame_nearest_neighbor_features_per_object (IntVOS.py:345-434, downsample configuration) on two
+    PreparedFrames: the fused window / min kernel alone -> [h, w, n_ids]; bit-identical to local_match on the
+    embeddings the frames were prepared from."""
+    lib = _lib.load()
+    a, b = prev_frame, cur_frame
+    if (a.h, a.w, a.C, a.compute, a.max_distance) != (b.h, b.w, b.C, b.compute, b.max_distance):
+        raise ValueError("the two frames were prepared for different shapes / arithmetic / window radius")
+    if b.max_distance < 0:
+        raise ValueError("the frames were prepared without a pooled plane (max_distance < 0)")
+    lab = _labels(prev_frame_labels, "prev_frame_labels")
+    if lab.numel() != b.h * b.w:
+        raise ValueError("prev_frame_labels must have height*width entries")
+    dev = b.device
+    if out is None:
+        out = torch.empty((b.h, b.w, n_ids), dtype=torch.float32, device=dev)
+        out_is_preset = False
+    elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != b.h * b.w * n_ids:
+        raise ValueError("out must be a contiguous float32 tensor of h*w*n_ids elements")
+    with torch.cuda.device(dev):
+        rc = lib.manet_local_match_frames(a.ws.data_ptr(), b.ws.data_ptr(), lab.data_ptr(), b.h, b.w, b.C, b.compute,
+                                          n_ids, b.max_distance, out.data_ptr(), int(bool(out_is_preset)),
+                                          _stream_ptr(dev))
+    _lib.check(rc, "manet_local_match_frames")
+    return out.view(b.h, b.w, n_ids)
 
 
 def normalize_merge_(x, mem=None, normalize=True):

@@ -67,6 +67,10 @@ typedef void *manet_stream_t; /* a hipStream_t */
 
 /* flags of the fused epilogue of manet_global_match */
 #define MANET_EPI_NORMALIZE 1 /* g = (sigmoid(g) - 0.5) * 2            IntVOS.py:611-612 */
+/* manet_global_match_prepared_ex with a MANET_EMB_PACKED query and k_nn = 1 only: the caller promises that `match_ws`
+ * holds 0xff bytes throughout (e.g. it filled it once and has only used it for calls with this flag since); the call
+ * then skips its fill launch and leaves the workspace in that state again (the epilogue re-arms what it reads). */
+#define MANET_EPI_KEYS_ARMED 2
 
 const char *manet_version(void);
 const char *manet_last_error_string(void);
@@ -142,6 +146,26 @@ int manet_global_match_ex(const void *query, int q_dtype, int64_t q_stride_n, in
                           int compute, float *out, float *mem_inout, int epilogue_flags, void *workspace,
                           size_t workspace_bytes, manet_stream_t stream);
 
+/* Per-frame operands, made ONCE when a frame's embedding is produced (the reference computes every
+ * frame's embedding up front, test.py:143-154, batch 14): from ONE read of the C-major embedding,
+ *   - the query operand image of the global match (the frame workspace's first bytes: pass the workspace itself as a
+ *     MANET_EMB_PACKED query to manet_global_match_prepared_ex), and, when max_distance >= 0,
+ *   - the 2x2-average-pooled plane of the local match (IntVOS.py:282-284) with a border of the reference's padding
+ *     value 1e20 (IntVOS.py:287) and the fused local kernel's tile table, read by manet_local_match_frames.
+ * A propagated frame then reads its own embedding once and the previous frame's not at all (that frame's plane was
+ * made when IT was the current frame; test.py:259 `prev_embedding = current_embedding`).
+ *   emb            n_frames x [h][w][C] in MANET_EMB_F32 / MANET_EMB_BF16 storage, element strides (s_f, s_y, s_x, s_c);
+ *                  extract_feature's [B,C,h,w] batch (IntVOS.py:578-581) is (C*h*w, w, 1, h*w): one launch for the batch.
+ *   frames_ws      n_frames workspaces, frame_ws_stride bytes apart (>= manet_frame_workspace_bytes, multiple of 1024).
+ *   max_distance   the local window radius the plane is padded for (cfg.MODEL_MAX_LOCAL_DISTANCE), or -1: no plane.
+ *   fill_ptr       optional: fill_words 32-bit words at fill_ptr are set to fill_value by the same launch (the caller's
+ *                  next local-match `out`, pre-set to 1.0f = 0x3f800000, see manet_local_match_frames). */
+int manet_frame_workspace_bytes(int h, int w, int C, int compute, int max_distance, size_t *bytes);
+int manet_frame_prepare(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y, int64_t s_x, int64_t s_c,
+                        int n_frames, int h, int w, int C, int compute, int max_distance, void *frames_ws,
+                        size_t frame_ws_stride, void *fill_ptr, int64_t fill_words, uint32_t fill_value,
+                        manet_stream_t stream);
+
 /* Stand-alone normalise / min-merge (IntVOS.py:611-622, :718-723), in place on x[n]
  * (and on mem_inout[n] when not NULL). */
 int manet_normalize_merge_f32(float *x, float *mem_inout, int64_t n, int normalize,
@@ -186,6 +210,15 @@ int manet_local_match_ex(const void *prev, int64_t p_sy, int64_t p_sx, int64_t p
                          const int32_t *prev_labels, int h, int w, int C, int n_ids, int max_distance,
                          int downsample, float *out, void *workspace, size_t workspace_bytes,
                          manet_stream_t stream);
+
+/* manet_local_match_f32 (downsample configuration) on two PREPARED frames (manet_frame_prepare with the same h, w, C,
+ * compute, max_distance): one launch, the fused window / min kernel reading the two pooled planes -- no pooling pass, no
+ * full-resolution read.  For max_distance >= 11 the kernel combines partial minima in `out` by atomicMin and needs it
+ * pre-set to 1.0f: out_is_preset != 0 says the caller did that (manet_frame_prepare's fill), else a fill launch is
+ * enqueued first.  Bit-identical to manet_local_match_ex on the same embeddings. */
+int manet_local_match_frames(const void *prev_frame_ws, const void *cur_frame_ws, const int32_t *prev_labels,
+                             int h, int w, int C, int compute, int n_ids, int max_distance, float *out,
+                             int out_is_preset, manet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* correlation_package forward (correlation_cuda.cc:10-87).
@@ -304,7 +337,9 @@ int manet_correlation_backward_f32(const float *in1, const float *in2, const flo
  * events on its own stream.  manet_profile_end synchronises on those events (the only call in
  * this library that blocks) and returns the per-launch durations in milliseconds. */
 int manet_profile_begin(int max_launches);
-/* Tuning knobs for experiments (process-wide; the defaults are the shipped configuration):
+/* Tuning knobs for experiments (process-wide; the defaults are the shipped configuration).  Refused
+ * (MANET_E_INVALID) unless the environment has MANET_TUNING=1: without that opt-in nothing can change them, and the
+ * data path keeps no state between calls.
  * key 0 = block -> (query tile, bank split) mapping of the global-match kernel (0 XCD-aware),
  * key 1 = forced number of bank splits (0 = automatic),
  * key 2 = form of the bf16 kernels (bit field, see launch_main_bf16 in csrc/global_match.hip),
@@ -316,6 +351,10 @@ int manet_profile_end(float *ms_out, int capacity, int *n_launches);
  * manet_local_match_*), the HBM-bound stage of the path */
 int manet_profile_end2(float *ms_out, int capacity, int *n_launches, float *local_ms_out,
                        int local_capacity, int *n_local);
+/* durations recorded so far on one channel, without ending the session (call before manet_profile_end*; blocks on the
+ * recorded events): 0 = global-match main kernel, 1 = local-window stage, 2 = manet_frame_prepare, 3 = the exact
+ * re-rank kernel of MANET_COMPUTE_BF16_REFINE */
+int manet_profile_read(int channel, float *ms_out, int capacity, int *n_launches);
 
 #ifdef __cplusplus
 }

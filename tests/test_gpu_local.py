@@ -1,5 +1,7 @@
 """GPU parity of the local-window matching and correlation HIP paths (through the C ABI) against the
 committed reference vectors and the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -194,6 +196,7 @@ def test_fused_kernel_every_window_size(ops, oracle, d):
                                   downsample=True).reshape(h, w, n_ids)
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
         lib = _lib.load()
+        os.environ["MANET_TUNING"] = "1"  # the setters refuse without the opt-in
         _lib.check(lib.manet_tune_set(4, 1), "manet_tune_set")  # MANET_TUNE_LOCAL_UNFUSED
         try:
             unfused = ops.local_match(p, c, l, n_ids, d)
@@ -222,6 +225,7 @@ def test_full_size_local_cfg5_grid(ops, oracle):
                               lab.cpu().numpy().reshape(h, w, 1), n_ids, d, downsample=True).reshape(h, w, n_ids)
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
     lib = _lib.load()
+    os.environ["MANET_TUNING"] = "1"
     _lib.check(lib.manet_tune_set(4, 1), "manet_tune_set")  # MANET_TUNE_LOCAL_UNFUSED
     try:
         unfused = ops.local_match(pf.permute(1, 2, 0), cf.permute(1, 2, 0), lab, n_ids, d)

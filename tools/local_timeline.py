@@ -7,6 +7,7 @@ from cvpr2020_manet_amd import ops, _lib
 lib = _lib.load()
 lib.manet_dbg_read.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 import os
+os.environ['MANET_TUNING']='1'
 lib.manet_tune_set(3, int(os.environ.get('ABL','0')))
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
