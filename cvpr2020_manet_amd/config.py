@@ -45,6 +45,10 @@ FLAGS = [
     ("MODEL_NUM_CLASSES", I, 21), ("MODEL_SEMANTIC_EMBEDDING_DIM", I, 100), ("MODEL_HEAD_EMBEDDING_DIM", I, 256),
     ("MODEL_LOCAL_DOWNSAMPLE", B, True), ("MODEL_MAX_LOCAL_DISTANCE", I, 12), ("MODEL_SELECT_PERCENT", F, 0.8),
     ("MODEL_USEIntSeg", B, False),
+    # MI355X matching path (not in the reference; a reference cfg without them gets the defaults):
+    #   MODEL_MATCH_COMPUTE  arithmetic of the global match: f32 (exact) | bf16 | bf16x3 | bf16r (bf16 filter + fp32 re-rank)
+    #   MODEL_EMB_DTYPE      storage of extract_feature's output in HBM: f32 | bf16 (2-byte embeddings end to end)
+    ("MODEL_MATCH_COMPUTE", S, "f32"), ("MODEL_EMB_DTYPE", S, "f32"),
     # train
     ("TRAIN_LR", F, 0.0007), ("TRAIN_LR_GAMMA", F, 0.1), ("TRAIN_MOMENTUM", F, 0.9),
     ("TRAIN_WEIGHT_DECAY", F, 0.00004), ("TRAIN_POWER", F, 0.9), ("TRAIN_BATCH_SIZE", I, 2),

@@ -521,26 +521,50 @@ __global__ __launch_bounds__(256) void frame_prepare_kernel(const FramePrep A)
     float *s_norm = rows + (long)PIX * KP;      // [PIX]
     const int rp = blockIdx.x / A.nxc, cx = blockIdx.x - rp * A.nxc;
     const int x0 = cx * XC, y0 = 2 * rp;
-    for (int idx = tid; idx < PIX * C; idx += 256) {  // lanes along x: row segments of the C-major source
-        const int k = idx / PIX, p = idx - k * PIX;
+    {  // stage [pixel][k]: lanes along x (row segments of the C-major source), KB unconditional loads in flight per thread
+        constexpr int NKQ = 256 / PIX, KB = 5;
+        const int p = tid % PIX, kq = tid / PIX;
         const int y = y0 + p / XC, x = x0 + p % XC;
-        rows[p * KP + k] = (y < A.h && x < A.w) ? emb_load(src, (long)y * A.s_y + (long)x * A.s_x + (long)k * A.s_c) : 0.0f;
+        const bool in = (y < A.h && x < A.w);
+        const SRC *sp = src + (long)(y < A.h ? y : A.h - 1) * A.s_y + (long)(x < A.w ? x : A.w - 1) * A.s_x;
+        float *rp_ = rows + p * KP;
+        for (int k0 = kq; k0 < C; k0 += NKQ * KB) {
+            float v[KB];
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                const int k = k0 + j * NKQ;
+                v[j] = emb_load(sp, (long)(k < C ? k : C - 1) * A.s_c);
+            }
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                const int k = k0 + j * NKQ;
+                if (k < C) rp_[k] = in ? v[j] : 0.0f;
+            }
+        }
     }
     for (int idx = tid; idx < PIX * (kpad - C); idx += 256) {
         const int p = idx / (kpad - C), k = C + idx - p * (kpad - C);
         rows[p * KP + k] = 0.0f;
     }
     __syncthreads();
-    if (tid < PIX) {  // |q|^2: the k-ascending fmaf chain of the oracle, as pack_rows_kernel
+    if (tid < PIX) {  // |q|^2: the k-ascending fmaf chain of the oracle, as pack_rows_kernel (reads batched ahead of the chain)
         const float *row = rows + tid * KP;
         float n = 0.0f;
-        if (A.compute == MANET_COMPUTE_BF16) {
-            for (int k = 0; k < C; ++k) {
-                const float x = bf2f(f2bf(row[k]));
+        const bool rnd = (A.compute == MANET_COMPUTE_BF16);
+        int k = 0;
+        for (; k + 10 <= C; k += 10) {
+            float v[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) v[j] = row[k + j];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const float x = rnd ? bf2f(f2bf(v[j])) : v[j];
                 n = fmaf(x, x, n);
             }
-        } else {
-            for (int k = 0; k < C; ++k) n = fmaf(row[k], row[k], n);
+        }
+        for (; k < C; ++k) {
+            const float x = rnd ? bf2f(f2bf(row[k])) : row[k];
+            n = fmaf(x, x, n);
         }
         s_norm[tid] = n;
     }
@@ -1982,7 +2006,7 @@ int manet_frame_prepare(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y
     if (fill_words < 0 || (fill_words > 0 && !fill_ptr)) return manet_set_error(MANET_E_INVALID, "bad fill request");
     const ManetFrameLayout F = manet_frame_layout(h, w, C, compute, max_distance);
     const Geom G = geom_of(C, compute);
-    constexpr int XC = 64;
+    const int XC = manet_tune_get(MANET_TUNE_FRAME_XC, 0) == 1 ? 64 : 32;  // (tuning: 64-column workgroups)
     FramePrep A;
     A.emb = emb;
     A.s_f = (long)s_f; A.s_y = (long)s_y; A.s_x = (long)s_x; A.s_c = (long)s_c;
@@ -2003,16 +2027,16 @@ int manet_frame_prepare(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y
     const size_t lds = (size_t)2 * XC * (G.kpad + 1) * sizeof(float) + 2 * XC * sizeof(float);
     const dim3 grid((unsigned)(A.n_data + aux), 1, (unsigned)n_frames);
     hipStream_t st = (hipStream_t)stream;
-    manet_profile_record(st, true, 2);
-    if (emb_dtype == MANET_EMB_F32) {
-        (void)hipFuncSetAttribute((const void *)frame_prepare_kernel<float, XC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((frame_prepare_kernel<float, XC>), grid, dim3(256), lds, st, A);
-    } else if (emb_dtype == MANET_EMB_BF16) {
-        (void)hipFuncSetAttribute((const void *)frame_prepare_kernel<unsigned short, XC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((frame_prepare_kernel<unsigned short, XC>), grid, dim3(256), lds, st, A);
-    } else {
+    if (emb_dtype != MANET_EMB_F32 && emb_dtype != MANET_EMB_BF16)
         return manet_set_error(MANET_E_INVALID, "embedding dtype %d (MANET_EMB_F32 / MANET_EMB_BF16)", emb_dtype);
-    }
+    const void *fn = emb_dtype == MANET_EMB_F32
+                         ? (XC == 64 ? (const void *)frame_prepare_kernel<float, 64> : (const void *)frame_prepare_kernel<float, 32>)
+                         : (XC == 64 ? (const void *)frame_prepare_kernel<unsigned short, 64>
+                                     : (const void *)frame_prepare_kernel<unsigned short, 32>);
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    void *args[] = {(void *)&A};
+    manet_profile_record(st, true, 2);
+    (void)hipLaunchKernel(fn, grid, dim3(256), args, lds, st);
     manet_profile_record(st, false, 2);
     return manet_check_launch("manet_frame_prepare");
 }

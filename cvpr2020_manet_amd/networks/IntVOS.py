@@ -24,6 +24,8 @@ What differs, deliberately:
     torch.autograd.Functions (cvpr2020_manet_amd/autograd.py) so that ``loss.backward()`` of
     train_stage1.py:126-156 reaches the encoder exactly as it does through the reference's pure-PyTorch path.
 """
+from collections import OrderedDict
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -40,7 +42,8 @@ WRONG_LABEL_PADDING_DISTANCE = 1e20
 # IntVOS(cfg, ...) re-binds it to the cfg it is given.
 cfg = _default_cfg
 
-# arithmetic of the QK^T contraction: "f32" (exact fp32 MFMA) | "bf16" | "bf16x3"
+# arithmetic of the QK^T contraction used by the MODULE-LEVEL functions: "f32" (exact fp32 MFMA) | "bf16" | "bf16x3" |
+# "bf16r".  An IntVOS instance carries its own (constructor argument / cfg.MODEL_MATCH_COMPUTE).
 COMPUTE = "f32"
 
 
@@ -299,6 +302,8 @@ def _run_head(head, embedding_chw, per_object):
     inference on the GPU a DynamicSegHead takes the shared-embedding route (no repeat / cat of the C-channel
     embedding, depthwise stage of those channels computed once); otherwise the reference's literal form."""
     n = per_object.shape[0]
+    if embedding_chw.dtype != torch.float32:  # 2-byte embeddings (MODEL_EMB_DTYPE bf16): the head computes in fp32
+        embedding_chw = embedding_chw.float()
     if (isinstance(head, DynamicSegHead) and not head.training and not torch.is_grad_enabled()
             and embedding_chw.is_cuda and embedding_chw.dtype == torch.float32):
         return head.forward_shared(embedding_chw.unsqueeze(0), per_object)
@@ -308,15 +313,31 @@ def _run_head(head, embedding_chw, per_object):
 # --------------------------------------------------------------------------------------------------
 MAX_CLIP_FRAMES = 104       # hard-coded clip length of the reference's memories (IntVOS.py:617,645)
 MAX_INTERACTIONS = 9        # IntVOS.py:641,645
+MAX_CACHED_FRAMES = 2 * MAX_CLIP_FRAMES + 8  # prepared per-frame operands kept per model (17 MB each at 480p)
+MAX_CACHED_BANKS = 2        # prepared memory banks kept per model (one per sequence name)
+_EMB_DTYPES = {"f32": torch.float32, "fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
+               "bfloat16": torch.bfloat16, torch.float32: torch.float32, torch.bfloat16: torch.bfloat16}
 
 
 class IntVOS(nn.Module):
     """reference IntVOS.py:530-764: same constructor, methods, dict conventions, state-dict keys."""
 
-    def __init__(self, cfg, feature_extracter):
+    def __init__(self, cfg, feature_extracter, compute=None, emb_dtype=None):
+        """cfg, feature_extracter: as the reference.  compute / emb_dtype (optional, this implementation only; default:
+        cfg.MODEL_MATCH_COMPUTE / cfg.MODEL_EMB_DTYPE when the cfg has them, else "f32" / "f32"):
+          compute    arithmetic of the global match: "f32" exact | "bf16" | "bf16x3" | "bf16r"
+          emb_dtype  storage type of extract_feature's output: "f32" | "bf16" (the matching kernels then read 2-byte
+                     embeddings end to end; the heads widen them)"""
         super().__init__()
         set_cfg(cfg)
         self.cfg = cfg
+        self.compute = compute if compute is not None else getattr(cfg, "MODEL_MATCH_COMPUTE", "f32")
+        if self.compute not in ops.COMPUTE:
+            raise ValueError("compute=%r (one of %s)" % (self.compute, sorted(ops.COMPUTE)))
+        ed = emb_dtype if emb_dtype is not None else getattr(cfg, "MODEL_EMB_DTYPE", "f32")
+        if ed not in _EMB_DTYPES:
+            raise ValueError("emb_dtype=%r ('f32' or 'bf16')" % (ed,))
+        self.emb_dtype = _EMB_DTYPES[ed]
         self.feature_extracter = feature_extracter  # embedding extractor (out of scope; any module)
         self.feature_extracter.cls_conv = nn.Sequential()
         self.feature_extracter.upsample4 = nn.Sequential()
@@ -334,7 +355,8 @@ class IntVOS(nn.Module):
         for m in self.semantic_embedding:
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
-        self._bank_cache = {}  # seq_name -> (identity key, ops.PreparedBank, keyed tensors): see _prepared_bank
+        self._bank_cache = OrderedDict()   # seq_name -> (identity key, ops.PreparedBank, keyed tensors): _prepared_bank
+        self._frame_cache = OrderedDict()  # identity key of a [C,h,w] embedding -> ops.PreparedFrame: _prepared_frame
         self.dynamic_seghead = DynamicSegHead()  # propagation head
         if cfg.MODEL_USEIntSeg:
             self.inter_seghead = IntSegHead(in_dim=cfg.MODEL_SEMANTIC_EMBEDDING_DIM + 3)
@@ -345,17 +367,98 @@ class IntVOS(nn.Module):
         """The sorted / packed memory bank of the annotated frame, reused while the caller keeps passing the SAME
         embedding and scribble tensors (identity = storage pointer, shape, strides and torch's in-place version
         counter): test.py:237-259 / :276-295 propagate a whole clip against one annotated frame, so the bank is
-        sorted and packed once per interaction instead of once per frame.  One bank per sequence name."""
+        sorted and packed once per interaction instead of once per frame.  One bank per sequence name, the
+        MAX_CACHED_BANKS most recently used sequences.  (Writes that bypass torch's version counter -- `.data`, raw
+        pointers -- are invisible to the key: call invalidate_caches() after such a write.)"""
         key = (ref_emb_chw.data_ptr(), tuple(ref_emb_chw.shape), tuple(ref_emb_chw.stride()), ref_emb_chw._version,
                ref_emb_chw.dtype, ref_label.data_ptr(), tuple(ref_label.shape), ref_label._version, ref_label.dtype,
-               n_ids, COMPUTE, bool(self.cfg.TEST_MODE))
+               n_ids, self.compute, bool(self.cfg.TEST_MODE))
         hit = self._bank_cache.get(seq_name)
         if hit is not None and hit[0] == key:
+            self._bank_cache.move_to_end(seq_name)
             return hit[1]
-        bank = ops.PreparedBank(ref_emb_hwc, ref_lab_flat, n_ids, compute=COMPUTE)
+        bank = ops.PreparedBank(ref_emb_hwc, ref_lab_flat, n_ids, compute=self.compute)
         # keep the keyed tensors alive so that their storage pointers cannot be recycled under the key
         self._bank_cache[seq_name] = (key, bank, ref_emb_chw, ref_label)
+        self._bank_cache.move_to_end(seq_name)
+        while len(self._bank_cache) > MAX_CACHED_BANKS:
+            self._bank_cache.popitem(last=False)
         return bank
+
+    # ---- per-frame operands (SURVEY 8f rank 4: the producer side of the path) ------------------------------------
+    def _frame_key(self, emb_chw, d):
+        return (emb_chw.data_ptr(), tuple(emb_chw.shape), tuple(emb_chw.stride()), emb_chw._version, emb_chw.dtype,
+                self.compute, d)
+
+    def _local_radius(self):
+        """window radius the pooled planes are padded for; -1 (no plane) when the fused local kernel does not apply"""
+        d = int(self.cfg.MODEL_MAX_LOCAL_DISTANCE)
+        return d if (self.cfg.MODEL_LOCAL_DOWNSAMPLE and 0 <= d <= 12) else -1
+
+    def _prepared_frame(self, emb_chw, preset=None):
+        """ops.PreparedFrame of one [C,h,w] embedding: the query operand image of the global match + the pooled plane of
+        the local match, made by ONE launch from one read of the embedding, and reused for as long as the caller keeps
+        passing the same tensor -- test.py:259 `prev_embedding = current_embedding` makes every frame the previous
+        frame of the next step, and every interaction round walks the same `embedding_memory`.  Returns
+        (frame, preset_done).  Inside a HIP-graph capture nothing is cached (a replay sees new contents in the same
+        buffers), the prepare launch is part of the graph."""
+        d = self._local_radius()
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = self._frame_key(emb_chw, d)
+        hit = None if capturing else self._frame_cache.get(key)
+        if hit is not None:
+            self._frame_cache.move_to_end(key)
+            return hit, False
+        frame = ops.prepare_frames(emb_chw, compute=self.compute, max_distance=d, preset=preset)
+        if not capturing:
+            frame.keep = emb_chw  # the key holds a storage pointer: keep the tensor alive with the entry
+            self._frame_cache[key] = frame
+            while len(self._frame_cache) > MAX_CACHED_FRAMES:
+                self._frame_cache.popitem(last=False)
+        return frame, preset is not None
+
+    def prepare_clip(self, embeddings, batch=16):
+        """Optional, for drivers that hold a clip's embeddings in one tensor (test.py:143-154 `embedding_memory`):
+        prepares every frame of `embeddings` [F,C,h,w] up front, `batch` frames per launch, so the propagation loop
+        finds each `embeddings[i]` ready.  Returns `embeddings` (in this model's storage type: pass the result on)."""
+        if embeddings.dtype != self.emb_dtype:
+            embeddings = embeddings.to(self.emb_dtype)
+        if not embeddings.is_cuda or (torch.is_grad_enabled() and embeddings.requires_grad):
+            return embeddings
+        d = self._local_radius()
+        for i0 in range(0, embeddings.shape[0], batch):
+            chunk = embeddings[i0:i0 + batch]
+            for j, fr in enumerate(ops.prepare_frames(chunk, compute=self.compute, max_distance=d)):
+                e = embeddings[i0 + j]
+                fr.keep = e
+                self._frame_cache[self._frame_key(e, d)] = fr
+        while len(self._frame_cache) > max(MAX_CACHED_FRAMES, embeddings.shape[0]):
+            self._frame_cache.popitem(last=False)
+        return embeddings
+
+    def invalidate_caches(self):
+        """Drop the prepared banks / frames and the heads' folded BatchNorm constants.  Called by train(),
+        load_state_dict() and _apply() (device / dtype moves); call it yourself after writing to a parameter or an
+        embedding through `.data` or a raw pointer -- such writes do not bump torch's version counters, which is all
+        the identity keys can see."""
+        self._bank_cache.clear()
+        self._frame_cache.clear()
+        for m in self.modules():
+            if hasattr(m, "_fold_cache"):
+                object.__setattr__(m, "_fold_cache", None)
+
+    def train(self, mode=True):
+        self.invalidate_caches()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate_caches()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        if hasattr(self, "_bank_cache"):
+            self.invalidate_caches()
+        return super()._apply(fn, *args, **kwargs)
 
     # reference IntVOS.py:556-575
     def forward(self, x=None, ref_scribble_label=None, previous_frame_mask=None,
@@ -380,9 +483,17 @@ class IntVOS(nn.Module):
         return dic, global_map_tmp_dic
 
     # reference IntVOS.py:578-581
-    def extract_feature(self, x):
+    def extract_feature(self, x, packed=False):
+        """as the reference; the output is stored in this model's `emb_dtype`.  packed=True (inference): the per-frame
+        operands of every frame of the batch are written right here, by one launch for the whole batch (prepare_clip):
+        worthwhile when the caller keeps using THIS tensor's frames (a `torch.cat` of several batches copies them to new
+        storage -- then call prepare_clip on the concatenated tensor instead)."""
         x = self.feature_extracter(x)
         x = self.semantic_embedding(x)
+        if x.dtype != self.emb_dtype and not (torch.is_grad_enabled() and x.requires_grad):
+            x = x.to(self.emb_dtype)
+        if packed:
+            x = self.prepare_clip(x, batch=max(1, x.shape[0]))
         return x
 
     # reference IntVOS.py:583-681
@@ -422,25 +533,38 @@ class IntVOS(nn.Module):
             if k_nearest_neighbors > 1 and cfg.TEST_MODE:
                 keep = ref_lab != -1
                 ref_emb, ref_lab = ref_emb.reshape(-1, c)[keep], ref_lab[keep]
-            bank = None
-            if (k_nearest_neighbors == 1 and current_frame_embedding.is_cuda
-                    and not (torch.is_grad_enabled() and (ref_frame_embedding.requires_grad
-                                                          or current_frame_embedding.requires_grad))):
+            bank, fcur, lpre, preset_done = None, None, None, False
+            inference = current_frame_embedding.is_cuda and not (
+                torch.is_grad_enabled() and (ref_frame_embedding.requires_grad or current_frame_embedding.requires_grad
+                                             or previous_frame_embedding.requires_grad))
+            fused_local = use_local_map and inference and self._local_radius() >= 0
+            if k_nearest_neighbors == 1 and inference:
                 bank = self._prepared_bank(seq_names[n], ref_frame_embedding[n], ref_scribble_label[n], ref_emb,
                                            ref_lab, n_ids)
+            if inference and (bank is not None or fused_local):
+                # this frame's operands: ONE read of its embedding (cache hit when the driver prepared the clip, or on
+                # later interaction rounds); wide windows want the local map pre-set to 1.0 -- it rides in that launch
+                if fused_local and self._local_radius() >= 11:
+                    lpre = torch.empty((h, w, n_ids), dtype=torch.float32, device=current_frame_embedding.device)
+                fcur, preset_done = self._prepared_frame(current_frame_embedding[n], preset=lpre)
             if bank is not None:  # the propagation loop matches every frame against ONE annotated frame (test.py:237-259)
-                nn_features_n = bank.match(seq_current_frame_embedding,
-                                           normalize=bool(normalize_nearest_neighbor_distances),
+                nn_features_n = bank.match(fcur, normalize=bool(normalize_nearest_neighbor_distances),
                                            mem=mem).view(1, h, w, n_ids, 1)
             else:
                 nn_features_n = ops.global_match(ref_emb, seq_current_frame_embedding, ref_lab, n_ids,
-                                                 k_nearest_neighbors=k_nearest_neighbors, compute=COMPUTE,
+                                                 k_nearest_neighbors=k_nearest_neighbors, compute=self.compute,
                                                  normalize=bool(normalize_nearest_neighbor_distances),
                                                  mem=mem).view(1, h, w, n_ids, 1)
 
             # ---- local map
             seq_previous_frame_label = scale_previous_frame_label[n].permute(1, 2, 0)
-            if use_local_map:
+            if fused_local:
+                # the previous frame was the current frame of the last step (test.py:259): its plane is cached
+                fprev, _ = self._prepared_frame(previous_frame_embedding[n])
+                prev_frame_nn_features_n = ops.local_match_frames(
+                    fprev, fcur, seq_previous_frame_label, n_ids, out=lpre,
+                    out_is_preset=preset_done).view(1, h, w, n_ids, 1)
+            elif use_local_map:
                 prev_frame_nn_features_n = local_previous_frame_nearest_neighbor_features_per_object(
                     prev_frame_embedding=seq_prev_frame_embedding, query_embedding=seq_current_frame_embedding,
                     prev_frame_labels=seq_previous_frame_label, gt_ids=ref_obj_ids,
@@ -448,7 +572,7 @@ class IntVOS(nn.Module):
             else:
                 prev_frame_nn_features_n = ops.global_match(
                     seq_prev_frame_embedding, seq_current_frame_embedding, seq_previous_frame_label.reshape(-1),
-                    n_ids, k_nearest_neighbors=k_nearest_neighbors, compute=COMPUTE,
+                    n_ids, k_nearest_neighbors=k_nearest_neighbors, compute=self.compute,
                     normalize=True).view(1, h, w, n_ids, 1)
 
             # ---- local map memory (:638-661)
@@ -505,9 +629,14 @@ class IntVOS(nn.Module):
             seq_ref_frame_embedding = ref_frame_embedding[n].permute(1, 2, 0)
             seq_ref_scribble_label = scale_ref_scribble_label[n].permute(1, 2, 0)
             # ---- local map of the annotated frame against itself (:709-711)
-            nn_features_n = local_previous_frame_nearest_neighbor_features_per_object(
-                prev_frame_embedding=seq_ref_frame_embedding, query_embedding=seq_ref_frame_embedding,
-                prev_frame_labels=seq_ref_scribble_label, gt_ids=gt_id, max_distance=cfg.MODEL_MAX_LOCAL_DISTANCE)
+            if (ref_frame_embedding.is_cuda and self._local_radius() >= 0
+                    and not (torch.is_grad_enabled() and ref_frame_embedding.requires_grad)):
+                fref, _ = self._prepared_frame(ref_frame_embedding[n])
+                nn_features_n = ops.local_match_frames(fref, fref, seq_ref_scribble_label, n_ids).view(1, h, w, n_ids, 1)
+            else:
+                nn_features_n = local_previous_frame_nearest_neighbor_features_per_object(
+                    prev_frame_embedding=seq_ref_frame_embedding, query_embedding=seq_ref_frame_embedding,
+                    prev_frame_labels=seq_ref_scribble_label, gt_ids=gt_id, max_distance=cfg.MODEL_MAX_LOCAL_DISTANCE)
             # ---- global map update (:716-723): min-merge of THIS map into the stored one
             if seq_names[n] not in global_map_tmp_dic:
                 global_map_tmp_dic[seq_names[n]] = torch.ones_like(nn_features_n).repeat(MAX_CLIP_FRAMES, 1, 1, 1, 1)

@@ -34,9 +34,9 @@ def tiny_cfg():
                      "--MODEL_MAX_LOCAL_DISTANCE", "2"])
 
 
-def build_model(g, device):
+def build_model(g, device, **kw):
     from cvpr2020_manet_amd.networks import IntVOS as M
-    model = M.IntVOS(tiny_cfg(), TinyExtractor())
+    model = M.IntVOS(tiny_cfg(), TinyExtractor(), **kw)
     sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd::")}
     assert sorted(model.state_dict().keys()) == sorted(sd.keys()) == sorted(g["sd_keys"].tolist())
     model.load_state_dict(sd, strict=True)
@@ -195,6 +195,63 @@ def test_end_to_end_on_gpu_matches_reference_class():
 
 
 @pytest.mark.gpu
+def test_end_to_end_on_gpu_prepares_every_frame_once():
+    """the propagation script touches 4 frames (3 of them as query, 2 as annotated frame): each is prepared exactly once
+    (one launch each), whatever the number of times it is the current / previous / annotated frame or the round"""
+    from cvpr2020_manet_amd import ops
+    g = load_golden("e2e_tiny")
+    model = build_model(g, "cuda")
+    calls = []
+    real = ops.prepare_frames
+
+    def counting(emb, **kw):
+        calls.append(tuple(emb.shape))
+        return real(emb, **kw)
+    ops.prepare_frames = counting
+    try:
+        out = run_script(model, g, "cuda")
+    finally:
+        ops.prepare_frames = real
+    compare(out, g, tol_logits=5e-4)
+    # run_script: frames 1, 2, 3 of `embs` + the previous / current frame of the batch model.forward extracts itself
+    assert len(calls) == 5 and all(len(c) == 3 for c in calls)
+    # a driver that prepares the clip up front (prepare_clip) leaves the loop with nothing to prepare
+    model2 = build_model(g, "cuda")
+    real_extract = model2.extract_feature
+    model2.extract_feature = lambda x: real_extract(x, packed=True)
+    calls.clear()
+    ops.prepare_frames = counting
+    try:
+        out2 = run_script(model2, g, "cuda")
+    finally:
+        ops.prepare_frames = real
+    assert [c[0] for c in calls] == [4, 3]  # two batched launches [B, C, h, w]: the clip of 4, forward()'s own batch of 3
+    for k in ("prop1_logits_3", "prop2_logits_3", "gmap_round2", "lmap_tmp"):
+        assert torch.equal(out2[k], out[k]), k
+
+
+@pytest.mark.gpu
+def test_end_to_end_on_gpu_with_2_byte_embeddings_and_bf16_arithmetic():
+    """SURVEY 8f rank 4 through the drop-in module: IntVOS(cfg, fe, compute=..., emb_dtype="bf16") stores
+    extract_feature's output in bf16, the matching kernels read 2-byte embeddings (and, for compute="bf16", multiply in
+    bf16), the heads widen them.  Bounded against the reference class's fp32 logits (e2e_tiny.npz): the embeddings carry
+    8 significand bits, the logits move by a few 1e-3 of their range."""
+    g = load_golden("e2e_tiny")
+    ref_scale = max(float(np.abs(g[k]).max()) for k in ("int_logits", "prop1_logits_3", "prop2_logits_3"))
+    for compute in ("f32", "bf16", "bf16x3"):
+        model = build_model(g, "cuda", compute=compute, emb_dtype="bf16")
+        out = run_script(model, g, "cuda")
+        assert out["embs"].dtype == torch.bfloat16
+        np.testing.assert_allclose(out["embs"].float().cpu().numpy(), g["embs"], rtol=2 ** -8, atol=1e-6)
+        for k in ("gmap_round1", "gmap_round2", "lmap_tmp"):
+            err = float(np.abs(out[k].cpu().numpy() - g[k]).max())
+            assert err < 1e-2, (compute, k, err)  # normalised maps in [0, 1]
+        for k in ("int_logits", "prop1_logits_2", "prop1_logits_3", "int2_logits", "prop2_logits_3"):
+            err = float(np.abs(out[k].cpu().numpy() - g[k]).max())
+            assert err < 2e-2 * max(ref_scale, 1.0), (compute, k, err)
+
+
+@pytest.mark.gpu
 def test_module_functions_on_gpu_match_reference():
     from cvpr2020_manet_amd.networks import IntVOS as M
     M.set_cfg(tiny_cfg())
@@ -227,6 +284,8 @@ def test_cfg_defaults_equal_reference():
     from conftest import GOLDEN
     from cvpr2020_manet_amd.config import make_cfg
     ref = json.load(open(os.path.join(GOLDEN, "config_defaults.json")))
-    mine = {k: v for k, v in vars(make_cfg([])).items() if k != "ROOT_DIR"}
+    # (MODEL_MATCH_COMPUTE / MODEL_EMB_DTYPE are this implementation's two extension flags, absent from the reference)
+    mine = {k: v for k, v in vars(make_cfg([])).items() if k not in ("ROOT_DIR", "MODEL_MATCH_COMPUTE", "MODEL_EMB_DTYPE")}
     assert mine == ref
+    assert make_cfg([]).MODEL_MATCH_COMPUTE == "f32" and make_cfg([]).MODEL_EMB_DTYPE == "f32"
     assert make_cfg(["--TEST_MODE", "True", "--unknown-flag", "1"]).TEST_MODE is True
