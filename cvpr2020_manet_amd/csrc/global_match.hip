@@ -662,6 +662,46 @@ __device__ __forceinline__ float min3p(float m, float a, float b)
     return __builtin_elementwise_minimum(__builtin_elementwise_minimum(m, a), b);
 }
 
+// block -> (query tile, bank split, tile range [t0, t1)); false = nothing to do.
+// Big banks: S splits chosen on the host (pick_splits), split index tied to the XCD (block b runs on XCD b % 8 --
+// observed, used for speed only): the blocks of one XCD that are resident together stream the same bank range
+// through that XCD's L2.
+// Small banks (T < S tiles: a scribble-sized memory, the reference's normal case, test.py:170-176): the host cannot know
+// T without a sync (it only knows the upper bound M0 / 64), and S splits of at most one tile each would make every
+// workgroup load its 256-query operand for a single tile.  The kernel re-decides: S' = clamp(small_S, 1, T) splits with
+// small_S = resident workgroup slots / query tiles -- one full round of workgroups, whole tiles each -- and a flat
+// block -> (tile, split) map (such a bank fits every XCD's L2 anyway).  The minimum is order-independent: same bits.
+// `block_map`: bits 0-7 = tuning (0: XCD-aware, 1: tile fastest, 2: split fastest), bits 8.. = small_S.
+__device__ __forceinline__ bool split_of_block(int b, int nQT, int S, int T, int block_map, int &qt, int &s, int &t0,
+                                               int &t1)
+{
+    const int bm = block_map & 0xff, small_S = block_map >> 8;
+    if (T < S && small_S > 0) {
+        const int S2 = small_S < T ? small_S : T;
+        qt = b % nQT;
+        s = b / nQT;
+        if (s >= S2) return false;
+        t0 = (int)((long)s * T / S2);
+        t1 = (int)((long)(s + 1) * T / S2);
+        return t0 < t1;
+    }
+    if (bm == 0) {
+        const int xcd = b & 7;
+        const int idx = b >> 3;
+        qt = idx % nQT;
+        s = xcd + 8 * (idx / nQT);
+    } else if (bm == 1) {
+        qt = b % nQT;
+        s = b / nQT;
+    } else {
+        s = b % S;
+        qt = b / S;
+    }
+    t0 = (int)((long)s * T / S);
+    t1 = (int)((long)(s + 1) * T / S);
+    return t0 < t1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // main kernel, fp32: one workgroup = 256 queries x one bank split
 // sorted insert of d into the ascending list m[0..K-1] (drops the largest)
@@ -706,24 +746,9 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
 
     // XCD-aware mapping: block b runs on XCD b % 8 (observed, used for speed only).  All blocks
     // of one XCD that are resident together share a bank split -> the split streams through L2.
-    const int b = blockIdx.x;
-    int qt, s;
-    if (block_map == 0) {
-        const int xcd = b & 7;
-        const int idx = b >> 3;
-        qt = idx % nQT;
-        s = xcd + 8 * (idx / nQT);
-    } else if (block_map == 1) {  // tuning only: query tile fastest, no XCD awareness
-        qt = b % nQT;
-        s = b / nQT;
-    } else {                      // tuning only: split fastest
-        s = b % S;
-        qt = b / S;
-    }
+    int qt, s, t0, t1;
     const int T = meta[META_T];
-    const int t0 = (int)((long)s * T / S);
-    const int t1 = (int)((long)(s + 1) * T / S);
-    if (t0 >= t1) return;
+    if (!split_of_block(blockIdx.x, nQT, S, T, block_map, qt, s, t0, t1)) return;
 
     // Tile staging through registers (issue the global loads a whole tile-step early, write them to
     // LDS after the next barrier).  global_load_lds would save the VGPR round trip, but hipcc cannot
@@ -919,24 +944,9 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_pipe_kernel(const cha
     const int l31 = lane & 31;
     const int h = lane >> 5;
 
-    const int b = blockIdx.x;
-    int qt, s;
-    if (block_map == 0) {
-        const int xcd = b & 7;
-        const int idx = b >> 3;
-        qt = idx % nQT;
-        s = xcd + 8 * (idx / nQT);
-    } else if (block_map == 1) {
-        qt = b % nQT;
-        s = b / nQT;
-    } else {
-        s = b % S;
-        qt = b / S;
-    }
+    int qt, s, t0, t1;
     const int T = meta[META_T];
-    const int t0 = (int)((long)s * T / S);
-    const int t1 = (int)((long)(s + 1) * T / S);
-    if (t0 >= t1) return;
+    if (!split_of_block(blockIdx.x, nQT, S, T, block_map, qt, s, t0, t1)) return;
 
     const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
     auto stage_dma = [&](int t, int slot) __attribute__((always_inline)) {
@@ -1117,21 +1127,9 @@ __global__ __launch_bounds__(512, 1) void global_match_bf16_kernel(const char *_
     const int l31 = lane & 31;
     const int h = lane >> 5;
 
-    const int b = blockIdx.x;
-    int qt, s;
-    if (block_map == 0) {
-        const int xcd = b & 7;
-        const int idx = b >> 3;
-        qt = idx % nQT;
-        s = xcd + 8 * (idx / nQT);
-    } else {
-        qt = b % nQT;
-        s = b / nQT;
-    }
+    int qt, s, t0, t1;
     const int T = meta[META_T];
-    const int t0 = (int)((long)s * T / S);
-    const int t1 = (int)((long)(s + 1) * T / S);
-    if (t0 >= t1) return;
+    if (!split_of_block(blockIdx.x, nQT, S, T, block_map, qt, s, t0, t1)) return;
 
     // ---- staging of one STEP = TPS consecutive tiles ------------------------------------------------
     constexpr int PIECES = UNITS * TPS;  // 1 KiB pieces per step
@@ -1341,21 +1339,9 @@ void global_match_bf16_pipe_kernel(const char *__restrict__ qpack, const char *_
     const int l31 = lane & 31;
     const int h = lane >> 5;
 
-    const int b = blockIdx.x;
-    int qt, s;
-    if (block_map == 0) {
-        const int xcd = b & 7;
-        const int idx = b >> 3;
-        qt = idx % nQT;
-        s = xcd + 8 * (idx / nQT);
-    } else {
-        qt = b % nQT;
-        s = b / nQT;
-    }
+    int qt, s, t0, t1;
     const int T = meta[META_T];
-    const int t0 = (int)((long)s * T / S);
-    const int t1 = (int)((long)(s + 1) * T / S);
-    if (t0 >= t1) return;
+    if (!split_of_block(blockIdx.x, nQT, S, T, block_map, qt, s, t0, t1)) return;
 
     constexpr int PIECES = UNITS * TPS;  // 1 KiB pieces per step
     const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
@@ -1512,21 +1498,9 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     const int l31 = lane & 31;
     const int h = lane >> 5;
 
-    const int b = blockIdx.x;
-    int qt, s;
-    if (block_map == 0) {
-        const int xcd = b & 7;
-        const int idx = b >> 3;
-        qt = idx % nQT;
-        s = xcd + 8 * (idx / nQT);
-    } else {
-        qt = b % nQT;
-        s = b / nQT;
-    }
+    int qt, s, t0, t1;
     const int T = meta[META_T];
-    const int t0 = (int)((long)s * T / S);
-    const int t1 = (int)((long)(s + 1) * T / S);
-    if (t0 >= t1) return;
+    if (!split_of_block(blockIdx.x, nQT, S, T, block_map, qt, s, t0, t1)) return;
 
     constexpr int PIECES = UNITS * TPS;  // 1 KiB pieces per step
     const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
@@ -1847,6 +1821,15 @@ int check_common(int64_t N, int64_t M0, int C, int n_ids, int k_nn, int compute)
     return MANET_OK;
 }
 
+// the kernels' `block_map` argument: tuning bits + small_S (see split_of_block)
+int block_map_arg(int nQT, int slots)
+{
+    int small_S = slots / (nQT > 0 ? nQT : 1);
+    if (small_S < 1) small_S = 1;
+    if (small_S > 4096) small_S = 4096;
+    return (manet_tune_get(MANET_TUNE_BLOCK_MAP, 0) & 0xff) | (small_S << 8);
+}
+
 template <int KS, int KNN, bool ARG = false>
 void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S,
                      long N_pad, unsigned *keys, float *topk, hipStream_t st)
@@ -1857,7 +1840,7 @@ void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int 
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     manet_profile_record(st, true);
     hipLaunchKernelGGL((global_match_f32_kernel<KS, KNN, ARG>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack,
-                       bpack, meta, n_ids, nQT, S, N_pad, keys, topk, manet_tune_get(MANET_TUNE_BLOCK_MAP, 0));
+                       bpack, meta, n_ids, nQT, S, N_pad, keys, topk, block_map_arg(nQT, 512));
     manet_profile_record(st, false);
 }
 
@@ -1870,7 +1853,7 @@ void launch_main_f32_pipe(const char *qpack, const char *bpack, const int *meta,
                               (int)lds);
     manet_profile_record(st, true);
     hipLaunchKernelGGL((global_match_f32_pipe_kernel<KS>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack, bpack, meta,
-                       n_ids, nQT, S, N_pad, keys, manet_tune_get(MANET_TUNE_BLOCK_MAP, 0));
+                       n_ids, nQT, S, N_pad, keys, block_map_arg(nQT, 512));
     manet_profile_record(st, false);
 }
 
@@ -1883,7 +1866,7 @@ void launch_main_bf16_v(const char *qpack, const char *bpack, const int *meta, i
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     manet_profile_record(st, true);
     hipLaunchKernelGGL((global_match_bf16_kernel<KSB, X3, TPS, DMA>), dim3((unsigned)(nQT * S)), dim3(512), lds, st,
-                       qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, manet_tune_get(MANET_TUNE_BLOCK_MAP, 0),
+                       qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, block_map_arg(nQT, 256),
                        young_prio);
     manet_profile_record(st, false);
 }
@@ -1927,7 +1910,7 @@ void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int
             if (!fn) fn = (const void *)global_match_bf16_wide_kernel<KSB, 0>;
         }
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        int bm = manet_tune_get(MANET_TUNE_BLOCK_MAP, 0);
+        int bm = block_map_arg(nQT, narrow ? 256 : 512);
         void *args[] = {(void *)&qpack, (void *)&bpack, (void *)&meta, (void *)&n_ids, (void *)&nQT, (void *)&S,
                         (void *)&N_pad, (void *)&keys, (void *)&bm, (void *)&prio};
         manet_profile_record(st, true);

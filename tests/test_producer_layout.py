@@ -46,7 +46,7 @@ def test_packed_query_and_prepared_bank(ops, compute):
     assert torch.equal(plain, packed) and torch.equal(mem, packed)
     one_shot = ops.global_match(src(k).permute(1, 2, 0), src(q).permute(1, 2, 0), lab, 3, compute=compute, normalize=True)
     assert torch.equal(plain, one_shot)
-    with pytest.raises(ValueError, match="PackedQuery was packed"):
+    with pytest.raises(ValueError, match="was packed for"):
         ops.PreparedBank(k.permute(1, 2, 0), lab, 3, compute="bf16x3").match(pq)
 
 
