@@ -42,6 +42,10 @@ WRONG_LABEL_PADDING_DISTANCE = 1e20
 # IntVOS(cfg, ...) re-binds it to the cfg it is given.
 cfg = _default_cfg
 
+# DynamicSegHead blocks as ONE fused launch each (ops.sepconv7x7_pw) when they have 256 output channels; False = r2's
+# depthwise kernel + framework GEMM (A/B switch for examples/propagate_clip.py --unfused-head)
+FUSED_HEAD_BLOCKS = True
+
 # arithmetic of the QK^T contraction used by the MODULE-LEVEL functions: "f32" (exact fp32 MFMA) | "bf16" | "bf16x3" |
 # "bf16r".  An IntVOS instance carries its own (constructor argument / cfg.MODEL_MATCH_COMPUTE).
 COMPUTE = "f32"
@@ -231,8 +235,15 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
             b2 = (self.conv2.bias.detach().float() * scale2 + shift2 if self.conv2.bias is not None else shift2).contiguous()
             val = {"scale1": scale1.contiguous(), "shift1": shift1.contiguous(), "w2": w2, "b2": b2,
                    "w2_shared": w2[:, :cs].contiguous(), "w2_object": w2[:, cs:].contiguous()}
+            if self._fused_block():  # the one-launch form (ops.sepconv7x7_pw): 1x1 weight transposed, Cin padded to 16
+                val["w2t"], _ = ops.fold_pointwise(self.conv2, self.bn2)
         object.__setattr__(self, "_fold_cache", (key, val))  # plain attribute: not a buffer, not in the state dict
         return val
+
+    def _fused_block(self):
+        """the whole block in one launch (depthwise waves feeding fp32-MFMA waves, ops.sepconv7x7_pw)"""
+        return (self.conv2.out_channels == ops.SEPCONV_COUT and self.conv2.kernel_size == (1, 1)
+                and self.conv1.kernel_size == (7, 7) and FUSED_HEAD_BLOCKS)
 
     def forward(self, x, relu_in=False, defer_relu=False):
         """relu_in / defer_relu (inference fast path only, used by DynamicSegHead): the block's last ReLU is left to the
@@ -240,6 +251,9 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         activation less per block, same values."""
         if self._fast(x):
             k = self._folded()
+            if self._fused_block():
+                return ops.sepconv7x7_pw(x, self.conv1.weight, self.conv1.bias, k["scale1"], k["shift1"], k["w2t"], k["b2"],
+                                         relu_in=relu_in, relu_out=not defer_relu)
             x = ops.dwconv7x7_bn_relu(x, self.conv1.weight, self.conv1.bias, scale=k["scale1"], shift=k["shift1"],
                                       relu_in=relu_in)
             y = F.conv2d(x, k["w2"], k["b2"])
@@ -256,6 +270,9 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         shared [1, Cs, h, w], per_object [n, Cp, h, w], Cs + Cp == in_dim."""
         cs = shared.shape[1]
         k = self._folded(cs)
+        if self._fused_block():  # one launch: the shared channels are read with batch stride 0, no repeat / cat
+            return ops.sepconv7x7_pw(per_object, self.conv1.weight, self.conv1.bias, k["scale1"], k["shift1"], k["w2t"],
+                                     k["b2"], relu_out=not defer_relu, shared=shared)
         scale, shift = k["scale1"], k["shift1"]
         w1, b1 = self.conv1.weight, self.conv1.bias
         s1 = ops.dwconv7x7_bn_relu(shared, w1[:cs], b1[:cs], scale=scale[:cs], shift=shift[:cs])

@@ -540,6 +540,61 @@ def dwconv7x7_bn_relu(x, weight, bias=None, bn=None, relu=True, scale=None, shif
     return out
 
 
+SEPCONV_COUT = 256  # output channels the fused block kernel is built for (the reference's MODEL_HEAD_EMBEDDING_DIM)
+
+
+def fold_pointwise(conv2, bn2):
+    """(w2t, b2) for sepconv7x7_pw: conv2's [Cout, Cin, 1, 1] weight transposed to [Cin_pad, Cout] with eval-mode bn2
+    folded in (Cin padded with zero rows to a multiple of 16), and the folded bias [Cout]."""
+    scale2, shift2 = fold_bn(bn2)
+    w = conv2.weight.detach().float().reshape(conv2.out_channels, conv2.in_channels) * scale2[:, None]
+    cin = conv2.in_channels
+    pad = (cin + 15) // 16 * 16
+    w2t = torch.zeros((pad, conv2.out_channels), dtype=torch.float32, device=w.device)
+    w2t[:cin] = w.t()
+    b2 = (conv2.bias.detach().float() * scale2 + shift2) if conv2.bias is not None else shift2
+    return w2t.contiguous(), b2.contiguous()
+
+
+def sepconv7x7_pw(x, dw_weight, dw_bias, scale1, shift1, w2t, b2, relu_in=False, relu_out=False, shared=None):
+    """One _split_separable_conv2d block (IntVOS.py:488-506) in one launch: relu(bn1(dwconv7x7)) feeding an fp32-MFMA 1x1
+    contraction with bn2 folded in; the activation between the two never leaves the compute unit.
+    x [B, Cx, h, w] fp32; shared: optional [1, Cs, h, w] whose channels come FIRST and are the same for every batch item
+    (layer 1: the embedding, IntVOS.py:665-670) -- the repeat / cat is not built.  dw_weight [Cs+Cx, 1, 7, 7] etc. cover the
+    concatenated channels.  Returns [B, 256, h, w]; relu_out=False leaves relu2 to the next block's relu_in."""
+    _refuse_autograd("sepconv7x7_pw", x, shared, dw_weight, dw_bias, scale1, shift1, w2t, b2)
+    lib = _lib.load()
+    _need_gpu(x, "x")
+    x = x.float().contiguous()
+    B, Cx, h, w = x.shape
+    if shared is not None:
+        _need_gpu(shared, "shared")
+        shared = shared.float().contiguous()
+        if shared.shape[0] != 1 or tuple(shared.shape[2:]) != (h, w):
+            raise ValueError("shared must be [1, Cs, h, w] on the same grid as x")
+        Cs = shared.shape[1]
+        in_a, sa, Ca, in_b, sb, Cb = shared, 0, Cs, x, Cx * h * w, Cx
+    else:
+        in_a, sa, Ca, in_b, sb, Cb = x, Cx * h * w, Cx, None, 0, 0
+    cin = Ca + Cb
+    if dw_weight.numel() != cin * 49:
+        raise ValueError("dw_weight must be [%d, 1, 7, 7]" % cin)
+    if w2t.shape[0] != (cin + 15) // 16 * 16 or w2t.shape[1] != SEPCONV_COUT or b2.numel() != SEPCONV_COUT:
+        raise ValueError("w2t must be [%d, %d] (ops.fold_pointwise), b2 [%d]" % ((cin + 15) // 16 * 16, SEPCONV_COUT,
+                                                                             SEPCONV_COUT))
+    f = lambda t: None if t is None else t.detach().float().contiguous()
+    dw_weight, dw_bias, scale1, shift1, w2t, b2 = f(dw_weight), f(dw_bias), f(scale1), f(shift1), f(w2t), f(b2)
+    out = torch.empty((B, SEPCONV_COUT, h, w), dtype=torch.float32, device=x.device)
+    p = lambda t: None if t is None else t.data_ptr()
+    with torch.cuda.device(x.device):
+        rc = lib.manet_sepconv7x7_pw_f32(in_a.data_ptr(), sa, Ca, p(in_b), sb, Cb, B, h, w, dw_weight.data_ptr(), p(dw_bias),
+                                         p(scale1), p(shift1), int(bool(relu_in)), w2t.data_ptr(), w2t.shape[0],
+                                         b2.data_ptr(), SEPCONV_COUT, int(bool(relu_out)), out.data_ptr(),
+                                         _stream_ptr(x.device))
+    _lib.check(rc, "manet_sepconv7x7_pw_f32")
+    return out
+
+
 def relu_conv1x1_c1(x, weight, bias=None, relu_in=True):
     """DynamicSegHead's output layer in one pass over the activation (IntVOS.py:519,525): Conv2d(C, 1, 1) applied to
     max(x, 0) (relu_in) or to x.  x [B, C, h, w] fp32, weight [1, C, 1, 1], bias [1] or None -> [B, 1, h, w]."""

@@ -145,3 +145,47 @@ def test_folded_constants_follow_parameter_updates():
                 blk.conv2.weight.data = blk.conv2.weight.data.clone() * 1.1      # new storage
             torch.testing.assert_close(blk(x), literal(blk), rtol=1e-4, atol=1e-4)
             torch.testing.assert_close(blk(x), literal(blk), rtol=1e-4, atol=1e-4)  # second call: served from the cache
+
+
+@pytest.mark.gpu
+def test_fused_block_one_launch_vs_literal_module():
+    """ops.sepconv7x7_pw (depthwise waves feeding fp32-MFMA waves, the activation between the two stages never leaves the
+    CU) against the block's literal form relu2(bn2(conv2(relu1(bn1(conv1(x)))))): ragged tiles, Cin not a multiple of the
+    16-channel chunk, relu_in / deferred relu, the shared-embedding input of layer 1, and the full [3,256,120,214] size.
+    The depthwise stage keeps the two-kernel path's tap order; the 1x1 stage is an ascending-channel fp32 fmaf chain."""
+    import torch
+    from cvpr2020_manet_amd import ops
+    from cvpr2020_manet_amd.networks import IntVOS as M
+    torch.manual_seed(3)
+    for (B, cin, h, w) in ((3, 256, 30, 54), (2, 103, 9, 13), (1, 16, 4, 16), (2, 7, 21, 35), (3, 256, 120, 214)):
+        blk = M._split_separable_conv2d(cin, 256).cuda().eval()
+        for m in (blk.bn1, blk.bn2):
+            m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 2.0); m.weight.data.normal_(1, 0.2); m.bias.data.normal_(0, 0.2)
+        x = torch.randn(B, cin, h, w, device="cuda")
+        with torch.no_grad():
+            lit = blk.relu2(blk.bn2(blk.conv2(blk.relu1(blk.bn1(blk.conv1(x))))))
+            scale1, shift1 = ops.fold_bn(blk.bn1)
+            w2t, b2 = ops.fold_pointwise(blk.conv2, blk.bn2)
+            got = ops.sepconv7x7_pw(x, blk.conv1.weight, blk.conv1.bias, scale1, shift1, w2t, b2, relu_out=True)
+            torch.testing.assert_close(got, lit, rtol=2e-4, atol=2e-4)
+            # deferred ReLU out, ReLU folded into the read
+            raw = ops.sepconv7x7_pw(x, blk.conv1.weight, blk.conv1.bias, scale1, shift1, w2t, b2, relu_out=False)
+            assert torch.equal(torch.relu(raw), got)
+            a = ops.sepconv7x7_pw(x, blk.conv1.weight, blk.conv1.bias, scale1, shift1, w2t, b2, relu_in=True)
+            b_ = ops.sepconv7x7_pw(torch.relu(x), blk.conv1.weight, blk.conv1.bias, scale1, shift1, w2t, b2)
+            assert torch.equal(a, b_)
+            # against the two-kernel path: same depthwise bits, the contraction in another summation order
+            y = ops.dwconv7x7_bn_relu(x, blk.conv1.weight, blk.conv1.bias, scale=scale1, shift=shift1)
+            two = torch.nn.functional.conv2d(y, w2t[:cin].t().reshape(256, cin, 1, 1).contiguous(), b2)
+            torch.testing.assert_close(raw, two, rtol=2e-4, atol=2e-4)
+            # the module itself takes this path in eval mode
+            torch.testing.assert_close(blk(x), lit, rtol=2e-4, atol=2e-4)
+            if cin > 3:  # layer 1's two-source input: the first cin-3 channels shared by the batch
+                shared, per = x[:1, :cin - 3].contiguous(), x[:, cin - 3:].contiguous()
+                full = torch.cat((shared.repeat(B, 1, 1, 1), per), 1)
+                want = ops.sepconv7x7_pw(full, blk.conv1.weight, blk.conv1.bias, scale1, shift1, w2t, b2)
+                got2 = ops.sepconv7x7_pw(per, blk.conv1.weight, blk.conv1.bias, scale1, shift1, w2t, b2, shared=shared)
+                assert torch.equal(got2, want)
+                torch.testing.assert_close(blk.forward_shared(shared, per), blk(full), rtol=0, atol=0)
+    with pytest.raises(ValueError):
+        ops.sepconv7x7_pw(x, blk.conv1.weight, blk.conv1.bias, scale1, shift1, w2t[:16], b2)
