@@ -226,30 +226,32 @@ __global__ __launch_bounds__(64 * RC_WAVES) void relu_conv1x1_c1_kernel(const fl
 // r2 ran them as two kernels with the [B,256,h,w] activation y (79 MB at 3 objects, 480p) written and re-read in between
 // and the contraction in the framework's GEMM: 60 + 108 us per block, 45 % of an end-to-end frame.  Here y never leaves
 // the CU: a workgroup owns a 4 x 16 pixel tile of one batch item and ALL 256 output channels, and is split by role --
-//   waves 0-3   matrix waves: 64 output channels x 64 pixels each (2 x 2 blocks of v_mfma_f32_32x32x2_f32, 64 accumulator
-//               VGPRs); per chunk of 16 input channels 8 k-steps x 4 MFMAs with A = folded 1x1 weights and B = y, both
-//               read from LDS as one dword per lane (conflict-free);
-//   waves 4-11  depthwise waves: per chunk each wave computes 2 channels x 64 pixels, one output per lane, 49 dependent
-//               fmaf with the tap weight in an SGPR (the channel is wave-uniform) and the input from the LDS halo tile at
-//               compile-time offsets -- the tap order (ky outer, kx inner) and the bn1 expression of
-//               dwconv7x7_bn_relu_kernel, so y is bit-identical to the two-kernel path; they also stage the NEXT chunks'
-//               halo tiles (global -> registers -> LDS, zero padding and the preceding block's deferred ReLU applied on
-//               the way);
+//   waves 0-3  matrix waves: 64 output channels x 64 pixels each (2 x 2 blocks of v_mfma_f32_32x32x2_f32, 64 accumulator
+//              VGPRs); per chunk of 16 input channels 8 k-steps x 4 MFMAs with A = folded 1x1 weights and B = y, both read
+//              from LDS as one dword per lane (conflict-free);
+//   waves 4-7  depthwise waves: per chunk each wave computes 4 channels x 64 pixels, a lane owns 4 neighbouring pixels of
+//              one channel: per kernel row three LDS reads (10 window floats) feed 28 fmaf whose tap weights sit in the
+//              lane's registers (the channel's 49 taps + bias + bn1 scale / shift, one padded 52-float row, prefetched a
+//              chunk ahead); tap order (ky outer, kx inner) and bn1 expression of dwconv7x7_bn_relu_kernel, so y is
+//              bit-identical to the two-kernel path.  They also stage the NEXT chunks' halo tiles (global -> registers ->
+//              LDS, zero padding and the preceding block's deferred ReLU applied on the way);
 // so the matrix pipe and the vector pipe of every SIMD run side by side (MI355X_MICROARCH.md: an MFMA-only and a
-// VALU-only wave on one SIMD overlap), one barrier per chunk.  The 1x1 weights arrive by LDS-DMA from a pre-transposed
-// [Cin_pad][256] copy (bn2 folded in), double buffered.  The input may come from TWO tensors (channels [0, Ca) from
-// `in_a`, the rest from `in_b`, each with its own batch stride): layer 1 reads the C-channel embedding with batch stride
-// 0 next to the per-object maps, i.e. IntVOS.py:665-670's repeat / cat is never built.
+// VALU-only wave on one SIMD overlap), one barrier per chunk; per chunk the matrix waves need 32 x 64 = 2 048 cycles, the
+// depthwise waves ~450 VALU / LDS instructions -- about the same time: both pipes are busy.  The 1x1 weights arrive by
+// LDS-DMA from a pre-transposed [Cin_pad][256] copy (bn2 folded in), double buffered.  The input may come from TWO tensors
+// (channels [0, Ca) from `in_a`, the rest from `in_b`, each with its own batch stride): layer 1 reads the C-channel
+// embedding with batch stride 0 next to the per-object maps, i.e. IntVOS.py:665-670's repeat / cat is never built.
 constexpr int SC_TY = 4, SC_TX = 16, SC_P = SC_TY * SC_TX, SC_KC = 16, SC_CO = 256;
 constexpr int SC_IR = SC_TY + 2 * DW_R, SC_IC = SC_TX + 2 * DW_R;  // halo tile 10 x 22
 constexpr int SC_IW = 24, SC_ICH = SC_IR * SC_IW;                  // LDS row stride / floats per channel
-constexpr int SC_NMM = 4, SC_NDW = 8, SC_NT = 64 * (SC_NMM + SC_NDW);
+constexpr int SC_NMM = 4, SC_NDW = 4, SC_NT = 64 * (SC_NMM + SC_NDW);
 constexpr int SC_NLD = (SC_KC * SC_IR * SC_IC + 64 * SC_NDW - 1) / (64 * SC_NDW);  // staged elements per depthwise thread
+constexpr int SC_WROW = 52;  // floats per row of the padded depthwise parameter table: 49 taps, bias, bn1 scale, bn1 shift
 struct SepConv {
     const float *in_a, *in_b;
     long sa, sb;  // batch strides (elements); 0 = the same tensor for every batch item
     int Ca, Cin, nchunks, h, w;
-    const float *dw_w, *dw_b, *s1, *t1;
+    const float *dwp;  // [Cin_pad][SC_WROW]
     int relu_in;
     const float *w2t, *b2;
     int relu_out;
@@ -267,62 +269,76 @@ __global__ __launch_bounds__(SC_NT) void sepconv7x7_pw_kernel(const SepConv A)
     const int h = A.h, w = A.w, n = A.nchunks;
     const long plane = (long)h * w;
 
-    // ---- depthwise waves: staging of a chunk's halo tile (registers in between, so the loads fly under the arithmetic)
+    // ---- depthwise waves: staging of a chunk's halo tile.  A thread's SC_NLD elements keep their place for the whole
+    // kernel: pixel offset, validity and LDS slot are computed once, a chunk only moves the channel base.
     const int t_dw = tid - 64 * SC_NMM;
-    float stg[SC_NLD];
-    auto stage_load = [&](int c) __attribute__((always_inline)) {
+    int s_pix[SC_NLD], s_lds[SC_NLD];  // s_lds < 0: no element; bit 30 of s_pix clear + s_ok: inside the image
+    unsigned s_ok = 0;
+    if (!mm) {
 #pragma unroll
         for (int j = 0; j < SC_NLD; ++j) {
             const int e = t_dw + 64 * SC_NDW * j;
             const int ch = e / (SC_IR * SC_IC), rem = e - ch * (SC_IR * SC_IC);
             const int r = rem / SC_IC, col = rem - r * SC_IC;
-            const int ci = c * SC_KC + ch, y = y0 - DW_R + r, x = x0 - DW_R + col;
-            const bool ok = e < SC_KC * SC_IR * SC_IC && ci < A.Cin && y >= 0 && y < h && x >= 0 && x < w;
-            const int cc = ci < A.Cin ? ci : A.Cin - 1, yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
+            const int y = y0 - DW_R + r, x = x0 - DW_R + col;
+            const bool have = e < SC_KC * SC_IR * SC_IC;
+            if (have && y >= 0 && y < h && x >= 0 && x < w) s_ok |= 1u << j;
+            s_pix[j] = min(max(y, 0), h - 1) * w + min(max(x, 0), w - 1);
+            s_lds[j] = have ? (ch * SC_ICH + r * SC_IW + col) | (ch << 20) : -1;
+        }
+    }
+    float stg[SC_NLD];
+    auto stage_load = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < SC_NLD; ++j) {
+            const int ch = (s_lds[j] >> 20) & 15;
+            const int ci = c * SC_KC + ch;
+            const int cc = ci < A.Cin ? ci : A.Cin - 1;
             const float *src = cc < A.Ca ? A.in_a + (long)b * A.sa + (long)cc * plane
                                          : A.in_b + (long)b * A.sb + (long)(cc - A.Ca) * plane;
-            float v = src[(unsigned)(yc * w + xc)];  // unconditional load, selected afterwards
-            v = ok ? v : 0.0f;
+            float v = src[(unsigned)s_pix[j]];  // unconditional load, selected afterwards
+            v = (((s_ok >> j) & 1u) && ci < A.Cin) ? v : 0.0f;
             stg[j] = A.relu_in ? fmaxf(v, 0.0f) : v;
         }
     };
     auto stage_store = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < SC_NLD; ++j) {
-            const int e = t_dw + 64 * SC_NDW * j;
-            const int ch = e / (SC_IR * SC_IC), rem = e - ch * (SC_IR * SC_IC);
-            const int r = rem / SC_IC, col = rem - r * SC_IC;
-            if (e < SC_KC * SC_IR * SC_IC) inbuf[buf][ch * SC_ICH + r * SC_IW + col] = stg[j];
-        }
+        for (int j = 0; j < SC_NLD; ++j)
+            if (s_lds[j] >= 0) inbuf[buf][s_lds[j] & 0xfffff] = stg[j];
     };
-    // lane -> pixel of the tile: the two 32-lane halves of a ds_read_b32 each see rows {0, 2} / {1, 3}: with the row stride
-    // of 24 floats those are 32 distinct banks for every tap offset
-    const int px = lane & 15, py = ((lane >> 4) & 1) * 2 + (lane >> 5);
-    auto dw_compute = [&](int c, int bin, int bd) __attribute__((always_inline)) {
-#pragma unroll 1
-        for (int jc = 0; jc < SC_KC / SC_NDW; ++jc) {
-            const int ch = (wave - SC_NMM) + SC_NDW * jc;  // wave-uniform
-            const int ci = c * SC_KC + ch;
-            float o = 0.0f;
-            if (ci < A.Cin) {
-                const float *wk = A.dw_w + (long)ci * (DW_K * DW_K);
-                const float *src = &inbuf[bin][ch * SC_ICH + py * SC_IW + px];
-                float acc = 0.0f;
-                // one kernel row at a time (7 LDS reads + 7 scalar weight loads in flight): unrolled over ky the compiler
-                // hoists all 49 reads and, next to the matrix waves' 64 accumulator registers, spills
-#pragma unroll 1
-                for (int ky = 0; ky < DW_K; ++ky) {
-                    float v[DW_K];
+    // lane -> (channel of the wave's four, row, group of 4 columns)
+    const int chl = lane >> 4, py = (lane >> 2) & 3, pxg = (lane & 3) * 4;
+    const int ch_dw = (wave - SC_NMM) * 4 + chl;  // channel inside the chunk (waves 4-7)
+    f32x4 wq[SC_WROW / 4];                        // this lane's channel: 49 taps, bias, scale, shift
+    auto w_load = [&](int c) __attribute__((always_inline)) {
+        const float *src = A.dwp + (long)(c * SC_KC + ch_dw) * SC_WROW;
 #pragma unroll
-                    for (int kx = 0; kx < DW_K; ++kx) v[kx] = src[ky * SC_IW + kx];
+        for (int i = 0; i < SC_WROW / 4; ++i) wq[i] = *(const f32x4 *)(src + 4 * i);
+    };
+    auto dw_compute = [&](int bin, int bd) __attribute__((always_inline)) {
+        const float *src = &inbuf[bin][ch_dw * SC_ICH + py * SC_IW + pxg];
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                    for (int kx = 0; kx < DW_K; ++kx) acc = fmaf(v[kx], wk[ky * DW_K + kx], acc);
-                }
-                const float bc = A.dw_b ? A.dw_b[ci] : 0.0f, sc = A.s1 ? A.s1[ci] : 1.0f, sh = A.t1 ? A.t1[ci] : 0.0f;
-                o = fmaxf(fmaf(acc + bc, sc, sh), 0.0f);
+        for (int ky = 0; ky < DW_K; ++ky) {
+            // (ties this row's reads behind the previous row's arithmetic: the unrolled loop otherwise keeps 70 window
+            // registers in flight)
+            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
+            const f32x4 u0 = *(const f32x4 *)(src + ky * SC_IW), u1 = *(const f32x4 *)(src + ky * SC_IW + 4);
+            const f32x2 u2 = *(const f32x2 *)(src + ky * SC_IW + 8);
+            const float v[10] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3], u2[0], u2[1]};
+#pragma unroll
+            for (int kx = 0; kx < DW_K; ++kx) {
+                const int t = ky * DW_K + kx;
+                const float wt = wq[t >> 2][t & 3];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[p] = fmaf(v[kx + p], wt, acc[p]);
             }
-            dbuf[bd][ch * SC_P + py * SC_TX + px] = o;
         }
+        const float bc = wq[12][1], sc = wq[12][2], sh = wq[12][3];
+        f32x4 o;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o[p] = fmaxf(fmaf(acc[p] + bc, sc, sh), 0.0f);
+        *(f32x4 *)&dbuf[bd][ch_dw * SC_P + py * SC_TX + pxg] = o;
     };
     // ---- matrix waves
     const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&wbuf[0][0]);
@@ -361,14 +377,18 @@ __global__ __launch_bounds__(SC_NT) void sepconv7x7_pw_kernel(const SepConv A)
         w_dma(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
+        w_load(0);
         stage_load(0);
         stage_store(0);
     }
     __syncthreads();
     if (!mm) {
         if (n > 1) stage_load(1);
-        dw_compute(0, 0, 0);
-        if (n > 1) stage_store(1);
+        dw_compute(0, 0);
+        if (n > 1) {
+            w_load(1);
+            stage_store(1);
+        }
     }
     __syncthreads();
     for (int c = 0; c < n; ++c) {
@@ -378,8 +398,11 @@ __global__ __launch_bounds__(SC_NT) void sepconv7x7_pw_kernel(const SepConv A)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             if (c + 2 < n) stage_load(c + 2);
-            if (c + 1 < n) dw_compute(c + 1, (c + 1) & 1, (c + 1) & 1);
-            if (c + 2 < n) stage_store(c & 1);
+            if (c + 1 < n) dw_compute((c + 1) & 1, (c + 1) & 1);  // with the parameters loaded one iteration ago
+            if (c + 2 < n) {
+                w_load(c + 2);  // lands under the next barrier and the next iteration's staging loads
+                stage_store(c & 1);
+            }
         }
         __syncthreads();
     }
@@ -441,28 +464,29 @@ extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, 
 }
 
 // One _split_separable_conv2d block in one launch (sepconv7x7_pw_kernel); out channels fixed at 256 (the reference's
-// MODEL_HEAD_EMBEDDING_DIM, config.py:48).
+// MODEL_HEAD_EMBEDDING_DIM, config.py:48).  dw_params: [Cin_pad][52] = per input channel the 49 taps, the depthwise bias,
+// bn1 scale and bn1 shift (rows beyond Cin: anything).
 extern "C" int manet_sepconv7x7_pw_f32(const float *in_a, int64_t batch_stride_a, int Ca, const float *in_b,
-                                       int64_t batch_stride_b, int Cb, int B, int h, int w, const float *dw_weight,
-                                       const float *dw_bias, const float *bn1_scale, const float *bn1_shift, int relu_in,
-                                       const float *w2t, int Cin_pad, const float *b2, int Cout, int relu_out, float *out,
-                                       manet_stream_t stream)
+                                       int64_t batch_stride_b, int Cb, int B, int h, int w, const float *dw_params,
+                                       int relu_in, const float *w2t, int Cin_pad, const float *b2, int Cout, int relu_out,
+                                       float *out, manet_stream_t stream)
 {
     const int Cin = Ca + Cb;
-    if (!in_a || Ca <= 0 || Cb < 0 || (Cb > 0 && !in_b) || !dw_weight || !w2t || !b2 || !out || B <= 0 || B > 65535 ||
+    if (!in_a || Ca <= 0 || Cb < 0 || (Cb > 0 && !in_b) || !dw_params || !w2t || !b2 || !out || B <= 0 || B > 65535 ||
         h <= 0 || w <= 0)
         return manet_set_error(MANET_E_INVALID, "bad arguments");
     if (Cout != SC_CO) return manet_set_error(MANET_E_INVALID, "Cout=%d (this kernel is built for %d output channels)", Cout, SC_CO);
     const int nchunks = (Cin + SC_KC - 1) / SC_KC;
     if (Cin_pad != nchunks * SC_KC)
-        return manet_set_error(MANET_E_INVALID, "w2t must have %d rows (Cin padded to whole chunks of %d), got %d",
+        return manet_set_error(MANET_E_INVALID, "w2t / dw_params must have %d rows (Cin padded to whole chunks of %d), got %d",
                                nchunks * SC_KC, SC_KC, Cin_pad);
-    if (((size_t)w2t & 15) != 0) return manet_set_error(MANET_E_INVALID, "w2t must be 16-byte aligned");
-    if ((long)h * w >= (1L << 31)) return manet_set_error(MANET_E_INVALID, "plane too large");
+    if (((size_t)w2t & 15) != 0 || ((size_t)dw_params & 15) != 0)
+        return manet_set_error(MANET_E_INVALID, "w2t and dw_params must be 16-byte aligned");
+    if ((long)h * w >= (1L << 30)) return manet_set_error(MANET_E_INVALID, "plane too large");
     SepConv A;
     A.in_a = in_a; A.in_b = in_b ? in_b : in_a; A.sa = (long)batch_stride_a; A.sb = (long)batch_stride_b;
     A.Ca = Ca; A.Cin = Cin; A.nchunks = nchunks; A.h = h; A.w = w;
-    A.dw_w = dw_weight; A.dw_b = dw_bias; A.s1 = bn1_scale; A.t1 = bn1_shift; A.relu_in = relu_in;
+    A.dwp = dw_params; A.relu_in = relu_in;
     A.w2t = w2t; A.b2 = b2; A.relu_out = relu_out; A.out = out;
     dim3 grid((unsigned)((w + SC_TX - 1) / SC_TX), (unsigned)((h + SC_TY - 1) / SC_TY), (unsigned)B);
     hipLaunchKernelGGL(sepconv7x7_pw_kernel, grid, dim3(SC_NT), 0, (hipStream_t)stream, A);

@@ -237,6 +237,7 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
                    "w2_shared": w2[:, :cs].contiguous(), "w2_object": w2[:, cs:].contiguous()}
             if self._fused_block():  # the one-launch form (ops.sepconv7x7_pw): 1x1 weight transposed, Cin padded to 16
                 val["w2t"], _ = ops.fold_pointwise(self.conv2, self.bn2)
+                val["dwp"] = ops.pack_depthwise(self.conv1.weight, self.conv1.bias, scale1, shift1)
         object.__setattr__(self, "_fold_cache", (key, val))  # plain attribute: not a buffer, not in the state dict
         return val
 
@@ -252,8 +253,7 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         if self._fast(x):
             k = self._folded()
             if self._fused_block():
-                return ops.sepconv7x7_pw(x, self.conv1.weight, self.conv1.bias, k["scale1"], k["shift1"], k["w2t"], k["b2"],
-                                         relu_in=relu_in, relu_out=not defer_relu)
+                return ops.sepconv7x7_pw(x, k["dwp"], k["w2t"], k["b2"], relu_in=relu_in, relu_out=not defer_relu)
             x = ops.dwconv7x7_bn_relu(x, self.conv1.weight, self.conv1.bias, scale=k["scale1"], shift=k["shift1"],
                                       relu_in=relu_in)
             y = F.conv2d(x, k["w2"], k["b2"])
@@ -271,8 +271,7 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         cs = shared.shape[1]
         k = self._folded(cs)
         if self._fused_block():  # one launch: the shared channels are read with batch stride 0, no repeat / cat
-            return ops.sepconv7x7_pw(per_object, self.conv1.weight, self.conv1.bias, k["scale1"], k["shift1"], k["w2t"],
-                                     k["b2"], relu_out=not defer_relu, shared=shared)
+            return ops.sepconv7x7_pw(per_object, k["dwp"], k["w2t"], k["b2"], relu_out=not defer_relu, shared=shared)
         scale, shift = k["scale1"], k["shift1"]
         w1, b1 = self.conv1.weight, self.conv1.bias
         s1 = ops.dwconv7x7_bn_relu(shared, w1[:cs], b1[:cs], scale=scale[:cs], shift=shift[:cs])

@@ -556,13 +556,29 @@ def fold_pointwise(conv2, bn2):
     return w2t.contiguous(), b2.contiguous()
 
 
-def sepconv7x7_pw(x, dw_weight, dw_bias, scale1, shift1, w2t, b2, relu_in=False, relu_out=False, shared=None):
+def pack_depthwise(dw_weight, dw_bias, scale1, shift1):
+    """dw_params for sepconv7x7_pw: [Cin_pad, 52] = per input channel the 49 taps, the depthwise bias, bn1 scale and bn1
+    shift (Cin padded to a multiple of 16)."""
+    cin = dw_weight.shape[0]
+    pad = (cin + 15) // 16 * 16
+    t = torch.zeros((pad, 52), dtype=torch.float32, device=dw_weight.device)
+    t[:cin, :49] = dw_weight.detach().float().reshape(cin, 49)
+    if dw_bias is not None:
+        t[:cin, 49] = dw_bias.detach().float()
+    t[:cin, 50] = 1.0 if scale1 is None else scale1.detach().float()
+    if shift1 is not None:
+        t[:cin, 51] = shift1.detach().float()
+    return t.contiguous()
+
+
+def sepconv7x7_pw(x, dw_params, w2t, b2, relu_in=False, relu_out=False, shared=None):
     """One _split_separable_conv2d block (IntVOS.py:488-506) in one launch: relu(bn1(dwconv7x7)) feeding an fp32-MFMA 1x1
     contraction with bn2 folded in; the activation between the two never leaves the compute unit.
     x [B, Cx, h, w] fp32; shared: optional [1, Cs, h, w] whose channels come FIRST and are the same for every batch item
-    (layer 1: the embedding, IntVOS.py:665-670) -- the repeat / cat is not built.  dw_weight [Cs+Cx, 1, 7, 7] etc. cover the
-    concatenated channels.  Returns [B, 256, h, w]; relu_out=False leaves relu2 to the next block's relu_in."""
-    _refuse_autograd("sepconv7x7_pw", x, shared, dw_weight, dw_bias, scale1, shift1, w2t, b2)
+    (layer 1: the embedding, IntVOS.py:665-670) -- the repeat / cat is not built.  dw_params (pack_depthwise) and w2t / b2
+    (fold_pointwise) cover the concatenated channels.  Returns [B, 256, h, w]; relu_out=False leaves relu2 to the next
+    block's relu_in."""
+    _refuse_autograd("sepconv7x7_pw", x, shared, dw_params, w2t, b2)
     lib = _lib.load()
     _need_gpu(x, "x")
     x = x.float().contiguous()
@@ -577,20 +593,18 @@ def sepconv7x7_pw(x, dw_weight, dw_bias, scale1, shift1, w2t, b2, relu_in=False,
     else:
         in_a, sa, Ca, in_b, sb, Cb = x, Cx * h * w, Cx, None, 0, 0
     cin = Ca + Cb
-    if dw_weight.numel() != cin * 49:
-        raise ValueError("dw_weight must be [%d, 1, 7, 7]" % cin)
-    if w2t.shape[0] != (cin + 15) // 16 * 16 or w2t.shape[1] != SEPCONV_COUT or b2.numel() != SEPCONV_COUT:
-        raise ValueError("w2t must be [%d, %d] (ops.fold_pointwise), b2 [%d]" % ((cin + 15) // 16 * 16, SEPCONV_COUT,
-                                                                             SEPCONV_COUT))
-    f = lambda t: None if t is None else t.detach().float().contiguous()
-    dw_weight, dw_bias, scale1, shift1, w2t, b2 = f(dw_weight), f(dw_bias), f(scale1), f(shift1), f(w2t), f(b2)
+    pad = (cin + 15) // 16 * 16
+    if tuple(dw_params.shape) != (pad, 52):
+        raise ValueError("dw_params must be [%d, 52] (ops.pack_depthwise)" % pad)
+    if w2t.shape[0] != pad or w2t.shape[1] != SEPCONV_COUT or b2.numel() != SEPCONV_COUT:
+        raise ValueError("w2t must be [%d, %d] (ops.fold_pointwise), b2 [%d]" % (pad, SEPCONV_COUT, SEPCONV_COUT))
+    f = lambda t: t.detach().float().contiguous()
+    dw_params, w2t, b2 = f(dw_params), f(w2t), f(b2)
     out = torch.empty((B, SEPCONV_COUT, h, w), dtype=torch.float32, device=x.device)
-    p = lambda t: None if t is None else t.data_ptr()
     with torch.cuda.device(x.device):
-        rc = lib.manet_sepconv7x7_pw_f32(in_a.data_ptr(), sa, Ca, p(in_b), sb, Cb, B, h, w, dw_weight.data_ptr(), p(dw_bias),
-                                         p(scale1), p(shift1), int(bool(relu_in)), w2t.data_ptr(), w2t.shape[0],
-                                         b2.data_ptr(), SEPCONV_COUT, int(bool(relu_out)), out.data_ptr(),
-                                         _stream_ptr(x.device))
+        rc = lib.manet_sepconv7x7_pw_f32(in_a.data_ptr(), sa, Ca, None if in_b is None else in_b.data_ptr(), sb, Cb, B, h, w,
+                                         dw_params.data_ptr(), int(bool(relu_in)), w2t.data_ptr(), pad, b2.data_ptr(),
+                                         SEPCONV_COUT, int(bool(relu_out)), out.data_ptr(), _stream_ptr(x.device))
     _lib.check(rc, "manet_sepconv7x7_pw_f32")
     return out
 

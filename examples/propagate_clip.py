@@ -52,12 +52,21 @@ def main():
     ap.add_argument("--fused-mask-step", action="store_true",
                     help="use ops.upsample_argmax instead of F.interpolate + argmax (test.py:253-255)")
     ap.add_argument("--graph", action="store_true", help="capture a propagated frame in a HIP graph and replay it")
+    ap.add_argument("--unfused-head", action="store_true",
+                    help="A/B: DynamicSegHead blocks as r2's depthwise kernel + framework GEMM instead of one fused launch")
+    ap.add_argument("--compute", type=str, default=None, help="arithmetic of the global match (f32 | bf16 | bf16x3 | bf16r)")
+    ap.add_argument("--emb-dtype", type=str, default=None, help="storage of the embeddings (f32 | bf16)")
+    ap.add_argument("--prepare-clip", action="store_true",
+                    help="prepare every frame's operands up front (model.prepare_clip) instead of on first use")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "needs the MI355X"
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     cfg = make_cfg(["--TEST_MODE", "True"])
-    model = IntVOS(cfg, StandInEncoder(cfg.MODEL_ASPP_OUTDIM)).to(dev).eval()
+    if args.unfused_head:
+        from cvpr2020_manet_amd.networks import IntVOS as _M
+        _M.FUSED_HEAD_BLOCKS = False
+    model = IntVOS(cfg, StandInEncoder(cfg.MODEL_ASPP_OUTDIM), compute=args.compute, emb_dtype=args.emb_dtype).to(dev).eval()
     F_, H, W, nobj = args.frames, args.height, args.width, args.objects
     seq = "synthetic"
 
@@ -71,6 +80,8 @@ def main():
     with torch.no_grad():
         imgs = torch.randn(F_, 3, H, W, device=dev)
         embedding_memory = torch.cat([model.extract_feature(imgs[i:i + 4]) for i in range(0, F_, 4)], 0)
+        if args.prepare_clip:
+            embedding_memory = model.prepare_clip(embedding_memory)
         _, _, eh, ew = embedding_memory.shape
         start = F_ // 2
         scribble = torch.full((1, 1, eh, ew), -1.0, device=dev)  # -1 = unlabelled

@@ -279,7 +279,8 @@ int manet_relu_conv1x1_c1_f32(const float *in, int B, int C, long HW, const floa
  *                  each with its own batch stride in elements -- stride 0 = one tensor shared by every batch item (layer 1:
  *                  the C-channel embedding next to the per-object maps, networks/IntVOS.py:665-670, no repeat / cat);
  *                  relu_in != 0: read through max(x, 0) (the preceding block's relu2, :503-505)
- *   dw_weight      [Ca+Cb][7][7], dw_bias / bn1_scale / bn1_shift [Ca+Cb] or NULL (0 / 1 / 0), as manet_dwconv7x7_bn_relu_*
+ *   dw_params      [Cin_pad][52] fp32, 16-byte aligned: per input channel the 49 taps [7][7], then the depthwise bias, bn1
+ *                  scale and bn1 shift (the arguments of manet_dwconv7x7_bn_relu_*, one padded row per channel)
  *   w2t            [Cin_pad][Cout] fp32, 16-byte aligned: the 1x1 weight TRANSPOSED with eval-mode bn2 folded in
  *                  (w2t[ci][co] = conv2.weight[co][ci] * bn2_scale[co]), rows Ca+Cb .. Cin_pad-1 zero, Cin_pad = Ca+Cb rounded
  *                  up to a multiple of 16;  b2 [Cout] = conv2.bias * bn2_scale + bn2_shift;  Cout must be 256
@@ -287,8 +288,7 @@ int manet_relu_conv1x1_c1_f32(const float *in, int B, int C, long HW, const floa
  * The depthwise stage is bit-identical to manet_dwconv7x7_bn_relu_ex; the contraction is the ascending-channel fp32 fmaf
  * chain of v_mfma_f32_32x32x2_f32. */
 int manet_sepconv7x7_pw_f32(const float *in_a, int64_t batch_stride_a, int Ca, const float *in_b,
-                            int64_t batch_stride_b, int Cb, int B, int h, int w, const float *dw_weight,
-                            const float *dw_bias, const float *bn1_scale, const float *bn1_shift, int relu_in,
+                            int64_t batch_stride_b, int Cb, int B, int h, int w, const float *dw_params, int relu_in,
                             const float *w2t, int Cin_pad, const float *b2, int Cout, int relu_out, float *out,
                             manet_stream_t stream);
 

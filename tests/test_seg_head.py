@@ -166,13 +166,14 @@ def test_fused_block_one_launch_vs_literal_module():
             lit = blk.relu2(blk.bn2(blk.conv2(blk.relu1(blk.bn1(blk.conv1(x))))))
             scale1, shift1 = ops.fold_bn(blk.bn1)
             w2t, b2 = ops.fold_pointwise(blk.conv2, blk.bn2)
-            got = ops.sepconv7x7_pw(x, blk.conv1.weight, blk.conv1.bias, scale1, shift1, w2t, b2, relu_out=True)
+            dwp = ops.pack_depthwise(blk.conv1.weight, blk.conv1.bias, scale1, shift1)
+            got = ops.sepconv7x7_pw(x, dwp, w2t, b2, relu_out=True)
             torch.testing.assert_close(got, lit, rtol=2e-4, atol=2e-4)
             # deferred ReLU out, ReLU folded into the read
-            raw = ops.sepconv7x7_pw(x, blk.conv1.weight, blk.conv1.bias, scale1, shift1, w2t, b2, relu_out=False)
+            raw = ops.sepconv7x7_pw(x, dwp, w2t, b2, relu_out=False)
             assert torch.equal(torch.relu(raw), got)
-            a = ops.sepconv7x7_pw(x, blk.conv1.weight, blk.conv1.bias, scale1, shift1, w2t, b2, relu_in=True)
-            b_ = ops.sepconv7x7_pw(torch.relu(x), blk.conv1.weight, blk.conv1.bias, scale1, shift1, w2t, b2)
+            a = ops.sepconv7x7_pw(x, dwp, w2t, b2, relu_in=True)
+            b_ = ops.sepconv7x7_pw(torch.relu(x), dwp, w2t, b2)
             assert torch.equal(a, b_)
             # against the two-kernel path: same depthwise bits, the contraction in another summation order
             y = ops.dwconv7x7_bn_relu(x, blk.conv1.weight, blk.conv1.bias, scale=scale1, shift=shift1)
@@ -183,9 +184,9 @@ def test_fused_block_one_launch_vs_literal_module():
             if cin > 3:  # layer 1's two-source input: the first cin-3 channels shared by the batch
                 shared, per = x[:1, :cin - 3].contiguous(), x[:, cin - 3:].contiguous()
                 full = torch.cat((shared.repeat(B, 1, 1, 1), per), 1)
-                want = ops.sepconv7x7_pw(full, blk.conv1.weight, blk.conv1.bias, scale1, shift1, w2t, b2)
-                got2 = ops.sepconv7x7_pw(per, blk.conv1.weight, blk.conv1.bias, scale1, shift1, w2t, b2, shared=shared)
+                want = ops.sepconv7x7_pw(full, dwp, w2t, b2)
+                got2 = ops.sepconv7x7_pw(per, dwp, w2t, b2, shared=shared)
                 assert torch.equal(got2, want)
                 torch.testing.assert_close(blk.forward_shared(shared, per), blk(full), rtol=0, atol=0)
-    with pytest.raises(ValueError):
-        ops.sepconv7x7_pw(x, blk.conv1.weight, blk.conv1.bias, scale1, shift1, w2t[:16], b2)
+    with torch.no_grad(), pytest.raises(ValueError):
+        ops.sepconv7x7_pw(x, dwp, w2t[:16], b2)
