@@ -245,8 +245,9 @@ constexpr int SC_TY = 4, SC_TX = 16, SC_P = SC_TY * SC_TX, SC_KC = 16, SC_CO = 2
 constexpr int SC_IR = SC_TY + 2 * DW_R, SC_IC = SC_TX + 2 * DW_R;  // halo tile 10 x 22
 constexpr int SC_IW = 24, SC_ICH = SC_IR * SC_IW;                  // LDS row stride / floats per channel
 constexpr int SC_NMM = 4, SC_NDW = 4, SC_NT = 64 * (SC_NMM + SC_NDW);
-constexpr int SC_NLD = (SC_KC * SC_IR * SC_IC + 64 * SC_NDW - 1) / (64 * SC_NDW);  // staged elements per depthwise thread
-constexpr int SC_WROW = 52;  // floats per row of the padded depthwise parameter table: 49 taps, bias, bn1 scale, bn1 shift
+constexpr int SC_NLD = (SC_KC * SC_IR * SC_IC + 64 * SC_NMM - 1) / (64 * SC_NMM);  // staged elements per matrix-wave thread
+constexpr int SC_WROW = 64;  // floats per row of the padded depthwise parameter table: 49 taps, bias, bn1 scale, bn1 shift, 0..
+constexpr int SC_WPIECES = SC_KC * SC_CO / 256, SC_PPIECES = SC_KC * SC_WROW / 256;  // 1 KiB LDS-DMA pieces per chunk
 struct SepConv {
     const float *in_a, *in_b;
     long sa, sb;  // batch strides (elements); 0 = the same tensor for every batch item
@@ -259,9 +260,10 @@ struct SepConv {
 };
 __global__ __launch_bounds__(SC_NT) void sepconv7x7_pw_kernel(const SepConv A)
 {
-    __shared__ __attribute__((aligned(1024))) float wbuf[2][SC_KC * SC_CO];
-    __shared__ __attribute__((aligned(16))) float inbuf[2][SC_KC * SC_ICH];
-    __shared__ __attribute__((aligned(16))) float dbuf[2][SC_KC * SC_P];
+    __shared__ __attribute__((aligned(1024))) float wbuf[2][SC_KC * SC_CO];    // 1x1 weights of a chunk, [k][co]
+    __shared__ __attribute__((aligned(1024))) float pbuf[2][SC_KC * SC_WROW];  // depthwise parameters of a chunk
+    __shared__ __attribute__((aligned(16))) float inbuf[2][SC_KC * SC_ICH];    // halo tiles of a chunk's 16 channels
+    __shared__ __attribute__((aligned(16))) float dbuf[2][SC_KC * SC_P];       // y of a chunk, [k][pixel]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool mm = wave < SC_NMM;
@@ -269,15 +271,15 @@ __global__ __launch_bounds__(SC_NT) void sepconv7x7_pw_kernel(const SepConv A)
     const int h = A.h, w = A.w, n = A.nchunks;
     const long plane = (long)h * w;
 
-    // ---- depthwise waves: staging of a chunk's halo tile.  A thread's SC_NLD elements keep their place for the whole
-    // kernel: pixel offset, validity and LDS slot are computed once, a chunk only moves the channel base.
-    const int t_dw = tid - 64 * SC_NMM;
-    int s_pix[SC_NLD], s_lds[SC_NLD];  // s_lds < 0: no element; bit 30 of s_pix clear + s_ok: inside the image
+    // ---- matrix waves, side job: staging of the halo tiles (their VALU is idle between MFMAs).  A thread's SC_NLD elements
+    // keep their place for the whole kernel: pixel offset, validity and LDS slot are computed once, a chunk only moves the
+    // channel base.
+    int s_pix[SC_NLD], s_lds[SC_NLD];  // s_lds: LDS slot | channel << 20, < 0: no element
     unsigned s_ok = 0;
-    if (!mm) {
+    if (mm) {
 #pragma unroll
         for (int j = 0; j < SC_NLD; ++j) {
-            const int e = t_dw + 64 * SC_NDW * j;
+            const int e = tid + 64 * SC_NMM * j;
             const int ch = e / (SC_IR * SC_IC), rem = e - ch * (SC_IR * SC_IC);
             const int r = rem / SC_IC, col = rem - r * SC_IC;
             const int y = y0 - DW_R + r, x = x0 - DW_R + col;
@@ -288,67 +290,40 @@ __global__ __launch_bounds__(SC_NT) void sepconv7x7_pw_kernel(const SepConv A)
         }
     }
     float stg[SC_NLD];
+    auto stage_load1 = [&](int c, int j) __attribute__((always_inline)) {
+        const int ch = (s_lds[j] >> 20) & 15;
+        const int ci = c * SC_KC + ch;
+        const int cc = ci < A.Cin ? ci : A.Cin - 1;
+        const float *src = cc < A.Ca ? A.in_a + (long)b * A.sa + (long)cc * plane
+                                     : A.in_b + (long)b * A.sb + (long)(cc - A.Ca) * plane;
+        float v = src[(unsigned)s_pix[j]];  // unconditional load, selected afterwards
+        v = (((s_ok >> j) & 1u) && ci < A.Cin) ? v : 0.0f;
+        stg[j] = A.relu_in ? fmaxf(v, 0.0f) : v;
+    };
     auto stage_load = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < SC_NLD; ++j) {
-            const int ch = (s_lds[j] >> 20) & 15;
-            const int ci = c * SC_KC + ch;
-            const int cc = ci < A.Cin ? ci : A.Cin - 1;
-            const float *src = cc < A.Ca ? A.in_a + (long)b * A.sa + (long)cc * plane
-                                         : A.in_b + (long)b * A.sb + (long)(cc - A.Ca) * plane;
-            float v = src[(unsigned)s_pix[j]];  // unconditional load, selected afterwards
-            v = (((s_ok >> j) & 1u) && ci < A.Cin) ? v : 0.0f;
-            stg[j] = A.relu_in ? fmaxf(v, 0.0f) : v;
-        }
+        for (int j = 0; j < SC_NLD; ++j) stage_load1(c, j);
     };
     auto stage_store = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < SC_NLD; ++j)
             if (s_lds[j] >= 0) inbuf[buf][s_lds[j] & 0xfffff] = stg[j];
     };
-    // lane -> (channel of the wave's four, row, group of 4 columns)
-    const int chl = lane >> 4, py = (lane >> 2) & 3, pxg = (lane & 3) * 4;
-    const int ch_dw = (wave - SC_NMM) * 4 + chl;  // channel inside the chunk (waves 4-7)
-    f32x4 wq[SC_WROW / 4];                        // this lane's channel: 49 taps, bias, scale, shift
-    auto w_load = [&](int c) __attribute__((always_inline)) {
-        const float *src = A.dwp + (long)(c * SC_KC + ch_dw) * SC_WROW;
-#pragma unroll
-        for (int i = 0; i < SC_WROW / 4; ++i) wq[i] = *(const f32x4 *)(src + 4 * i);
-    };
-    auto dw_compute = [&](int bin, int bd) __attribute__((always_inline)) {
-        const float *src = &inbuf[bin][ch_dw * SC_ICH + py * SC_IW + pxg];
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int ky = 0; ky < DW_K; ++ky) {
-            // (ties this row's reads behind the previous row's arithmetic: the unrolled loop otherwise keeps 70 window
-            // registers in flight)
-            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
-            const f32x4 u0 = *(const f32x4 *)(src + ky * SC_IW), u1 = *(const f32x4 *)(src + ky * SC_IW + 4);
-            const f32x2 u2 = *(const f32x2 *)(src + ky * SC_IW + 8);
-            const float v[10] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3], u2[0], u2[1]};
-#pragma unroll
-            for (int kx = 0; kx < DW_K; ++kx) {
-                const int t = ky * DW_K + kx;
-                const float wt = wq[t >> 2][t & 3];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) acc[p] = fmaf(v[kx + p], wt, acc[p]);
-            }
-        }
-        const float bc = wq[12][1], sc = wq[12][2], sh = wq[12][3];
-        f32x4 o;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) o[p] = fmaxf(fmaf(acc[p] + bc, sc, sh), 0.0f);
-        *(f32x4 *)&dbuf[bd][ch_dw * SC_P + py * SC_TX + pxg] = o;
-    };
-    // ---- matrix waves
+    // the chunk's 1x1 weights [16][256] and depthwise parameters [16][64] by LDS-DMA
     const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&wbuf[0][0]);
+    const unsigned pbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&pbuf[0][0]);
     auto w_dma = [&](int c, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < (SC_KC * SC_CO / 256) / SC_NMM; ++i) {
-            const int pc = wave * ((SC_KC * SC_CO / 256) / SC_NMM) + i;  // 1 KiB piece of the chunk's [16][256] slice
+        for (int i = 0; i < SC_WPIECES / SC_NMM; ++i) {
+            const int pc = wave * (SC_WPIECES / SC_NMM) + i;
             lds_dma16(A.w2t + (long)c * (SC_KC * SC_CO) + pc * 256 + lane * 4,
                       wbase + (unsigned)buf * (unsigned)(SC_KC * SC_CO * 4) + (unsigned)pc * 1024u);
         }
+    };
+    auto p_dma = [&](int c, int buf) __attribute__((always_inline)) {
+        static_assert(SC_PPIECES == SC_NMM, "one parameter piece per matrix wave");
+        lds_dma16(A.dwp + (long)c * (SC_KC * SC_WROW) + wave * 256 + lane * 4,
+                  pbase + (unsigned)buf * (unsigned)(SC_KC * SC_WROW * 4) + (unsigned)wave * 1024u);
     };
     f32x16 acc[2][2];
 #pragma unroll
@@ -358,7 +333,8 @@ __global__ __launch_bounds__(SC_NT) void sepconv7x7_pw_kernel(const SepConv A)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const int co0 = wave * 64;
-    auto mma = [&](int buf) __attribute__((always_inline)) {
+    // 8 k-steps x 4 MFMAs on chunk `buf`; between the k-steps the staging loads of chunk `cs` (if >= 0) are issued
+    auto mma = [&](int buf, int cs) __attribute__((always_inline)) {
         const float *Wt = &wbuf[buf][(lane >> 5) * SC_CO + co0 + (lane & 31)];
         const float *D = &dbuf[buf][(lane >> 5) * SC_P + (lane & 31)];
 #pragma unroll
@@ -369,40 +345,75 @@ __global__ __launch_bounds__(SC_NT) void sepconv7x7_pw_kernel(const SepConv A)
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if (cs >= 0) {
+#pragma unroll
+                for (int j = 2 * kk; j < 2 * kk + 2; ++j)
+                    if (j < SC_NLD) stage_load1(cs, j);
+            }
         }
     };
 
-    // ---- prologue: chunk 0's tile and weights; then y of chunk 0 while chunk 1 is staged
+    // ---- depthwise waves: lane -> (channel of the wave's four, row, group of 4 columns)
+    const int chl = lane >> 4, py = (lane >> 2) & 3, pxg = (lane & 3) * 4;
+    const int ch_dw = (wave - SC_NMM) * 4 + chl;  // channel inside the chunk (waves 4-7)
+    auto dw_compute = [&](int buf) __attribute__((always_inline)) {
+        const float *src = &inbuf[buf][ch_dw * SC_ICH + py * SC_IW + pxg];
+        const float *wr = &pbuf[buf][ch_dw * SC_WROW];  // the 16 lanes of a channel read the same words: broadcast
+        float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ky = 0; ky < DW_K; ++ky) {
+            // (ties this row's reads behind the previous row's arithmetic: the unrolled loop otherwise keeps 70 window
+            // registers in flight)
+            asm volatile("" : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3]));
+            const f32x4 u0 = *(const f32x4 *)(src + ky * SC_IW), u1 = *(const f32x4 *)(src + ky * SC_IW + 4);
+            const f32x2 u2 = *(const f32x2 *)(src + ky * SC_IW + 8);
+            const float v[10] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3], u2[0], u2[1]};
+#pragma unroll
+            for (int kx = 0; kx < DW_K; ++kx) {
+                const float wt = wr[ky * DW_K + kx];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) a4[p] = fmaf(v[kx + p], wt, a4[p]);
+            }
+        }
+        const float bc = wr[49], sc = wr[50], sh = wr[51];
+        f32x4 o;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o[p] = fmaxf(fmaf(a4[p] + bc, sc, sh), 0.0f);
+        *(f32x4 *)&dbuf[buf][ch_dw * SC_P + py * SC_TX + pxg] = o;
+    };
+
+    // ---- schedule.  Iteration c: the matrix waves multiply chunk c (wbuf / dbuf [c & 1]) while the depthwise waves
+    // produce y of chunk c + 1 (inbuf / pbuf [(c + 1) & 1] -> dbuf [(c + 1) & 1]); under their MFMAs the matrix waves fetch
+    // what the NEXT iterations need into the buffers the previous iteration released: the 1x1 weights of chunk c + 1
+    // (wbuf [(c + 1) & 1], last read in iteration c - 1), the depthwise parameters and the halo tile of chunk c + 2
+    // (pbuf / inbuf [c & 1], last read in iteration c - 1).  One barrier per iteration.
     if (mm) {
         w_dma(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        w_load(0);
+        p_dma(0, 0);
+        if (n > 1) p_dma(1, 1);
         stage_load(0);
         stage_store(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (!mm) {
-        if (n > 1) stage_load(1);
-        dw_compute(0, 0);
+    if (mm) {
         if (n > 1) {
-            w_load(1);
+            stage_load(1);
             stage_store(1);
         }
+    } else {
+        dw_compute(0);
     }
     __syncthreads();
     for (int c = 0; c < n; ++c) {
         if (mm) {
             if (c + 1 < n) w_dma(c + 1, (c + 1) & 1);
-            mma(c & 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if (c + 2 < n) stage_load(c + 2);
-            if (c + 1 < n) dw_compute((c + 1) & 1, (c + 1) & 1);  // with the parameters loaded one iteration ago
-            if (c + 2 < n) {
-                w_load(c + 2);  // lands under the next barrier and the next iteration's staging loads
-                stage_store(c & 1);
-            }
+            if (c + 2 < n) p_dma(c + 2, c & 1);
+            mma(c & 1, c + 2 < n ? c + 2 : -1);
+            if (c + 2 < n) stage_store(c & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+        } else if (c + 1 < n) {
+            dw_compute((c + 1) & 1);
         }
         __syncthreads();
     }
@@ -464,7 +475,7 @@ extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, 
 }
 
 // One _split_separable_conv2d block in one launch (sepconv7x7_pw_kernel); out channels fixed at 256 (the reference's
-// MODEL_HEAD_EMBEDDING_DIM, config.py:48).  dw_params: [Cin_pad][52] = per input channel the 49 taps, the depthwise bias,
+// MODEL_HEAD_EMBEDDING_DIM, config.py:48).  dw_params: [Cin_pad][64] = per input channel the 49 taps, the depthwise bias,
 // bn1 scale and bn1 shift (rows beyond Cin: anything).
 extern "C" int manet_sepconv7x7_pw_f32(const float *in_a, int64_t batch_stride_a, int Ca, const float *in_b,
                                        int64_t batch_stride_b, int Cb, int B, int h, int w, const float *dw_params,

@@ -557,11 +557,11 @@ def fold_pointwise(conv2, bn2):
 
 
 def pack_depthwise(dw_weight, dw_bias, scale1, shift1):
-    """dw_params for sepconv7x7_pw: [Cin_pad, 52] = per input channel the 49 taps, the depthwise bias, bn1 scale and bn1
-    shift (Cin padded to a multiple of 16)."""
+    """dw_params for sepconv7x7_pw: [Cin_pad, 64] = per input channel the 49 taps, the depthwise bias, bn1 scale and bn1
+    shift, zero padding (Cin padded to a multiple of 16; 16 rows = the 4 KiB a chunk's LDS-DMA moves)."""
     cin = dw_weight.shape[0]
     pad = (cin + 15) // 16 * 16
-    t = torch.zeros((pad, 52), dtype=torch.float32, device=dw_weight.device)
+    t = torch.zeros((pad, 64), dtype=torch.float32, device=dw_weight.device)
     t[:cin, :49] = dw_weight.detach().float().reshape(cin, 49)
     if dw_bias is not None:
         t[:cin, 49] = dw_bias.detach().float()
@@ -594,8 +594,8 @@ def sepconv7x7_pw(x, dw_params, w2t, b2, relu_in=False, relu_out=False, shared=N
         in_a, sa, Ca, in_b, sb, Cb = x, Cx * h * w, Cx, None, 0, 0
     cin = Ca + Cb
     pad = (cin + 15) // 16 * 16
-    if tuple(dw_params.shape) != (pad, 52):
-        raise ValueError("dw_params must be [%d, 52] (ops.pack_depthwise)" % pad)
+    if tuple(dw_params.shape) != (pad, 64):
+        raise ValueError("dw_params must be [%d, 64] (ops.pack_depthwise)" % pad)
     if w2t.shape[0] != pad or w2t.shape[1] != SEPCONV_COUT or b2.numel() != SEPCONV_COUT:
         raise ValueError("w2t must be [%d, %d] (ops.fold_pointwise), b2 [%d]" % (pad, SEPCONV_COUT, SEPCONV_COUT))
     f = lambda t: t.detach().float().contiguous()

@@ -279,8 +279,8 @@ int manet_relu_conv1x1_c1_f32(const float *in, int B, int C, long HW, const floa
  *                  each with its own batch stride in elements -- stride 0 = one tensor shared by every batch item (layer 1:
  *                  the C-channel embedding next to the per-object maps, networks/IntVOS.py:665-670, no repeat / cat);
  *                  relu_in != 0: read through max(x, 0) (the preceding block's relu2, :503-505)
- *   dw_params      [Cin_pad][52] fp32, 16-byte aligned: per input channel the 49 taps [7][7], then the depthwise bias, bn1
- *                  scale and bn1 shift (the arguments of manet_dwconv7x7_bn_relu_*, one padded row per channel)
+ *   dw_params      [Cin_pad][64] fp32, 16-byte aligned: per input channel the 49 taps [7][7], then the depthwise bias, bn1
+ *                  scale and bn1 shift, then zeros (the arguments of manet_dwconv7x7_bn_relu_*, one padded row per channel)
  *   w2t            [Cin_pad][Cout] fp32, 16-byte aligned: the 1x1 weight TRANSPOSED with eval-mode bn2 folded in
  *                  (w2t[ci][co] = conv2.weight[co][ci] * bn2_scale[co]), rows Ca+Cb .. Cin_pad-1 zero, Cin_pad = Ca+Cb rounded
  *                  up to a multiple of 16;  b2 [Cout] = conv2.bias * bn2_scale + bn2_shift;  Cout must be 256
