@@ -64,7 +64,7 @@ SIGNATURES = {
     "manet_local_match_backward_workspace_bytes": (_i, [_i, _i, _i, _i, _szp]),
     "manet_local_match_backward_f32": (_i, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i, _i, _i,
                                             _i, _i, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _sz, _vp]),
-    "manet_sepconv7x7_pw_f32": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "manet_conv1x1_f32": (_i, [_vp, _i64, _i, _i, _i64, _vp, _vp, _i, _i, _vp, _vp]),
     "manet_frame_workspace_bytes": (_i, [_i, _i, _i, _i, _i, _szp]),
     "manet_frame_prepare": (_i, [_vp, _i, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i64,
                                  ctypes.c_uint32, _vp]),

@@ -220,110 +220,50 @@ __global__ __launch_bounds__(64 * RC_WAVES) void relu_conv1x1_c1_kernel(const fl
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// One whole _split_separable_conv2d (IntVOS.py:488-506) in ONE launch (VERDICT r2 "next" #3):
-//     y = relu(bn1(dwconv7x7(x)))          -- per channel, VALU
-//     z = bn2(conv1x1(y)) [, relu]         -- a [256 x Cin] x [Cin x pixels] contraction, fp32 MFMA (exact fp32 chain)
-// r2 ran them as two kernels with the [B,256,h,w] activation y (79 MB at 3 objects, 480p) written and re-read in between
-// and the contraction in the framework's GEMM: 60 + 108 us per block, 45 % of an end-to-end frame.  Here y never leaves
-// the CU: a workgroup owns a 4 x 16 pixel tile of one batch item and ALL 256 output channels, and is split by role --
-//   waves 0-3  matrix waves: 64 output channels x 64 pixels each (2 x 2 blocks of v_mfma_f32_32x32x2_f32, 64 accumulator
-//              VGPRs); per chunk of 16 input channels 8 k-steps x 4 MFMAs with A = folded 1x1 weights and B = y, both read
-//              from LDS as one dword per lane (conflict-free);
-//   waves 4-7  depthwise waves: per chunk each wave computes 4 channels x 64 pixels, a lane owns 4 neighbouring pixels of
-//              one channel: per kernel row three LDS reads (10 window floats) feed 28 fmaf whose tap weights sit in the
-//              lane's registers (the channel's 49 taps + bias + bn1 scale / shift, one padded 52-float row, prefetched a
-//              chunk ahead); tap order (ky outer, kx inner) and bn1 expression of dwconv7x7_bn_relu_kernel, so y is
-//              bit-identical to the two-kernel path.  They also stage the NEXT chunks' halo tiles (global -> registers ->
-//              LDS, zero padding and the preceding block's deferred ReLU applied on the way);
-// so the matrix pipe and the vector pipe of every SIMD run side by side (MI355X_MICROARCH.md: an MFMA-only and a
-// VALU-only wave on one SIMD overlap), one barrier per chunk; per chunk the matrix waves need 32 x 64 = 2 048 cycles, the
-// depthwise waves ~450 VALU / LDS instructions -- about the same time: both pipes are busy.  The 1x1 weights arrive by
-// LDS-DMA from a pre-transposed [Cin_pad][256] copy (bn2 folded in), double buffered.  The input may come from TWO tensors
-// (channels [0, Ca) from `in_a`, the rest from `in_b`, each with its own batch stride): layer 1 reads the C-channel
-// embedding with batch stride 0 next to the per-object maps, i.e. IntVOS.py:665-670's repeat / cat is never built.
-constexpr int SC_TY = 4, SC_TX = 16, SC_P = SC_TY * SC_TX, SC_KC = 16, SC_CO = 256;
-constexpr int SC_IR = SC_TY + 2 * DW_R, SC_IC = SC_TX + 2 * DW_R;  // halo tile 10 x 22
-constexpr int SC_IW = 24, SC_ICH = SC_IR * SC_IW;                  // LDS row stride / floats per channel
-constexpr int SC_NMM = 4, SC_NDW = 4, SC_NT = 64 * (SC_NMM + SC_NDW);
-constexpr int SC_NLD = (SC_KC * SC_IR * SC_IC + 64 * SC_NMM - 1) / (64 * SC_NMM);  // staged elements per matrix-wave thread
-constexpr int SC_WROW = 64;  // floats per row of the padded depthwise parameter table: 49 taps, bias, bn1 scale, bn1 shift, 0..
-constexpr int SC_WPIECES = SC_KC * SC_CO / 256, SC_PPIECES = SC_KC * SC_WROW / 256;  // 1 KiB LDS-DMA pieces per chunk
-struct SepConv {
-    const float *in_a, *in_b;
-    long sa, sb;  // batch strides (elements); 0 = the same tensor for every batch item
-    int Ca, Cin, nchunks, h, w;
-    const float *dwp;  // [Cin_pad][SC_WROW]
-    int relu_in;
-    const float *w2t, *b2;
-    int relu_out;
-    float *out;
-};
-__global__ __launch_bounds__(SC_NT) void sepconv7x7_pw_kernel(const SepConv A)
+// The 1x1 convolution of a _split_separable_conv2d (IntVOS.py:494,503-505: conv2 -> bn2 [-> relu2]) as an fp32-MFMA
+// contraction (VERDICT r2 "next" #3: r2 left it to the framework's GEMM -- 108 us of kernel + layout transposes per block
+// at [3,256,120,214], 45 % of an end-to-end frame):
+//     out[b][co][p] = b2[co] + sum_ci w2t[ci][co] * in[b][ci][p]          (bn2 folded into w2t / b2; optional ReLU)
+// v_mfma_f32_32x32x2_f32 is an exact fp32 fmaf chain in ascending ci.  A 1x1 convolution has no halo, so a tile is 64
+// CONSECUTIVE pixels of one batch item's flat [h*w] plane: every operand row is a contiguous 256-byte run and arrives by
+// LDS-DMA (no VGPR staging, no address arithmetic), every output store is 32 consecutive pixels = one full 128-byte line.
+//   workgroup = 4 waves = all 256 output channels x 64 pixels; a wave owns 64 channels (2 x 2 blocks, 64 accumulator VGPRs)
+//   chunk     = 16 input channels: in-slice [16][64] (4 KiB) + weight slice [16][256] (16 KiB), double buffered; per chunk a
+//               wave issues 5 DMA pieces and 8 k-steps x 4 MFMAs, both operands one dword per lane from LDS (conflict-free)
+//   40 KiB of LDS, ~100 VGPRs: four workgroups per CU, whose prologues / epilogues / barriers hide under each other's MFMAs
+// (the fused depthwise + 1x1 kernel built first in r3 -- depthwise waves feeding matrix waves through LDS, one 4 x 16-pixel
+// tile per workgroup -- was correct but 2-3x SLOWER than the two-kernel path: the 7x7 halo makes its input 3.4x the tile in
+// 88-byte row pieces, and with 95 KiB of LDS only one workgroup fits a CU, so every tile's prologue and epilogue -- 78 us of
+// a launch, measured -- ran exposed)
+constexpr int PW_P = 64, PW_KC = 16, PW_CO = 256, PW_NT = 256;
+__global__ __launch_bounds__(PW_NT, 4) void conv1x1_mfma_kernel(const float *__restrict__ in, long in_bs, int Cin, long HW,
+                                                                const float *__restrict__ w2t,
+                                                                const float *__restrict__ b2, int relu_out,
+                                                                float *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(1024))) float wbuf[2][SC_KC * SC_CO];    // 1x1 weights of a chunk, [k][co]
-    __shared__ __attribute__((aligned(1024))) float pbuf[2][SC_KC * SC_WROW];  // depthwise parameters of a chunk
-    __shared__ __attribute__((aligned(16))) float inbuf[2][SC_KC * SC_ICH];    // halo tiles of a chunk's 16 channels
-    __shared__ __attribute__((aligned(16))) float dbuf[2][SC_KC * SC_P];       // y of a chunk, [k][pixel]
+    __shared__ __attribute__((aligned(1024))) float wbuf[2][PW_KC * PW_CO];
+    __shared__ __attribute__((aligned(1024))) float xbuf[2][PW_KC * PW_P];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool mm = wave < SC_NMM;
-    const int x0 = blockIdx.x * SC_TX, y0 = blockIdx.y * SC_TY, b = blockIdx.z;
-    const int h = A.h, w = A.w, n = A.nchunks;
-    const long plane = (long)h * w;
-
-    // ---- matrix waves, side job: staging of the halo tiles (their VALU is idle between MFMAs).  A thread's SC_NLD elements
-    // keep their place for the whole kernel: pixel offset, validity and LDS slot are computed once, a chunk only moves the
-    // channel base.
-    int s_pix[SC_NLD], s_lds[SC_NLD];  // s_lds: LDS slot | channel << 20, < 0: no element
-    unsigned s_ok = 0;
-    if (mm) {
-#pragma unroll
-        for (int j = 0; j < SC_NLD; ++j) {
-            const int e = tid + 64 * SC_NMM * j;
-            const int ch = e / (SC_IR * SC_IC), rem = e - ch * (SC_IR * SC_IC);
-            const int r = rem / SC_IC, col = rem - r * SC_IC;
-            const int y = y0 - DW_R + r, x = x0 - DW_R + col;
-            const bool have = e < SC_KC * SC_IR * SC_IC;
-            if (have && y >= 0 && y < h && x >= 0 && x < w) s_ok |= 1u << j;
-            s_pix[j] = min(max(y, 0), h - 1) * w + min(max(x, 0), w - 1);
-            s_lds[j] = have ? (ch * SC_ICH + r * SC_IW + col) | (ch << 20) : -1;
-        }
-    }
-    float stg[SC_NLD];
-    auto stage_load1 = [&](int c, int j) __attribute__((always_inline)) {
-        const int ch = (s_lds[j] >> 20) & 15;
-        const int ci = c * SC_KC + ch;
-        const int cc = ci < A.Cin ? ci : A.Cin - 1;
-        const float *src = cc < A.Ca ? A.in_a + (long)b * A.sa + (long)cc * plane
-                                     : A.in_b + (long)b * A.sb + (long)(cc - A.Ca) * plane;
-        float v = src[(unsigned)s_pix[j]];  // unconditional load, selected afterwards
-        v = (((s_ok >> j) & 1u) && ci < A.Cin) ? v : 0.0f;
-        stg[j] = A.relu_in ? fmaxf(v, 0.0f) : v;
-    };
-    auto stage_load = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < SC_NLD; ++j) stage_load1(c, j);
-    };
-    auto stage_store = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < SC_NLD; ++j)
-            if (s_lds[j] >= 0) inbuf[buf][s_lds[j] & 0xfffff] = stg[j];
-    };
-    // the chunk's 1x1 weights [16][256] and depthwise parameters [16][64] by LDS-DMA
+    const long p0 = (long)blockIdx.x * PW_P;
+    const int b = blockIdx.y;
+    const float *src = in + (long)b * in_bs;
+    const int n = (Cin + PW_KC - 1) / PW_KC;  // Cin % 4 == 0: the last chunk may hold 4, 8 or 12 channels
     const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&wbuf[0][0]);
-    const unsigned pbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&pbuf[0][0]);
-    auto w_dma = [&](int c, int buf) __attribute__((always_inline)) {
+    const unsigned xbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&xbuf[0][0]);
+    // in-slice piece of this wave: channels 4 wave .. 4 wave + 3 of the chunk, lane -> (channel lane / 16, pixels 4 (lane % 16) ..)
+    long pix = p0 + 4 * (lane & 15);
+    if (pix > HW - 4) pix = HW - 4;  // the plane's last tile: clamped columns are computed and never stored
+    auto dma = [&](int c, int buf) __attribute__((always_inline)) {
+        const int k0 = c * PW_KC, kn = (Cin - k0) < PW_KC ? (Cin - k0) : PW_KC;  // channels of this chunk (multiple of 4)
 #pragma unroll
-        for (int i = 0; i < SC_WPIECES / SC_NMM; ++i) {
-            const int pc = wave * (SC_WPIECES / SC_NMM) + i;
-            lds_dma16(A.w2t + (long)c * (SC_KC * SC_CO) + pc * 256 + lane * 4,
-                      wbase + (unsigned)buf * (unsigned)(SC_KC * SC_CO * 4) + (unsigned)pc * 1024u);
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 4 + i;  // weight row = 1 KiB piece
+            if (row < kn)
+                lds_dma16(w2t + (long)(k0 + row) * PW_CO + lane * 4, wbase + (unsigned)buf * (unsigned)(PW_KC * PW_CO * 4) + (unsigned)row * 1024u);
         }
-    };
-    auto p_dma = [&](int c, int buf) __attribute__((always_inline)) {
-        static_assert(SC_PPIECES == SC_NMM, "one parameter piece per matrix wave");
-        lds_dma16(A.dwp + (long)c * (SC_KC * SC_WROW) + wave * 256 + lane * 4,
-                  pbase + (unsigned)buf * (unsigned)(SC_KC * SC_WROW * 4) + (unsigned)wave * 1024u);
+        if (wave * 4 < kn)
+            lds_dma16(src + (long)(k0 + wave * 4 + (lane >> 4)) * HW + pix, xbase + (unsigned)buf * (unsigned)(PW_KC * PW_P * 4) + (unsigned)wave * 1024u);
     };
     f32x16 acc[2][2];
 #pragma unroll
@@ -333,106 +273,42 @@ __global__ __launch_bounds__(SC_NT) void sepconv7x7_pw_kernel(const SepConv A)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const int co0 = wave * 64;
-    // 8 k-steps x 4 MFMAs on chunk `buf`; between the k-steps the staging loads of chunk `cs` (if >= 0) are issued
-    auto mma = [&](int buf, int cs) __attribute__((always_inline)) {
-        const float *Wt = &wbuf[buf][(lane >> 5) * SC_CO + co0 + (lane & 31)];
-        const float *D = &dbuf[buf][(lane >> 5) * SC_P + (lane & 31)];
-#pragma unroll
-        for (int kk = 0; kk < SC_KC / 2; ++kk) {
-            const float a0 = Wt[2 * kk * SC_CO], a1 = Wt[2 * kk * SC_CO + 32];
-            const float b0 = D[2 * kk * SC_P], b1 = D[2 * kk * SC_P + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            if (cs >= 0) {
-#pragma unroll
-                for (int j = 2 * kk; j < 2 * kk + 2; ++j)
-                    if (j < SC_NLD) stage_load1(cs, j);
-            }
-        }
-    };
-
-    // ---- depthwise waves: lane -> (channel of the wave's four, row, group of 4 columns)
-    const int chl = lane >> 4, py = (lane >> 2) & 3, pxg = (lane & 3) * 4;
-    const int ch_dw = (wave - SC_NMM) * 4 + chl;  // channel inside the chunk (waves 4-7)
-    auto dw_compute = [&](int buf) __attribute__((always_inline)) {
-        const float *src = &inbuf[buf][ch_dw * SC_ICH + py * SC_IW + pxg];
-        const float *wr = &pbuf[buf][ch_dw * SC_WROW];  // the 16 lanes of a channel read the same words: broadcast
-        float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int ky = 0; ky < DW_K; ++ky) {
-            // (ties this row's reads behind the previous row's arithmetic: the unrolled loop otherwise keeps 70 window
-            // registers in flight)
-            asm volatile("" : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3]));
-            const f32x4 u0 = *(const f32x4 *)(src + ky * SC_IW), u1 = *(const f32x4 *)(src + ky * SC_IW + 4);
-            const f32x2 u2 = *(const f32x2 *)(src + ky * SC_IW + 8);
-            const float v[10] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3], u2[0], u2[1]};
-#pragma unroll
-            for (int kx = 0; kx < DW_K; ++kx) {
-                const float wt = wr[ky * DW_K + kx];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) a4[p] = fmaf(v[kx + p], wt, a4[p]);
-            }
-        }
-        const float bc = wr[49], sc = wr[50], sh = wr[51];
-        f32x4 o;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) o[p] = fmaxf(fmaf(a4[p] + bc, sc, sh), 0.0f);
-        *(f32x4 *)&dbuf[buf][ch_dw * SC_P + py * SC_TX + pxg] = o;
-    };
-
-    // ---- schedule.  Iteration c: the matrix waves multiply chunk c (wbuf / dbuf [c & 1]) while the depthwise waves
-    // produce y of chunk c + 1 (inbuf / pbuf [(c + 1) & 1] -> dbuf [(c + 1) & 1]); under their MFMAs the matrix waves fetch
-    // what the NEXT iterations need into the buffers the previous iteration released: the 1x1 weights of chunk c + 1
-    // (wbuf [(c + 1) & 1], last read in iteration c - 1), the depthwise parameters and the halo tile of chunk c + 2
-    // (pbuf / inbuf [c & 1], last read in iteration c - 1).  One barrier per iteration.
-    if (mm) {
-        w_dma(0, 0);
-        p_dma(0, 0);
-        if (n > 1) p_dma(1, 1);
-        stage_load(0);
-        stage_store(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    if (mm) {
-        if (n > 1) {
-            stage_load(1);
-            stage_store(1);
-        }
-    } else {
-        dw_compute(0);
-    }
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int c = 0; c < n; ++c) {
-        if (mm) {
-            if (c + 1 < n) w_dma(c + 1, (c + 1) & 1);
-            if (c + 2 < n) p_dma(c + 2, c & 1);
-            mma(c & 1, c + 2 < n ? c + 2 : -1);
-            if (c + 2 < n) stage_store(c & 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
-        } else if (c + 1 < n) {
-            dw_compute((c + 1) & 1);
+        if (c + 1 < n) dma(c + 1, (c + 1) & 1);  // (its buffer was last read in iteration c - 1: everyone is past that barrier)
+        const float *Wt = &wbuf[c & 1][(lane >> 5) * PW_CO + co0 + (lane & 31)];
+        const float *X = &xbuf[c & 1][(lane >> 5) * PW_P + (lane & 31)];
+        const int ksteps = ((Cin - c * PW_KC) < PW_KC ? (Cin - c * PW_KC) : PW_KC) / 2;
+#pragma unroll
+        for (int kk = 0; kk < PW_KC / 2; ++kk) {
+            if (kk < ksteps) {  // uniform
+                const float a0 = Wt[2 * kk * PW_CO], a1 = Wt[2 * kk * PW_CO + 32];
+                const float x0 = X[2 * kk * PW_P], x1 = X[2 * kk * PW_P + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x1, acc[1][1], 0, 0, 0);
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (!mm) return;
-    // ---- epilogue: + folded bias [, ReLU], store.  C/D layout: column = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2)
-    // + 4 (lane >> 5) (output channel)
+    // C/D layout: column = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (output channel)
+    float *dst = out + (long)b * PW_CO * HW;
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
-        const int p = pb * 32 + (lane & 31);
-        const int y = y0 + p / SC_TX, x = x0 + p % SC_TX;
-        if (y >= h || x >= w) continue;
+        const long p = p0 + pb * 32 + (lane & 31);
+        if (p >= HW) continue;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float v = acc[cb][pb][r] + A.b2[co];
-                if (A.relu_out) v = fmaxf(v, 0.0f);
-                A.out[((long)b * SC_CO + co) * plane + (unsigned)(y * w + x)] = v;
+                float v = acc[cb][pb][r] + b2[co];
+                if (relu_out) v = fmaxf(v, 0.0f);
+                dst[(long)co * HW + p] = v;
             }
     }
 }
@@ -474,32 +350,19 @@ extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, 
     return manet_check_launch("manet_dwconv7x7_bn_relu_f32");
 }
 
-// One _split_separable_conv2d block in one launch (sepconv7x7_pw_kernel); out channels fixed at 256 (the reference's
-// MODEL_HEAD_EMBEDDING_DIM, config.py:48).  dw_params: [Cin_pad][64] = per input channel the 49 taps, the depthwise bias,
-// bn1 scale and bn1 shift (rows beyond Cin: anything).
-extern "C" int manet_sepconv7x7_pw_f32(const float *in_a, int64_t batch_stride_a, int Ca, const float *in_b,
-                                       int64_t batch_stride_b, int Cb, int B, int h, int w, const float *dw_params,
-                                       int relu_in, const float *w2t, int Cin_pad, const float *b2, int Cout, int relu_out,
-                                       float *out, manet_stream_t stream)
+// 1x1 convolution with 256 output channels as an fp32-MFMA contraction (conv1x1_mfma_kernel)
+extern "C" int manet_conv1x1_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const float *w2t,
+                                 const float *b2, int Cout, int relu_out, float *out, manet_stream_t stream)
 {
-    const int Cin = Ca + Cb;
-    if (!in_a || Ca <= 0 || Cb < 0 || (Cb > 0 && !in_b) || !dw_params || !w2t || !b2 || !out || B <= 0 || B > 65535 ||
-        h <= 0 || w <= 0)
+    if (!in || !w2t || !b2 || !out || B <= 0 || B > 65535 || Cin <= 0 || HW <= 0)
         return manet_set_error(MANET_E_INVALID, "bad arguments");
-    if (Cout != SC_CO) return manet_set_error(MANET_E_INVALID, "Cout=%d (this kernel is built for %d output channels)", Cout, SC_CO);
-    const int nchunks = (Cin + SC_KC - 1) / SC_KC;
-    if (Cin_pad != nchunks * SC_KC)
-        return manet_set_error(MANET_E_INVALID, "w2t / dw_params must have %d rows (Cin padded to whole chunks of %d), got %d",
-                               nchunks * SC_KC, SC_KC, Cin_pad);
-    if (((size_t)w2t & 15) != 0 || ((size_t)dw_params & 15) != 0)
-        return manet_set_error(MANET_E_INVALID, "w2t and dw_params must be 16-byte aligned");
-    if ((long)h * w >= (1L << 30)) return manet_set_error(MANET_E_INVALID, "plane too large");
-    SepConv A;
-    A.in_a = in_a; A.in_b = in_b ? in_b : in_a; A.sa = (long)batch_stride_a; A.sb = (long)batch_stride_b;
-    A.Ca = Ca; A.Cin = Cin; A.nchunks = nchunks; A.h = h; A.w = w;
-    A.dwp = dw_params; A.relu_in = relu_in;
-    A.w2t = w2t; A.b2 = b2; A.relu_out = relu_out; A.out = out;
-    dim3 grid((unsigned)((w + SC_TX - 1) / SC_TX), (unsigned)((h + SC_TY - 1) / SC_TY), (unsigned)B);
-    hipLaunchKernelGGL(sepconv7x7_pw_kernel, grid, dim3(SC_NT), 0, (hipStream_t)stream, A);
-    return manet_check_launch("manet_sepconv7x7_pw_f32");
+    if (Cout != PW_CO) return manet_set_error(MANET_E_INVALID, "Cout=%d (this kernel is built for %d output channels)", Cout, PW_CO);
+    if (Cin % 4 != 0 || HW % 4 != 0 || HW < 4)
+        return manet_set_error(MANET_E_INVALID, "Cin=%d and HW=%lld must be multiples of 4 (16-byte LDS-DMA rows)", Cin, (long long)HW);
+    if (((size_t)w2t & 15) != 0 || ((size_t)in & 15) != 0 || (in_batch_stride & 3) != 0)
+        return manet_set_error(MANET_E_INVALID, "in / w2t must be 16-byte aligned, the batch stride a multiple of 4 elements");
+    dim3 grid((unsigned)((HW + PW_P - 1) / PW_P), (unsigned)B);
+    hipLaunchKernelGGL(conv1x1_mfma_kernel, grid, dim3(PW_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin, (long)HW,
+                       w2t, b2, relu_out, out);
+    return manet_check_launch("manet_conv1x1_f32");
 }

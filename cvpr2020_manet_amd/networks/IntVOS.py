@@ -42,9 +42,9 @@ WRONG_LABEL_PADDING_DISTANCE = 1e20
 # IntVOS(cfg, ...) re-binds it to the cfg it is given.
 cfg = _default_cfg
 
-# DynamicSegHead blocks as ONE fused launch each (ops.sepconv7x7_pw) when they have 256 output channels; False = r2's
-# depthwise kernel + framework GEMM (A/B switch for examples/propagate_clip.py --unfused-head)
-FUSED_HEAD_BLOCKS = True
+# the heads' 1x1 convolutions on the fp32-MFMA kernel (ops.conv1x1_mfma) when they have 256 output channels; False = the
+# framework's GEMM as in r2 (A/B switch: examples/propagate_clip.py --framework-gemm)
+MFMA_POINTWISE = True
 
 # arithmetic of the QK^T contraction used by the MODULE-LEVEL functions: "f32" (exact fp32 MFMA) | "bf16" | "bf16x3" |
 # "bf16r".  An IntVOS instance carries its own (constructor argument / cfg.MODEL_MATCH_COMPUTE).
@@ -235,16 +235,22 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
             b2 = (self.conv2.bias.detach().float() * scale2 + shift2 if self.conv2.bias is not None else shift2).contiguous()
             val = {"scale1": scale1.contiguous(), "shift1": shift1.contiguous(), "w2": w2, "b2": b2,
                    "w2_shared": w2[:, :cs].contiguous(), "w2_object": w2[:, cs:].contiguous()}
-            if self._fused_block():  # the one-launch form (ops.sepconv7x7_pw): 1x1 weight transposed, Cin padded to 16
-                val["w2t"], _ = ops.fold_pointwise(self.conv2, self.bn2)
-                val["dwp"] = ops.pack_depthwise(self.conv1.weight, self.conv1.bias, scale1, shift1)
+            if self.conv2.out_channels == ops.PW_COUT and MFMA_POINTWISE:  # ops.conv1x1_mfma: the weight transposed
+                w2t = w2.reshape(w2.shape[0], w2.shape[1]).t().contiguous()
+                val["w2t"], val["w2t_shared"], val["w2t_object"] = w2t, w2t[:cs].contiguous(), w2t[cs:].contiguous()
         object.__setattr__(self, "_fold_cache", (key, val))  # plain attribute: not a buffer, not in the state dict
         return val
 
-    def _fused_block(self):
-        """the whole block in one launch (depthwise waves feeding fp32-MFMA waves, ops.sepconv7x7_pw)"""
-        return (self.conv2.out_channels == ops.SEPCONV_COUT and self.conv2.kernel_size == (1, 1)
-                and self.conv1.kernel_size == (7, 7) and FUSED_HEAD_BLOCKS)
+    def _pointwise(self, y, k, which, bias, relu):
+        """bn2(conv2(y)) [+ relu2] on the depthwise stage's output: the fp32-MFMA 1x1 kernel when the shapes allow (256 output
+        channels, Cin and h*w multiples of 4), else the framework's convolution with the same folded weights"""
+        wkey = {"all": "w2t", "shared": "w2t_shared", "object": "w2t_object"}[which]
+        if wkey in k and ops.conv1x1_mfma_ok(y, self.conv2.out_channels):
+            b2 = k["b2"] if bias else k.setdefault("b2_zero", torch.zeros_like(k["b2"]))
+            return ops.conv1x1_mfma(y, k[wkey], b2, relu_out=relu)
+        w = {"all": "w2", "shared": "w2_shared", "object": "w2_object"}[which]
+        z = F.conv2d(y, k[w], k["b2"] if bias else None)
+        return z.relu_() if relu else z
 
     def forward(self, x, relu_in=False, defer_relu=False):
         """relu_in / defer_relu (inference fast path only, used by DynamicSegHead): the block's last ReLU is left to the
@@ -252,12 +258,9 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         activation less per block, same values."""
         if self._fast(x):
             k = self._folded()
-            if self._fused_block():
-                return ops.sepconv7x7_pw(x, k["dwp"], k["w2t"], k["b2"], relu_in=relu_in, relu_out=not defer_relu)
             x = ops.dwconv7x7_bn_relu(x, self.conv1.weight, self.conv1.bias, scale=k["scale1"], shift=k["shift1"],
                                       relu_in=relu_in)
-            y = F.conv2d(x, k["w2"], k["b2"])
-            return y if defer_relu else y.relu_()
+            return self._pointwise(x, k, "all", True, not defer_relu)
         assert not relu_in and not defer_relu
         x = self.relu1(self.bn1(self.conv1(x)))
         x = self.relu2(self.bn2(self.conv2(x)))
@@ -270,14 +273,12 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         shared [1, Cs, h, w], per_object [n, Cp, h, w], Cs + Cp == in_dim."""
         cs = shared.shape[1]
         k = self._folded(cs)
-        if self._fused_block():  # one launch: the shared channels are read with batch stride 0, no repeat / cat
-            return ops.sepconv7x7_pw(per_object, k["dwp"], k["w2t"], k["b2"], relu_out=not defer_relu, shared=shared)
         scale, shift = k["scale1"], k["shift1"]
         w1, b1 = self.conv1.weight, self.conv1.bias
         s1 = ops.dwconv7x7_bn_relu(shared, w1[:cs], b1[:cs], scale=scale[:cs], shift=shift[:cs])
         p1 = ops.dwconv7x7_bn_relu(per_object, w1[cs:], b1[cs:], scale=scale[cs:], shift=shift[cs:])
-        y = F.conv2d(p1, k["w2_object"], k["b2"])
-        y += F.conv2d(s1, k["w2_shared"])  # broadcast over the objects
+        y = self._pointwise(p1, k, "object", True, False)
+        y += self._pointwise(s1, k, "shared", False, False)  # broadcast over the objects
         return y if defer_relu else y.relu_()
 
 

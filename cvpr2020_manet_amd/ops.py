@@ -540,72 +540,42 @@ def dwconv7x7_bn_relu(x, weight, bias=None, bn=None, relu=True, scale=None, shif
     return out
 
 
-SEPCONV_COUT = 256  # output channels the fused block kernel is built for (the reference's MODEL_HEAD_EMBEDDING_DIM)
+PW_COUT = 256  # output channels the MFMA 1x1 kernel is built for (the reference's MODEL_HEAD_EMBEDDING_DIM, config.py:48)
 
 
 def fold_pointwise(conv2, bn2):
-    """(w2t, b2) for sepconv7x7_pw: conv2's [Cout, Cin, 1, 1] weight transposed to [Cin_pad, Cout] with eval-mode bn2
-    folded in (Cin padded with zero rows to a multiple of 16), and the folded bias [Cout]."""
+    """(w2t, b2) for conv1x1_mfma: conv2's [Cout, Cin, 1, 1] weight transposed to [Cin, Cout] with eval-mode bn2 folded
+    in, and the folded bias [Cout]."""
     scale2, shift2 = fold_bn(bn2)
     w = conv2.weight.detach().float().reshape(conv2.out_channels, conv2.in_channels) * scale2[:, None]
-    cin = conv2.in_channels
-    pad = (cin + 15) // 16 * 16
-    w2t = torch.zeros((pad, conv2.out_channels), dtype=torch.float32, device=w.device)
-    w2t[:cin] = w.t()
     b2 = (conv2.bias.detach().float() * scale2 + shift2) if conv2.bias is not None else shift2
-    return w2t.contiguous(), b2.contiguous()
+    return w.t().contiguous(), b2.contiguous()
 
 
-def pack_depthwise(dw_weight, dw_bias, scale1, shift1):
-    """dw_params for sepconv7x7_pw: [Cin_pad, 64] = per input channel the 49 taps, the depthwise bias, bn1 scale and bn1
-    shift, zero padding (Cin padded to a multiple of 16; 16 rows = the 4 KiB a chunk's LDS-DMA moves)."""
-    cin = dw_weight.shape[0]
-    pad = (cin + 15) // 16 * 16
-    t = torch.zeros((pad, 64), dtype=torch.float32, device=dw_weight.device)
-    t[:cin, :49] = dw_weight.detach().float().reshape(cin, 49)
-    if dw_bias is not None:
-        t[:cin, 49] = dw_bias.detach().float()
-    t[:cin, 50] = 1.0 if scale1 is None else scale1.detach().float()
-    if shift1 is not None:
-        t[:cin, 51] = shift1.detach().float()
-    return t.contiguous()
+def conv1x1_mfma_ok(x, cout):
+    """shapes the MFMA 1x1 kernel takes: 256 output channels, Cin and h*w multiples of 4 (16-byte LDS-DMA rows)"""
+    return (cout == PW_COUT and x.dim() == 4 and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0
+            and x.shape[2] * x.shape[3] >= 4)
 
 
-def sepconv7x7_pw(x, dw_params, w2t, b2, relu_in=False, relu_out=False, shared=None):
-    """One _split_separable_conv2d block (IntVOS.py:488-506) in one launch: relu(bn1(dwconv7x7)) feeding an fp32-MFMA 1x1
-    contraction with bn2 folded in; the activation between the two never leaves the compute unit.
-    x [B, Cx, h, w] fp32; shared: optional [1, Cs, h, w] whose channels come FIRST and are the same for every batch item
-    (layer 1: the embedding, IntVOS.py:665-670) -- the repeat / cat is not built.  dw_params (pack_depthwise) and w2t / b2
-    (fold_pointwise) cover the concatenated channels.  Returns [B, 256, h, w]; relu_out=False leaves relu2 to the next
-    block's relu_in."""
-    _refuse_autograd("sepconv7x7_pw", x, shared, dw_params, w2t, b2)
+def conv1x1_mfma(x, w2t, b2, relu_out=False):
+    """conv2 -> bn2 [-> relu2] of a _split_separable_conv2d block (IntVOS.py:494,503-505) as an fp32-MFMA contraction fed by
+    LDS-DMA (manet_conv1x1_f32).  x [B, Cin, h, w] fp32; w2t [Cin, 256], b2 [256] from fold_pointwise -> [B, 256, h, w]."""
+    _refuse_autograd("conv1x1_mfma", x, w2t, b2)
     lib = _lib.load()
     _need_gpu(x, "x")
     x = x.float().contiguous()
-    B, Cx, h, w = x.shape
-    if shared is not None:
-        _need_gpu(shared, "shared")
-        shared = shared.float().contiguous()
-        if shared.shape[0] != 1 or tuple(shared.shape[2:]) != (h, w):
-            raise ValueError("shared must be [1, Cs, h, w] on the same grid as x")
-        Cs = shared.shape[1]
-        in_a, sa, Ca, in_b, sb, Cb = shared, 0, Cs, x, Cx * h * w, Cx
-    else:
-        in_a, sa, Ca, in_b, sb, Cb = x, Cx * h * w, Cx, None, 0, 0
-    cin = Ca + Cb
-    pad = (cin + 15) // 16 * 16
-    if tuple(dw_params.shape) != (pad, 64):
-        raise ValueError("dw_params must be [%d, 64] (ops.pack_depthwise)" % pad)
-    if w2t.shape[0] != pad or w2t.shape[1] != SEPCONV_COUT or b2.numel() != SEPCONV_COUT:
-        raise ValueError("w2t must be [%d, %d] (ops.fold_pointwise), b2 [%d]" % (pad, SEPCONV_COUT, SEPCONV_COUT))
-    f = lambda t: t.detach().float().contiguous()
-    dw_params, w2t, b2 = f(dw_params), f(w2t), f(b2)
-    out = torch.empty((B, SEPCONV_COUT, h, w), dtype=torch.float32, device=x.device)
+    B, cin, h, w = x.shape
+    if tuple(w2t.shape) != (cin, PW_COUT) or b2.numel() != PW_COUT:
+        raise ValueError("w2t must be [%d, %d] (ops.fold_pointwise), b2 [%d]" % (cin, PW_COUT, PW_COUT))
+    if not conv1x1_mfma_ok(x, PW_COUT):
+        raise ValueError("conv1x1_mfma needs Cin and h*w to be multiples of 4")
+    w2t, b2 = w2t.detach().float().contiguous(), b2.detach().float().contiguous()
+    out = torch.empty((B, PW_COUT, h, w), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = lib.manet_sepconv7x7_pw_f32(in_a.data_ptr(), sa, Ca, None if in_b is None else in_b.data_ptr(), sb, Cb, B, h, w,
-                                         dw_params.data_ptr(), int(bool(relu_in)), w2t.data_ptr(), pad, b2.data_ptr(),
-                                         SEPCONV_COUT, int(bool(relu_out)), out.data_ptr(), _stream_ptr(x.device))
-    _lib.check(rc, "manet_sepconv7x7_pw_f32")
+        rc = lib.manet_conv1x1_f32(x.data_ptr(), cin * h * w, B, cin, h * w, w2t.data_ptr(), b2.data_ptr(), PW_COUT,
+                                   int(bool(relu_out)), out.data_ptr(), _stream_ptr(x.device))
+    _lib.check(rc, "manet_conv1x1_f32")
     return out
 
 

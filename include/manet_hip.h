@@ -272,25 +272,17 @@ int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, int w, cons
 int manet_relu_conv1x1_c1_f32(const float *in, int B, int C, long HW, const float *weight, const float *bias,
                               int relu_in, float *out, manet_stream_t stream);
 
-/* One whole _split_separable_conv2d block of DynamicSegHead (networks/IntVOS.py:488-506) in one launch:
- *   y = relu(bn1(dwconv7x7(x)));  out = bn2(conv1x1(y)) [, relu]
- * with the [B,Cin,h,w] activation y kept inside the compute unit (depthwise waves feed fp32-MFMA waves through LDS).
- *   input          channels [0, Ca) from in_a [.][Ca][h][w], channels [Ca, Ca+Cb) from in_b [.][Cb][h][w] (Cb may be 0),
- *                  each with its own batch stride in elements -- stride 0 = one tensor shared by every batch item (layer 1:
- *                  the C-channel embedding next to the per-object maps, networks/IntVOS.py:665-670, no repeat / cat);
- *                  relu_in != 0: read through max(x, 0) (the preceding block's relu2, :503-505)
- *   dw_params      [Cin_pad][64] fp32, 16-byte aligned: per input channel the 49 taps [7][7], then the depthwise bias, bn1
- *                  scale and bn1 shift, then zeros (the arguments of manet_dwconv7x7_bn_relu_*, one padded row per channel)
- *   w2t            [Cin_pad][Cout] fp32, 16-byte aligned: the 1x1 weight TRANSPOSED with eval-mode bn2 folded in
- *                  (w2t[ci][co] = conv2.weight[co][ci] * bn2_scale[co]), rows Ca+Cb .. Cin_pad-1 zero, Cin_pad = Ca+Cb rounded
- *                  up to a multiple of 16;  b2 [Cout] = conv2.bias * bn2_scale + bn2_shift;  Cout must be 256
- *   out            [B][Cout][h][w] fp32 contiguous;  relu_out != 0 applies relu2 here (0: left to the next block's relu_in)
- * The depthwise stage is bit-identical to manet_dwconv7x7_bn_relu_ex; the contraction is the ascending-channel fp32 fmaf
- * chain of v_mfma_f32_32x32x2_f32. */
-int manet_sepconv7x7_pw_f32(const float *in_a, int64_t batch_stride_a, int Ca, const float *in_b,
-                            int64_t batch_stride_b, int Cb, int B, int h, int w, const float *dw_params, int relu_in,
-                            const float *w2t, int Cin_pad, const float *b2, int Cout, int relu_out, float *out,
-                            manet_stream_t stream);
+/* The 1x1 convolution of a _split_separable_conv2d block (networks/IntVOS.py:494,503-505: conv2 -> bn2 [-> relu2]) as an
+ * fp32-MFMA contraction, operands fed by LDS-DMA:
+ *     out[b][co][p] = b2[co] + sum_ci w2t[ci][co] * in[b][ci][p]      [max(., 0) if relu_out]
+ *   in   [B][Cin][HW] fp32, batch stride in_batch_stride elements (0 = one tensor for every batch item), 16-byte aligned;
+ *        Cin and HW multiples of 4
+ *   w2t  [Cin][Cout] fp32, 16-byte aligned: the 1x1 weight TRANSPOSED with eval-mode bn2 folded in
+ *        (w2t[ci][co] = conv2.weight[co][ci] * bn2_scale[co]);  b2 [Cout] = conv2.bias * bn2_scale + bn2_shift;  Cout = 256
+ *   out  [B][Cout][HW] fp32 contiguous.
+ * The sum is the ascending-channel fp32 fmaf chain of v_mfma_f32_32x32x2_f32. */
+int manet_conv1x1_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const float *w2t,
+                      const float *b2, int Cout, int relu_out, float *out, manet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Training path: what torch.autograd does for the reference's pure-PyTorch path

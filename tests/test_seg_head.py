@@ -148,45 +148,37 @@ def test_folded_constants_follow_parameter_updates():
 
 
 @pytest.mark.gpu
-def test_fused_block_one_launch_vs_literal_module():
-    """ops.sepconv7x7_pw (depthwise waves feeding fp32-MFMA waves, the activation between the two stages never leaves the
-    CU) against the block's literal form relu2(bn2(conv2(relu1(bn1(conv1(x)))))): ragged tiles, Cin not a multiple of the
-    16-channel chunk, relu_in / deferred relu, the shared-embedding input of layer 1, and the full [3,256,120,214] size.
-    The depthwise stage keeps the two-kernel path's tap order; the 1x1 stage is an ascending-channel fp32 fmaf chain."""
+def test_mfma_pointwise_vs_framework_conv_and_literal_module():
+    """ops.conv1x1_mfma (fp32-MFMA contraction fed by LDS-DMA) against the framework's 1x1 convolution with the same folded
+    weights, and the blocks that use it against their literal form relu2(bn2(conv2(relu1(bn1(conv1(x)))))): full chunks,
+    partial last chunks (Cin % 16 = 4, 8, 12), a partial last pixel tile, the full [3,256,120,214] size, the shared-embedding
+    route of layer 1 (K = 100 on one batch item)."""
     import torch
     from cvpr2020_manet_amd import ops
     from cvpr2020_manet_amd.networks import IntVOS as M
     torch.manual_seed(3)
-    for (B, cin, h, w) in ((3, 256, 30, 54), (2, 103, 9, 13), (1, 16, 4, 16), (2, 7, 21, 35), (3, 256, 120, 214)):
-        blk = M._split_separable_conv2d(cin, 256).cuda().eval()
-        for m in (blk.bn1, blk.bn2):
-            m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 2.0); m.weight.data.normal_(1, 0.2); m.bias.data.normal_(0, 0.2)
-        x = torch.randn(B, cin, h, w, device="cuda")
-        with torch.no_grad():
-            lit = blk.relu2(blk.bn2(blk.conv2(blk.relu1(blk.bn1(blk.conv1(x))))))
-            scale1, shift1 = ops.fold_bn(blk.bn1)
+    with torch.no_grad():
+        for (B, cin, h, w) in ((3, 256, 30, 54), (2, 100, 9, 12), (1, 16, 4, 16), (2, 4, 21, 36), (2, 44, 6, 10),
+                               (3, 256, 120, 214)):
+            blk = M._split_separable_conv2d(cin, 256).cuda().eval()
+            for m in (blk.bn1, blk.bn2):
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 2.0); m.weight.data.normal_(1, 0.2); m.bias.data.normal_(0, 0.2)
+            x = torch.randn(B, cin, h, w, device="cuda")
             w2t, b2 = ops.fold_pointwise(blk.conv2, blk.bn2)
-            dwp = ops.pack_depthwise(blk.conv1.weight, blk.conv1.bias, scale1, shift1)
-            got = ops.sepconv7x7_pw(x, dwp, w2t, b2, relu_out=True)
-            torch.testing.assert_close(got, lit, rtol=2e-4, atol=2e-4)
-            # deferred ReLU out, ReLU folded into the read
-            raw = ops.sepconv7x7_pw(x, dwp, w2t, b2, relu_out=False)
-            assert torch.equal(torch.relu(raw), got)
-            a = ops.sepconv7x7_pw(x, dwp, w2t, b2, relu_in=True)
-            b_ = ops.sepconv7x7_pw(torch.relu(x), dwp, w2t, b2)
-            assert torch.equal(a, b_)
-            # against the two-kernel path: same depthwise bits, the contraction in another summation order
-            y = ops.dwconv7x7_bn_relu(x, blk.conv1.weight, blk.conv1.bias, scale=scale1, shift=shift1)
-            two = torch.nn.functional.conv2d(y, w2t[:cin].t().reshape(256, cin, 1, 1).contiguous(), b2)
-            torch.testing.assert_close(raw, two, rtol=2e-4, atol=2e-4)
-            # the module itself takes this path in eval mode
-            torch.testing.assert_close(blk(x), lit, rtol=2e-4, atol=2e-4)
-            if cin > 3:  # layer 1's two-source input: the first cin-3 channels shared by the batch
-                shared, per = x[:1, :cin - 3].contiguous(), x[:, cin - 3:].contiguous()
-                full = torch.cat((shared.repeat(B, 1, 1, 1), per), 1)
-                want = ops.sepconv7x7_pw(full, dwp, w2t, b2)
-                got2 = ops.sepconv7x7_pw(per, dwp, w2t, b2, shared=shared)
-                assert torch.equal(got2, want)
-                torch.testing.assert_close(blk.forward_shared(shared, per), blk(full), rtol=0, atol=0)
-    with torch.no_grad(), pytest.raises(ValueError):
-        ops.sepconv7x7_pw(x, dwp, w2t[:16], b2)
+            want = torch.nn.functional.conv2d(x, w2t.t().reshape(256, cin, 1, 1).contiguous(), b2)
+            got = ops.conv1x1_mfma(x, w2t, b2)
+            torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
+            assert torch.equal(ops.conv1x1_mfma(x, w2t, b2, relu_out=True), torch.relu(got))
+            lit = blk.relu2(blk.bn2(blk.conv2(blk.relu1(blk.bn1(blk.conv1(x))))))
+            torch.testing.assert_close(blk(x), lit, rtol=2e-4, atol=2e-4)  # eval mode on the GPU: dw kernel + MFMA 1x1
+        # fp64 spot check of the chain on the large case
+        ref64 = torch.nn.functional.conv2d(x.double(), w2t.t().reshape(256, cin, 1, 1).double(), b2.double())
+        assert float((got.double() - ref64).abs().max()) < 2e-4
+        # layer 1's shared route: K = 100 over one batch item + K = 3 per object (framework conv: 3 % 4 != 0)
+        head = M.DynamicSegHead(in_dim=103, embed_dim=256).cuda().eval()
+        xs = torch.randn(3, 103, 24, 30, device="cuda")
+        shared = head.forward_shared(xs[:1, :100].contiguous(), xs[:, 100:].contiguous())
+        lit = head(torch.cat((xs[:1, :100].repeat(3, 1, 1, 1), xs[:, 100:]), 1))
+        torch.testing.assert_close(shared, lit, rtol=1e-3, atol=1e-3)
+        with pytest.raises(ValueError):
+            ops.conv1x1_mfma(torch.randn(1, 6, 4, 4, device="cuda"), torch.zeros(6, 256, device="cuda"), b2)
