@@ -230,13 +230,19 @@ __global__ __launch_bounds__(64 * RC_WAVES) void relu_conv1x1_c1_kernel(const fl
 //   workgroup = 4 waves = all 256 output channels x 64 pixels; a wave owns 64 channels (2 x 2 blocks, 64 accumulator VGPRs)
 //   chunk     = 16 input channels: in-slice [16][64] (4 KiB) + weight slice [16][256] (16 KiB), double buffered; per chunk a
 //               wave issues 5 DMA pieces and 8 k-steps x 4 MFMAs, both operands one dword per lane from LDS (conflict-free)
-//   40 KiB of LDS, ~100 VGPRs: four workgroups per CU, whose prologues / epilogues / barriers hide under each other's MFMAs
+//   41 KiB of LDS, 114 VGPRs: three workgroups per CU.
+// Measured at [3,256,120,214] (tools/pw_bench.py): 109-111 us = 0.58 of the fp32 matrix peak (the framework's GEMM incl. its
+// layout transposes: 131-134 us).  What was tried on top and did not move it: wave-private DMA pipelines without any barrier
+// in the loop (120 us), a persistent form that defers a tile's stores into the next tile's MFMA loop (111 us), operand
+// reads pinned one k-step ahead (hipcc already overlaps them with the previous k-step's MFMAs).  Ablations: the bare MFMA
+// loop 84 us, + DMA 94, + epilogue 109: the workgroups of a launch start together and stay in phase, so the memory phases
+// (79 MB in, 79 MB out, in 256-byte row pieces) mostly run with the matrix pipe idle.
 // (the fused depthwise + 1x1 kernel built first in r3 -- depthwise waves feeding matrix waves through LDS, one 4 x 16-pixel
 // tile per workgroup -- was correct but 2-3x SLOWER than the two-kernel path: the 7x7 halo makes its input 3.4x the tile in
 // 88-byte row pieces, and with 95 KiB of LDS only one workgroup fits a CU, so every tile's prologue and epilogue -- 78 us of
 // a launch, measured -- ran exposed)
 constexpr int PW_P = 64, PW_KC = 16, PW_CO = 256, PW_NT = 256;
-__global__ __launch_bounds__(PW_NT, 4) void conv1x1_mfma_kernel(const float *__restrict__ in, long in_bs, int Cin, long HW,
+__global__ __launch_bounds__(PW_NT, 3) void conv1x1_mfma_kernel(const float *__restrict__ in, long in_bs, int Cin, long HW,
                                                                 const float *__restrict__ w2t,
                                                                 const float *__restrict__ b2, int relu_out,
                                                                 float *__restrict__ out)
@@ -273,24 +279,37 @@ __global__ __launch_bounds__(PW_NT, 4) void conv1x1_mfma_kernel(const float *__r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const int co0 = wave * 64;
+    __shared__ float bsh[PW_CO];
+    bsh[tid] = b2[tid];  // the folded bias, read back in the epilogue (a global load per output would serialise it)
+    const int tail = Cin - (n - 1) * PW_KC;  // channels of the last chunk: 4, 8, 12 or 16
+    // A partial last chunk multiplies all 16 rows like the others (no branch in the MFMA loop: a branch per k-step keeps
+    // hipcc from overlapping a k-step's LDS reads with the previous k-step's MFMAs): its missing weight rows are ZERO in LDS,
+    // so whatever finite in-slice rows an earlier chunk left there contribute nothing.  (n == 1: the in-slice rows were
+    // never written; they are zeroed too.)
+    auto zero_tail = [&](int buf) __attribute__((always_inline)) {
+        for (int i = tid; i < (PW_KC - tail) * PW_CO; i += PW_NT) wbuf[buf][tail * PW_CO + i] = 0.0f;
+        if (n == 1)
+            for (int i = tid; i < (PW_KC - tail) * PW_P; i += PW_NT) xbuf[buf][tail * PW_P + i] = 0.0f;
+    };
     dma(0, 0);
+    if (n == 1 && tail < PW_KC) zero_tail(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int c = 0; c < n; ++c) {
-        if (c + 1 < n) dma(c + 1, (c + 1) & 1);  // (its buffer was last read in iteration c - 1: everyone is past that barrier)
+        if (c + 1 < n) {
+            dma(c + 1, (c + 1) & 1);  // (its buffer was last read in iteration c - 1: everyone is past that barrier)
+            if (c + 2 == n && tail < PW_KC) zero_tail((c + 1) & 1);
+        }
         const float *Wt = &wbuf[c & 1][(lane >> 5) * PW_CO + co0 + (lane & 31)];
         const float *X = &xbuf[c & 1][(lane >> 5) * PW_P + (lane & 31)];
-        const int ksteps = ((Cin - c * PW_KC) < PW_KC ? (Cin - c * PW_KC) : PW_KC) / 2;
 #pragma unroll
         for (int kk = 0; kk < PW_KC / 2; ++kk) {
-            if (kk < ksteps) {  // uniform
-                const float a0 = Wt[2 * kk * PW_CO], a1 = Wt[2 * kk * PW_CO + 32];
-                const float x0 = X[2 * kk * PW_P], x1 = X[2 * kk * PW_P + 32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x1, acc[1][1], 0, 0, 0);
-            }
+            const float a0 = Wt[2 * kk * PW_CO], a1 = Wt[2 * kk * PW_CO + 32];
+            const float x0 = X[2 * kk * PW_P], x1 = X[2 * kk * PW_P + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x1, acc[1][1], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -306,7 +325,7 @@ __global__ __launch_bounds__(PW_NT, 4) void conv1x1_mfma_kernel(const float *__r
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float v = acc[cb][pb][r] + b2[co];
+                float v = acc[cb][pb][r] + bsh[co];
                 if (relu_out) v = fmaxf(v, 0.0f);
                 dst[(long)co * HW + p] = v;
             }
