@@ -65,6 +65,9 @@ SIGNATURES = {
     "manet_local_match_backward_f32": (_i, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i, _i, _i,
                                             _i, _i, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _sz, _vp]),
     "manet_conv1x1_f32": (_i, [_vp, _i64, _i, _i, _i64, _vp, _vp, _i, _i, _vp, _vp]),
+    "manet_global_match_refine": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "manet_global_match_refine_stats": (_i, [_vp, _i64, _i, _i, ctypes.POINTER(ctypes.c_int64),
+                                             ctypes.POINTER(ctypes.c_int64)]),
     "manet_frame_workspace_bytes": (_i, [_i, _i, _i, _i, _i, _szp]),
     "manet_frame_prepare": (_i, [_vp, _i, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i64,
                                  ctypes.c_uint32, _vp]),
@@ -73,7 +76,7 @@ SIGNATURES = {
     "manet_correlation_backward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
 }
 
-COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3, COMPUTE_BF16_REFINE = 0, 1, 2, 3
 EMB_F32, EMB_BF16, EMB_PACKED = 0, 1, 2
 EPI_NORMALIZE = 1
 EPI_KEYS_ARMED = 2

@@ -41,6 +41,12 @@ constexpr int META_INTS = 256;
 constexpr int META_T = 0;          // [0]        number of bank tiles actually used
 constexpr int META_SEG = 1;        // [1..65]    first tile of object o (entry n_ids = T)
 constexpr int META_CNT = 130;      // [130..193] rows per object
+constexpr int META_KMAX = 200;     // [200]      max |k|^2 over the bank's rows, float bits (MANET_COMPUTE_BF16_REFINE)
+// MANET_COMPUTE_BF16_REFINE: a pre-pass over every REFINE_SUB-th bank tile gives an upper bound of the minimum; the full
+// bf16 pass then keeps, per (query, object), the bank rows that could beat it; up to REFINE_CAP of them are re-evaluated in
+// the reference's fp32 arithmetic
+constexpr int REFINE_SUB = 4;
+constexpr int REFINE_CAP = 8;
 
 // Packed operand image of one row block: `units` 16-byte units per row, stored [unit][row][16 B].
 //   f32    unit u = 2g+h holds k = 8g + 2j + h, j = 0..3 (4 floats)      -> v_mfma_f32_32x32x2_f32
@@ -97,6 +103,7 @@ struct Geom {
 Geom geom_of(int C, int compute)
 {
     Geom G;
+    if (compute == MANET_COMPUTE_BF16_REFINE) compute = MANET_COMPUTE_BF16;  // same operand images as plain bf16
     G.compute = compute;
     if (compute == MANET_COMPUTE_F32) {
         G.steps = pick_ks(C);
@@ -123,6 +130,10 @@ struct BankLayout {
     long T_max;  // upper bound on tiles: every object wastes < 1 tile
     long nblocks;  // pre-pass blocks of RPB rows
     size_t off_meta, off_hist, off_src, off_pack, total;
+    // MANET_COMPUTE_BF16_REFINE only: the sorted rows once more in fp32, row-major [T_max * 64][C] + their |k|^2 (what the
+    // exact re-rank reads), and the sub-sampled bank of the pre-pass (its own meta block + every REFINE_SUB-th tile)
+    long T_sub_max;
+    size_t off_rows, off_norms, off_sub_meta, off_sub_pack;
 };
 
 BankLayout bank_layout(int64_t M0, int C, int n_ids, int compute)
@@ -137,6 +148,16 @@ BankLayout bank_layout(int64_t M0, int C, int n_ids, int compute)
     L.off_src = manet_align_up(L.off_hist + (size_t)(L.nblocks > 0 ? L.nblocks : 1) * n_ids * sizeof(int), 256);
     L.off_pack = manet_align_up(L.off_src + (size_t)L.T_max * BT * sizeof(int), 1024);
     L.total = manet_align_up(L.off_pack + (size_t)L.T_max * L.tile_bytes, 1024);
+    L.T_sub_max = 0;
+    L.off_rows = L.off_norms = L.off_sub_meta = L.off_sub_pack = 0;
+    if (compute == MANET_COMPUTE_BF16_REFINE) {
+        L.T_sub_max = L.T_max / REFINE_SUB + n_ids + 1;
+        L.off_rows = L.total;
+        L.off_norms = manet_align_up(L.off_rows + (size_t)L.T_max * BT * C * sizeof(float), 256);
+        L.off_sub_meta = manet_align_up(L.off_norms + (size_t)L.T_max * BT * sizeof(float), 256);
+        L.off_sub_pack = manet_align_up(L.off_sub_meta + META_INTS * sizeof(int), 1024);
+        L.total = manet_align_up(L.off_sub_pack + (size_t)L.T_sub_max * L.tile_bytes, 1024);
+    }
     return L;
 }
 
@@ -145,6 +166,9 @@ struct MatchLayout {
     long N_pad;
     int nQT;
     size_t qblk_bytes, off_q, off_keys, off_topk, total;
+    // MANET_COMPUTE_BF16_REFINE: per (object, query) threshold / candidate count / candidate slots, and two counters
+    // (candidates kept, pairs that overflowed REFINE_CAP)
+    size_t off_thr, off_cnt, off_cand, off_stats;
 };
 
 constexpr int TOPK_SPLITS = 16;  // the top-k path trades a little tail balance for a bounded workspace
@@ -164,6 +188,15 @@ MatchLayout match_layout(int64_t N, int C, int n_ids, int compute, int k_nn = 1,
         L.total = manet_align_up(L.off_topk + (size_t)TOPK_SPLITS * n_ids * L.N_pad * MANET_MAX_KNN * sizeof(float), 1024);
     if (arg)  // 64-bit (distance key, bank slot) pairs of the arg-min form live where the top-k lists would
         L.total = manet_align_up(L.off_topk + (size_t)n_ids * L.N_pad * sizeof(unsigned long long), 1024);
+    L.off_thr = L.off_cnt = L.off_cand = L.off_stats = 0;
+    if (compute == MANET_COMPUTE_BF16_REFINE) {
+        const size_t pairs = (size_t)n_ids * L.N_pad;
+        L.off_thr = L.off_topk;
+        L.off_cnt = manet_align_up(L.off_thr + pairs * sizeof(float), 256);
+        L.off_cand = manet_align_up(L.off_cnt + pairs * sizeof(int), 256);
+        L.off_stats = manet_align_up(L.off_cand + pairs * REFINE_CAP * sizeof(int), 256);
+        L.total = manet_align_up(L.off_stats + 256, 1024);
+    }
     return L;
 }
 
@@ -1474,13 +1507,19 @@ void global_match_bf16_pipe_kernel(const char *__restrict__ qpack, const char *_
 //   step = 2 tiles = 4 passes; fragments F[k] bound to k, refilled with the next pass's k-step right behind
 //   the MFMAs that consumed them; the step's barrier sits before the LAST pass (its fragments are already in
 //   registers): it publishes the next step's buffer and frees the current one for the LDS-DMA of step + 2.
-template <int KSB, int ABL>
+// FILTER (MANET_COMPUTE_BF16_REFINE, second pass): instead of reducing to a minimum, every bank row whose bf16 distance is
+// within the query's threshold thr[object][query] is appended to the pair's candidate list (cnt / cand, REFINE_CAP slots;
+// cnt keeps counting past the capacity: overflow).  A pass's 16 distances per lane are first reduced to their minimum --
+// the same eight v_minimum3 the plain kernel spends -- and only a wave in which some lane's minimum passes its threshold
+// takes the slow path that looks at the individual rows.
+template <int KSB, int ABL, bool FILTER = false>
 __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const char *__restrict__ qpack,
                                                                         const char *__restrict__ bpack,
                                                                         const int *__restrict__ meta, int n_ids,
                                                                         int nQT, int S, long N_pad,
                                                                         unsigned *__restrict__ keys, int block_map,
-                                                                        int young_prio)
+                                                                        int young_prio, const float *__restrict__ thr,
+                                                                        int *__restrict__ cnt, int *__restrict__ cand)
 {
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     constexpr int NW = 4, TPS = 2, NQB = 4;  // waves, tiles per step, query blocks per wave
@@ -1537,9 +1576,16 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     while (meta[META_SEG + o + 1] <= t0) ++o;
     int seg_end = meta[META_SEG + o + 1];
     float ma[NQB], mb[NQB];  // two running minima per query block (even / odd accumulator registers)
+    float tq[NQB];           // FILTER: this lane's four queries' thresholds for the current object
 #pragma unroll
     for (int j = 0; j < NQB; ++j) ma[j] = mb[j] = MANET_WRONG_LABEL_PADDING_DISTANCE;
+    auto load_thr = [&](int obj) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NQB; ++j) tq[j] = FILTER ? thr[(size_t)obj * N_pad + qbase + 32 * j] : 0.0f;
+    };
+    if (FILTER) load_thr(o);
     auto flush = [&](int obj) {
+        if (FILTER) return;
 #pragma unroll
         for (int j = 0; j < NQB; ++j) {
             const float v = min3p(ma[j], mb[j], mb[j]);
@@ -1553,9 +1599,27 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
 #pragma unroll
             for (int j = 0; j < NQB; ++j) ma[j] = mb[j] = MANET_WRONG_LABEL_PADDING_DISTANCE;
             do { ++o; seg_end = meta[META_SEG + o + 1]; } while (t >= seg_end);
+            if (FILTER) load_thr(o);
         }
     };
     (void)young_prio;
+    // FILTER: minimum of a pass's 16 distances of one query block, and the slow path that appends the qualifying rows
+    // (accumulator register r of lane (l31, h) is bank row (r & 3) + 8 (r >> 2) + 4 h of the pass)
+    auto min16 = [&](const f32x16 &c) __attribute__((always_inline)) {
+        float p = min3p(c[0], c[1], c[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) p = min3p(p, c[r], c[r + 1]);
+        return min3p(p, c[15], c[15]);
+    };
+    auto emit = [&](const f32x16 &c, float t, int j, int row0) __attribute__((always_inline)) {
+        int *pc = cnt + (size_t)o * N_pad + qbase + 32 * j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (c[r] <= t) {
+                const int idx = atomicAdd(pc, 1);
+                if (idx < REFINE_CAP) cand[((size_t)o * N_pad + qbase + 32 * j) * REFINE_CAP + idx] = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            }
+    };
 
     // this lane's fragment offset inside a tile image: unit (2k + h), row rb * 32 + l31
     const unsigned frag_off = (unsigned)((h * BT + l31) * 16);
@@ -1565,7 +1629,7 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
 #define MANET_LOADF(k_, pass_base_) F[k_] = *(const u32x4 *)((pass_base_) + frag_off + (size_t)(k_) * (2 * BT * 16));
     // one pass = 32 bank rows x 128 queries: MFMAs of k-step k from F[k], then F[k] <- k-step k of the pass
     // at `next_base` (a tile's second row block is 32 * 16 bytes behind its first inside every unit)
-#define MANET_PASS(next_base_)                                                                     \
+#define MANET_PASS(next_base_, row0_)                                                              \
     {                                                                                              \
         f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};                                             \
         _Pragma("unroll") for (int k = 0; k < KSB; ++k)                                            \
@@ -1578,6 +1642,16 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); /* 4 MFMA */                        \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* the refill right behind them */  \
         }                                                                                          \
+        if (FILTER) {                                                                              \
+            const float p0 = min16(c0), p1 = min16(c1), p2 = min16(c2), p3 = min16(c3);            \
+            const bool hit = (p0 <= tq[0]) | (p1 <= tq[1]) | (p2 <= tq[2]) | (p3 <= tq[3]);         \
+            if (__ballot(hit)) { /* wave-uniform, rare */                                          \
+                if (p0 <= tq[0]) emit(c0, tq[0], 0, (row0_));                                      \
+                if (p1 <= tq[1]) emit(c1, tq[1], 1, (row0_));                                      \
+                if (p2 <= tq[2]) emit(c2, tq[2], 2, (row0_));                                      \
+                if (p3 <= tq[3]) emit(c3, tq[3], 3, (row0_));                                      \
+            }                                                                                      \
+        } else {                                                                                   \
         _Pragma("unroll") for (int r = 0; r < ((ABL & 4) ? 2 : 16); r += 4)                        \
         {                                                                                          \
             ma[0] = min3p(ma[0], c0[r], c0[r + 2]);                                                \
@@ -1588,6 +1662,7 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
             mb[2] = min3p(mb[2], c2[r + 1], c2[r + 3]);                                            \
             ma[3] = min3p(ma[3], c3[r], c3[r + 2]);                                                \
             mb[3] = min3p(mb[3], c3[r + 1], c3[r + 3]);                                            \
+        }                                                                                          \
         }                                                                                          \
     }
 
@@ -1605,13 +1680,13 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         const bool has_b = (t + 1 < t1);
         // ---- tile A: rows 0-31 (refill: A rows 32-63), rows 32-63 (refill: B rows 0-31)
         next_object(t);
-        MANET_PASS(cur + 32 * 16);
-        MANET_PASS(cur + TILE_BYTES);
+        MANET_PASS(cur + 32 * 16, t * BT);
+        MANET_PASS(cur + TILE_BYTES, t * BT + 32);
         // ---- tile B rows 0-31 (refill: B rows 32-63).  After this pass every fragment of `cur` is in
         // registers.
         if (has_b) {
             next_object(t + 1);
-            MANET_PASS(cur + TILE_BYTES + 32 * 16);
+            MANET_PASS(cur + TILE_BYTES + 32 * 16, (t + 1) * BT);
         }
         // ---- this wave's pieces of the next step have landed (issued one step ago) and its reads of `cur`
         // have returned; the barrier publishes the next buffer and frees `cur` for step + 2
@@ -1621,13 +1696,192 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         asm volatile("" ::: "memory");
         if (t + 2 * TPS < t1) stage_dma(t + 2 * TPS, buf);
         // ---- tile B rows 32-63 (refill: first pass of the next step; a stale read if there is none)
-        if (has_b) MANET_PASS(nxt);
+        if (has_b) MANET_PASS(nxt, (t + 1) * BT + 32);
     }
 #undef MANET_PASS
 #undef MANET_LOADF
 #undef MANET_MFMA
 #undef MANET_BF
     flush(o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MANET_COMPUTE_BF16_REFINE: fp32-exact minima at bf16 cost (VERDICT r2 "next" #4).
+//   IntVOS.py:81-85 is a MINIMUM over the bank, so any filter that keeps the true arg-min row may discard the rest:
+//   1. pre-pass  : the plain bf16 kernel over every REFINE_SUB-th bank tile -> U(n,o), a bf16 distance of SOME row, i.e. an
+//                  upper bound (to within the rounding bound E) of the minimum;
+//   2. threshold : thr(n,o) = U + 2 E(n,o), E from |q_n|, max |k| and U (below): every row m with fp32 distance
+//                  <= the fp32 minimum has bf16 distance <= thr;
+//   3. filter    : the bf16 wide kernel over the WHOLE bank (FILTER form) appends the rows with bf16 distance <= thr to the
+//                  pair's candidate list (REFINE_CAP slots);
+//   4. re-rank   : the candidates are re-evaluated in the reference's fp32 arithmetic -- the oracle's fmaf chains, from
+//                  the fp32 copy of the sorted bank -- and reduced; a pair whose list overflowed scans its object's rows
+//                  instead.  The result is the fp32 kernel's, bit for bit.
+// The bound: with u = 2^-9 (bf16 round-to-nearest), q~ = bf16(q), k~ = bf16(k), e = (q~ - q) - (k~ - k), |e| <= u (|q| + |k|):
+//   | |q~ - k~|^2 - |q - k|^2 | = | 2 (q - k).e + |e|^2 | <= 2 u s sqrt(d) + u^2 s^2,   s = |q| + max |k|,  d = |q - k|^2
+// plus the fp32 accumulation error of either evaluation (a = 8 (C + 8) 2^-24 s^2, generous).  For the two rows that matter
+// (the pre-pass's best row and the true arg-min) d <= U + E0 + a with the crude E0 = (2u + u^2) s^2 + a, hence
+//   E = 2 u s sqrt(max(U, 0) + E0 + a) + u^2 s^2 + a   bounds both, and thr = U + 2 E (x 1.05 against the bound's own rounding).
+
+// the sorted bank once more as fp32 rows + |k|^2 (k-ascending fmaf chain over the fp32 values, as the f32 images carry
+// it) + the bank's max |k|^2; grid = tiles, 256 threads
+template <typename SRC>
+__global__ __launch_bounds__(256) void bank_rows_f32_kernel(const SRC *__restrict__ src, long s_row, long s_c,
+                                                            const int *__restrict__ src_of, int *__restrict__ meta, int C,
+                                                            float *__restrict__ rows, float *__restrict__ norms)
+{
+    const long tile = blockIdx.x;
+    if (tile >= meta[META_T]) return;
+    for (int idx = threadIdx.x; idx < BT * C; idx += 256) {
+        const int r = s_c == 1 ? idx / C : idx % BT, k = s_c == 1 ? idx % C : idx / BT;  // lanes along the source's fast axis
+        const int sr = src_of[tile * BT + r];
+        rows[(tile * BT + r) * C + k] = sr >= 0 ? emb_load(src, (long)sr * s_row + (long)k * s_c) : 0.0f;
+    }
+    if (threadIdx.x < BT) {
+        const long slot = tile * BT + threadIdx.x;
+        float n = MANET_WRONG_LABEL_PADDING_DISTANCE;
+        const int sr = src_of[slot];
+        if (sr >= 0) {
+            n = 0.0f;
+            for (int k = 0; k < C; ++k) {
+                const float x = emb_load(src, (long)sr * s_row + (long)k * s_c);
+                n = fmaf(x, x, n);
+            }
+            atomicMax((unsigned *)&meta[META_KMAX], __float_as_uint(n));  // n >= 0: the bit pattern orders like the value
+        }
+        norms[slot] = n;
+    }
+}
+
+// sub-sampled bank of the pre-pass: every REFINE_SUB-th tile of every object (at least one per non-empty object)
+__global__ void sub_segments_kernel(int n_ids, const int *__restrict__ meta, int *__restrict__ sub_meta)
+{
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int o = 0; o < n_ids; ++o) {
+            sub_meta[META_SEG + o] = t;
+            t += (meta[META_SEG + o + 1] - meta[META_SEG + o] + REFINE_SUB - 1) / REFINE_SUB;
+        }
+        sub_meta[META_SEG + n_ids] = t;
+        sub_meta[META_T] = t;
+    }
+}
+__global__ __launch_bounds__(256) void sub_copy_kernel(int n_ids, const int *__restrict__ meta,
+                                                       const int *__restrict__ sub_meta, const char *__restrict__ bpack,
+                                                       char *__restrict__ spack, long tile_bytes)
+{
+    const int j = blockIdx.x;
+    if (j >= sub_meta[META_T]) return;
+    int o = 0;
+    while (sub_meta[META_SEG + o + 1] <= j) ++o;
+    const long src_tile = meta[META_SEG + o] + (long)(j - sub_meta[META_SEG + o]) * REFINE_SUB;
+    const uint4 *a = (const uint4 *)(bpack + src_tile * tile_bytes);
+    uint4 *b = (uint4 *)(spack + (long)j * tile_bytes);
+    for (long i = threadIdx.x; i < tile_bytes / 16; i += 256) b[i] = a[i];
+}
+
+// |q~_n|^2 out of the bf16 query image: the three bf16 pieces in k slots C+3 .. C+5 (see Geom)
+__device__ __forceinline__ float query_norm_from_image(const char *qimg, long qblk_bytes, long n, int C)
+{
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int k = C + 3 + i, u = 2 * (k >> 4) + ((k >> 3) & 1), e = k & 7;
+        const unsigned short b = *(const unsigned short *)(qimg + (n >> 5) * qblk_bytes + ((long)u * QB + (n & 31)) * 16 + e * 2);
+        s += bf2f(b);  // hi + mid + lo: exact in fp32
+    }
+    return s;
+}
+
+__global__ void refine_threshold_kernel(const unsigned *__restrict__ keys, const char *__restrict__ qimg, long qblk_bytes,
+                                        int C, const int *__restrict__ meta, long N, long N_pad, int n_ids,
+                                        float *__restrict__ thr, int *__restrict__ cnt, unsigned long long *__restrict__ stats)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) stats[0] = stats[1] = 0ull;
+    if (i >= (long)n_ids * N_pad) return;
+    const long n = i % N_pad;
+    cnt[i] = 0;
+    const unsigned k = keys[i];
+    float t = -INFINITY;  // no row of this object anywhere: no candidates, the result is the padding distance
+    if (k != 0xffffffffu && n < N) {
+        const float U = float_of(k);
+        const float u = 0.001953125f;  // 2^-9
+        const float qn = sqrtf(fmaxf(query_norm_from_image(qimg, qblk_bytes, n, C), 0.0f)) * 1.004f;  // |q| <= |q~| / (1 - u)
+        const float kn = sqrtf(__uint_as_float((unsigned)meta[META_KMAX])) * 1.0001f;
+        const float s = qn + kn, s2 = s * s;
+        const float a = 8.0f * (float)(C + 8) * 5.9604645e-8f * s2;
+        const float E0 = (2.0f * u + u * u) * s2 + a;
+        const float E = 2.0f * u * s * sqrtf(fmaxf(U, 0.0f) + E0 + a) + u * u * s2 + a;
+        t = U + 2.1f * E;  // (NaN stays NaN: no candidates)
+    }
+    thr[i] = t;
+}
+
+// exact re-rank + the usual epilogue (decode / normalise / min-merge); lanes along the queries, grid.y = object
+template <typename SRC>
+__global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restrict__ q, long q_sn, long q_sc,
+                                                            const float *__restrict__ rows, const float *__restrict__ norms,
+                                                            const int *__restrict__ meta, const int *__restrict__ cnt,
+                                                            const int *__restrict__ cand, long N, long N_pad, int C, int n_ids,
+                                                            int flags, float *__restrict__ out, float *__restrict__ mem,
+                                                            unsigned long long *__restrict__ stats)
+{
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int o = blockIdx.y;
+    if (n >= N) return;
+    const long pair = (long)o * N_pad + n;
+    const int c = cnt[pair];
+    const SRC *qr = q + n * q_sn;
+    float best = MANET_WRONG_LABEL_PADDING_DISTANCE;  // IntVOS.py:81-83: an object without rows
+    if (c > REFINE_CAP) {
+        // more qualifying rows than the list holds (duplicated bank rows, ...): scan the object's rows.  Every lane of the
+        // wave walks the same rows: the bank reads are wave-uniform.
+        float xs = 0.0f;
+        for (int k = 0; k < C; ++k) {
+            const float x = emb_load(qr, (long)k * q_sc);
+            xs = fmaf(x, x, xs);
+        }
+        const long r0 = (long)meta[META_SEG + o] * BT, r1 = r0 + meta[META_CNT + o];
+        best = INFINITY;
+        for (long r = r0; r < r1; ++r) {
+            const float *kr = rows + r * C;
+            float mm = 0.0f;
+            for (int k = 0; k < C; ++k) mm = fmaf(emb_load(qr, (long)k * q_sc), kr[k], mm);
+            best = __builtin_elementwise_minimum(best, fmaf(-2.0f, mm, xs + norms[r]));
+        }
+        atomicAdd(&stats[1], 1ull);
+    } else if (c > 0) {
+        int slot[REFINE_CAP];
+        float mm[REFINE_CAP];
+#pragma unroll
+        for (int j = 0; j < REFINE_CAP; ++j) {
+            slot[j] = cand[pair * REFINE_CAP + (j < c ? j : 0)];
+            mm[j] = 0.0f;
+        }
+        float xs = 0.0f;
+        for (int k = 0; k < C; ++k) {
+            const float x = emb_load(qr, (long)k * q_sc);
+            xs = fmaf(x, x, xs);
+#pragma unroll
+            for (int j = 0; j < REFINE_CAP; ++j)
+                if (j < c) mm[j] = fmaf(x, rows[(long)slot[j] * C + k], mm[j]);
+        }
+        best = INFINITY;
+#pragma unroll
+        for (int j = 0; j < REFINE_CAP; ++j)
+            if (j < c) best = __builtin_elementwise_minimum(best, fmaf(-2.0f, mm[j], xs + norms[slot[j]]));  // IntVOS.py:39
+        atomicAdd(&stats[0], (unsigned long long)c);
+    }
+    float g = best;
+    if (flags & MANET_EPI_NORMALIZE) g = manet_normalize_dist(g);
+    const long i = n * n_ids + o;
+    if (mem) {
+        const float mv = mem[i];
+        g = (g <= mv) ? g : mv;
+        mem[i] = g;
+    }
+    out[i] = g;
 }
 
 // decode + (sigmoid-0.5)*2 (IntVOS.py:611-612) + min-merge with the stored map (IntVOS.py:620-622)
@@ -1816,8 +2070,11 @@ int check_common(int64_t N, int64_t M0, int C, int n_ids, int k_nn, int compute)
         return manet_set_error(MANET_E_INVALID, "k_nn=%d (supported 1..%d)", k_nn, MANET_MAX_KNN);
     if (k_nn > 1 && compute != MANET_COMPUTE_F32)
         return manet_set_error(MANET_E_INVALID, "k_nn > 1 needs MANET_COMPUTE_F32");
-    if (compute != MANET_COMPUTE_F32 && compute != MANET_COMPUTE_BF16 && compute != MANET_COMPUTE_BF16X3)
-        return manet_set_error(MANET_E_INVALID, "compute=%d (MANET_COMPUTE_F32 / _BF16 / _BF16X3)", compute);
+    if (compute != MANET_COMPUTE_F32 && compute != MANET_COMPUTE_BF16 && compute != MANET_COMPUTE_BF16X3 &&
+        compute != MANET_COMPUTE_BF16_REFINE)
+        return manet_set_error(MANET_E_INVALID, "compute=%d (MANET_COMPUTE_F32 / _BF16 / _BF16X3 / _BF16_REFINE)", compute);
+    if (compute == MANET_COMPUTE_BF16_REFINE && C + BF16_SPECIAL > 112)
+        return manet_set_error(MANET_E_INVALID, "MANET_COMPUTE_BF16_REFINE supports C <= 106 (the wide bf16 kernel)");
     return MANET_OK;
 }
 
@@ -1882,7 +2139,7 @@ void launch_main_bf16_v(const char *qpack, const char *bpack, const int *meta, i
 // MANET_TUNE_ABLATION (key 3) selects the timing-ablation instantiations of the two pipelined kernels.
 template <int KSB, bool X3>
 void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S, long N_pad,
-                      unsigned *keys, hipStream_t st)
+                      unsigned *keys, hipStream_t st, int prof_channel = 0)
 {
     const int v = manet_tune_get(MANET_TUNE_BF16_VARIANT, 0);
     const int tps = v & 3, reg = (v >> 2) & 1, flat = (v >> 4) & 1;
@@ -1911,11 +2168,15 @@ void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int
         }
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int bm = block_map_arg(nQT, narrow ? 256 : 512);
+        const float *no_thr = nullptr;
+        int *no_cnt = nullptr, *no_cand = nullptr;
+        // (the narrow kernel takes the first ten arguments; the wide one also the FILTER form's three, unused here)
         void *args[] = {(void *)&qpack, (void *)&bpack, (void *)&meta, (void *)&n_ids, (void *)&nQT, (void *)&S,
-                        (void *)&N_pad, (void *)&keys, (void *)&bm, (void *)&prio};
-        manet_profile_record(st, true);
+                        (void *)&N_pad, (void *)&keys, (void *)&bm, (void *)&prio, (void *)&no_thr, (void *)&no_cnt,
+                        (void *)&no_cand};
+        manet_profile_record(st, true, prof_channel);
         (void)hipLaunchKernel(fn, dim3((unsigned)(nQT * S)), dim3(threads), args, lds, st);
-        manet_profile_record(st, false);
+        manet_profile_record(st, false, prof_channel);
         return;
     }
 #define MANET_BV(TPS_)                                                                                         \
@@ -1925,6 +2186,53 @@ void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int
     else if (tps == 2) { MANET_BV((X3 ? 2 : 4)) }
     else { MANET_BV((X3 ? 1 : 2)) }
 #undef MANET_BV
+}
+
+// MANET_COMPUTE_BF16_REFINE on a prepared bank (see the kernels' header comment).  `qimg` = the query's bf16 operand
+// image (made by the caller of this function), `qraw` = the same query as stored (fp32 / bf16, element strides).
+int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long q_sc, const char *bws, const BankLayout &BL,
+               char *mws, const MatchLayout &ML, long N, int C, int n_ids, float *out, float *mem, int flags, hipStream_t st)
+{
+    const int *meta = (const int *)(bws + BL.off_meta), *sub_meta = (const int *)(bws + BL.off_sub_meta);
+    unsigned *keys = (unsigned *)(mws + ML.off_keys);
+    float *thr = (float *)(mws + ML.off_thr);
+    int *cnt = (int *)(mws + ML.off_cnt), *cand = (int *)(mws + ML.off_cand);
+    unsigned long long *stats = (unsigned long long *)(mws + ML.off_stats);
+    // 1. pre-pass over the sub-sampled bank -> keys = U
+    const int S1 = pick_splits(ML.nQT, BL.T_sub_max, 512);
+    if (ML.G.steps == 2) launch_main_bf16<2, false>(qimg, bws + BL.off_sub_pack, sub_meta, n_ids, ML.nQT, S1, ML.N_pad, keys, st, 3);
+    else launch_main_bf16<7, false>(qimg, bws + BL.off_sub_pack, sub_meta, n_ids, ML.nQT, S1, ML.N_pad, keys, st, 3);
+    // 2. thresholds, counters
+    const long pairs = (long)n_ids * ML.N_pad;
+    hipLaunchKernelGGL(refine_threshold_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, (const unsigned *)keys,
+                       qimg, (long)ML.qblk_bytes, C, meta, N, ML.N_pad, n_ids, thr, cnt, stats);
+    // 3. filter pass over the whole bank
+    {
+        const int S = pick_splits(ML.nQT, BL.T_max, 512);
+        const size_t lds = (size_t)2 * 2 * bank_tile_bytes_u(2 * ML.G.steps, false);
+        const void *fn = ML.G.steps == 2 ? (const void *)global_match_bf16_wide_kernel<2, 0, true>
+                                         : (const void *)global_match_bf16_wide_kernel<7, 0, true>;
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const char *bpack = bws + BL.off_pack;
+        int nQT = ML.nQT, Sv = S, bm = block_map_arg(ML.nQT, 512), prio = 0;
+        long N_pad = ML.N_pad;
+        const float *thr_c = thr;
+        void *args[] = {(void *)&qimg, (void *)&bpack, (void *)&meta, (void *)&n_ids, (void *)&nQT, (void *)&Sv,
+                        (void *)&N_pad, (void *)&keys, (void *)&bm, (void *)&prio, (void *)&thr_c, (void *)&cnt, (void *)&cand};
+        manet_profile_record(st, true, 0);
+        (void)hipLaunchKernel(fn, dim3((unsigned)(nQT * S)), dim3(256), args, lds, st);
+        manet_profile_record(st, false, 0);
+    }
+    // 4. exact re-rank + epilogue
+    const dim3 grid((unsigned)((N + 255) / 256), (unsigned)n_ids);
+    const float *rows = (const float *)(bws + BL.off_rows), *norms = (const float *)(bws + BL.off_norms);
+    if (q_dtype == MANET_EMB_F32)
+        hipLaunchKernelGGL(refine_rerank_kernel<float>, grid, dim3(256), 0, st, (const float *)qraw, q_sn, q_sc, rows, norms, meta,
+                           (const int *)cnt, (const int *)cand, N, ML.N_pad, C, n_ids, flags, out, mem, stats);
+    else
+        hipLaunchKernelGGL(refine_rerank_kernel<unsigned short>, grid, dim3(256), 0, st, (const unsigned short *)qraw, q_sn, q_sc,
+                           rows, norms, meta, (const int *)cnt, (const int *)cand, N, ML.N_pad, C, n_ids, flags, out, mem, stats);
+    return manet_check_launch("manet_global_match (bf16 filter + fp32 re-rank)");
 }
 
 }  // namespace
@@ -1993,7 +2301,7 @@ int manet_frame_prepare(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y
     FramePrep A;
     A.emb = emb;
     A.s_f = (long)s_f; A.s_y = (long)s_y; A.s_x = (long)s_x; A.s_c = (long)s_c;
-    A.h = h; A.w = w; A.C = C; A.compute = compute; A.units = G.units; A.kpad = G.kpad;
+    A.h = h; A.w = w; A.C = C; A.compute = G.compute; A.units = G.units; A.kpad = G.kpad;  // (G.compute: _BF16_REFINE packs as _BF16)
     A.ws = (char *)frames_ws; A.ws_stride = (long)frame_ws_stride; A.qblk_bytes = (long)G.qblk_bytes;
     A.off_plane = (long)F.off_plane; A.off_tab = (long)F.off_tab;
     A.d = max_distance; A.hp = F.hp; A.wp = F.wp; A.HPAD = F.HPAD; A.WS = F.WS; A.PS = F.PS;
@@ -2089,6 +2397,24 @@ int manet_bank_prepare_ex(const void *bank, int emb_dtype, int64_t b_stride_m, i
     rc = launch_bank_pack(bank, emb_dtype, (long)b_stride_m, (long)b_stride_c, (const int *)src_of, (const int *)meta, (long)M0,
                           C, L.G, ws + L.off_pack, L.T_max, st);
     if (rc) return rc;
+    if (compute == MANET_COMPUTE_BF16_REFINE) {
+        // the fp32 copy of the sorted rows the exact re-rank reads, and the sub-sampled bank of the pre-pass
+        float *rows = (float *)(ws + L.off_rows), *norms = (float *)(ws + L.off_norms);
+        int *sub_meta = (int *)(ws + L.off_sub_meta);
+        if (L.T_max > 0) {
+            if (emb_dtype == MANET_EMB_F32)
+                hipLaunchKernelGGL(bank_rows_f32_kernel<float>, dim3((unsigned)L.T_max), dim3(256), 0, st, (const float *)bank,
+                                   (long)b_stride_m, (long)b_stride_c, (const int *)src_of, meta, C, rows, norms);
+            else
+                hipLaunchKernelGGL(bank_rows_f32_kernel<unsigned short>, dim3((unsigned)L.T_max), dim3(256), 0, st,
+                                   (const unsigned short *)bank, (long)b_stride_m, (long)b_stride_c, (const int *)src_of, meta, C,
+                                   rows, norms);
+        }
+        fill32(sub_meta, 0u, META_INTS, st);
+        hipLaunchKernelGGL(sub_segments_kernel, dim3(1), dim3(64), 0, st, n_ids, (const int *)meta, sub_meta);
+        hipLaunchKernelGGL(sub_copy_kernel, dim3((unsigned)L.T_sub_max), dim3(256), 0, st, n_ids, (const int *)meta,
+                           (const int *)sub_meta, (const char *)(ws + L.off_pack), ws + L.off_sub_pack, (long)L.tile_bytes);
+    }
     return manet_check_launch("manet_bank_prepare");
 }
 
@@ -2155,6 +2481,13 @@ int manet_global_match_prepared_ex(const void *query, int emb_dtype, int64_t q_s
         qpack = mws + ML.off_q;
     } else if (!armed) {
         fill32(keys, 0xffffffffu, (size_t)n_ids * ML.N_pad, st);
+    }
+    if (compute == MANET_COMPUTE_BF16_REFINE) {
+        if (emb_dtype == MANET_EMB_PACKED)
+            return manet_set_error(MANET_E_INVALID, "MANET_COMPUTE_BF16_REFINE re-ranks in fp32 from the query as stored: pass "
+                                                    "it to manet_global_match_refine next to its packed image");
+        return run_refine(qpack, query, emb_dtype, (long)q_stride_n, (long)q_stride_c, bws, BL, mws, ML, (long)N, C, n_ids, out,
+                          mem_inout, epilogue_flags, st);
     }
     // resident workgroup slots: f32 and plain bf16 (wide kernel) = 2 x 256-thread workgroups per CU,
     // split-bf16 (and the tuning-only narrow/flat bf16 forms) = 1 x 512-thread workgroup per CU
@@ -2316,6 +2649,45 @@ int manet_global_match_backward_f32(const float *query, int64_t q_stride_n, int6
                        n_ids, grad_query, (long)gq_stride_n, (long)gq_stride_c, grad_bank, (long)gb_stride_m,
                        (long)gb_stride_c);
     return manet_check_launch("manet_global_match_backward_f32");
+}
+
+int manet_global_match_refine(const void *query, int emb_dtype, int64_t q_stride_n, int64_t q_stride_c,
+                              const void *query_image, const void *bank_ws, int64_t N, int64_t M0, int C, int n_ids,
+                              float *out, float *mem_inout, int epilogue_flags, void *match_ws, size_t match_ws_bytes,
+                              manet_stream_t stream)
+{
+    const int compute = MANET_COMPUTE_BF16_REFINE;
+    int rc = check_common(N, M0, C, n_ids, 1, compute);
+    if (rc) return rc;
+    if (!query || !bank_ws || !out || !match_ws) return manet_set_error(MANET_E_INVALID, "null pointer");
+    if (emb_dtype != MANET_EMB_F32 && emb_dtype != MANET_EMB_BF16)
+        return manet_set_error(MANET_E_INVALID, "embedding dtype %d (MANET_EMB_F32 / MANET_EMB_BF16)", emb_dtype);
+    if (!query_image)  // no image at hand: the general entry point packs one
+        return manet_global_match_prepared_ex(query, emb_dtype, q_stride_n, q_stride_c, bank_ws, N, M0, C, n_ids, 1, compute, out,
+                                              mem_inout, epilogue_flags, match_ws, match_ws_bytes, stream);
+    BankLayout BL = bank_layout(M0, C, n_ids, compute);
+    MatchLayout ML = match_layout(N, C, n_ids, compute, 1);
+    if (match_ws_bytes < ML.total)
+        return manet_set_error(MANET_E_WORKSPACE, "match workspace %zu < %zu bytes", match_ws_bytes, ML.total);
+    hipStream_t st = (hipStream_t)stream;
+    fill32((char *)match_ws + ML.off_keys, 0xffffffffu, (size_t)n_ids * ML.N_pad, st);
+    return run_refine((const char *)query_image, query, emb_dtype, (long)q_stride_n, (long)q_stride_c, (const char *)bank_ws, BL,
+                      (char *)match_ws, ML, (long)N, C, n_ids, out, mem_inout, epilogue_flags & ~MANET_EPI_KEYS_ARMED, st);
+}
+
+int manet_global_match_refine_stats(const void *match_ws, int64_t N, int C, int n_ids, int64_t *candidates,
+                                    int64_t *overflowed_pairs)
+{
+    if (!match_ws) return manet_set_error(MANET_E_INVALID, "null pointer");
+    int rc = check_common(N, 0, C, n_ids, 1, MANET_COMPUTE_BF16_REFINE);
+    if (rc) return rc;
+    MatchLayout ML = match_layout(N, C, n_ids, MANET_COMPUTE_BF16_REFINE, 1);
+    unsigned long long h[2] = {0, 0};
+    if (hipMemcpy(h, (const char *)match_ws + ML.off_stats, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)  // (blocks)
+        return manet_set_error(MANET_E_LAUNCH, "reading the statistics failed");
+    if (candidates) *candidates = (int64_t)h[0];
+    if (overflowed_pairs) *overflowed_pairs = (int64_t)h[1];
+    return MANET_OK;
 }
 
 int manet_normalize_merge_f32(float *x, float *mem_inout, int64_t n, int normalize, manet_stream_t stream)

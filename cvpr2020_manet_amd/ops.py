@@ -9,8 +9,14 @@ import torch
 
 from . import _lib
 
+# "bf16r": bf16 filter + exact fp32 re-rank (MANET_COMPUTE_BF16_REFINE): MANET_COMPUTE_F32's result bit for bit, ~1.4x bf16's cost
 COMPUTE = {"f32": _lib.COMPUTE_F32, "fp32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16,
-           "bf16x3": _lib.COMPUTE_BF16X3}
+           "bf16x3": _lib.COMPUTE_BF16X3, "bf16r": _lib.COMPUTE_BF16_REFINE}
+
+
+def _image_kind(compute_code):
+    """operand images depend on the arithmetic only through this: bf16r packs exactly as bf16"""
+    return _lib.COMPUTE_BF16 if compute_code == _lib.COMPUTE_BF16_REFINE else compute_code
 
 _ws_cache = {}
 
@@ -192,15 +198,19 @@ class PreparedBank:
         e.g. for every frame of a clip right after extract_feature: no per-frame pack pass)"""
         import ctypes
         lib = _lib.load()
-        armed = False
+        armed, raw = False, None
         if isinstance(query_embeddings, (PackedQuery, PreparedFrame)):
             pq = query_embeddings
-            if pq.C != self.C or pq.compute != self.compute:
+            if pq.C != self.C or _image_kind(pq.compute) != _image_kind(self.compute):
                 raise ValueError("the query operand was packed for C=%d compute=%d, bank has C=%d compute=%d"
                                  % (pq.C, pq.compute, self.C, self.compute))
             _refuse_autograd("PreparedBank.match", mem)
             qry, N, C, q_code, q_s0, q_s1 = pq.image, pq.N, pq.C, _lib.EMB_PACKED, 0, 0
-            armed = k_nearest_neighbors == 1
+            armed = k_nearest_neighbors == 1 and self.compute != _lib.COMPUTE_BF16_REFINE
+            if self.compute == _lib.COMPUTE_BF16_REFINE:  # the exact re-rank reads the query as stored
+                if pq.raw is None:
+                    raise ValueError("compute='bf16r' needs the embedding the operand image was made from (still alive)")
+                raw, _, _ = _flat(pq.raw, "query_embeddings")
         else:
             _refuse_autograd("PreparedBank.match", query_embeddings, mem)
             qry, N, C = _flat(query_embeddings, "query_embeddings")
@@ -224,13 +234,31 @@ class PreparedBank:
                 raise ValueError("mem must be a contiguous float32 tensor of N*n_ids elements")
             mem_ptr = mem.data_ptr()
         flags = (_lib.EPI_NORMALIZE if normalize else 0) | (_lib.EPI_KEYS_ARMED if armed else 0)
+        self._last = (ws, N)  # (refine_stats)
         with torch.cuda.device(dev):
-            rc = lib.manet_global_match_prepared_ex(qry.data_ptr(), q_code, q_s0, q_s1,
-                                                    self.ws.data_ptr(), N, self.M0, C, self.n_ids,
-                                                    k_nearest_neighbors, self.compute, out.data_ptr(), mem_ptr,
-                                                    flags, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+            if raw is not None:
+                rc = lib.manet_global_match_refine(raw.data_ptr(), _emb_code(raw), raw.stride(0), raw.stride(1), qry.data_ptr(),
+                                                   self.ws.data_ptr(), N, self.M0, C, self.n_ids, out.data_ptr(), mem_ptr,
+                                                   flags, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+            else:
+                rc = lib.manet_global_match_prepared_ex(qry.data_ptr(), q_code, q_s0, q_s1,
+                                                        self.ws.data_ptr(), N, self.M0, C, self.n_ids,
+                                                        k_nearest_neighbors, self.compute, out.data_ptr(), mem_ptr,
+                                                        flags, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
         _lib.check(rc, "manet_global_match_prepared_ex")
         return out
+
+    def refine_stats(self):
+        """compute='bf16r': (candidate rows re-evaluated in fp32, (query, object) pairs whose candidate list overflowed) of
+        the LAST match() on this bank; synchronises."""
+        import ctypes
+        if self.compute != _lib.COMPUTE_BF16_REFINE or getattr(self, "_last", None) is None:
+            raise RuntimeError("refine_stats: no compute='bf16r' match has run on this bank")
+        ws, N = self._last
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(_lib.load().manet_global_match_refine_stats(ws.data_ptr(), N, self.C, self.n_ids, ctypes.byref(a),
+                                                               ctypes.byref(b)), "manet_global_match_refine_stats")
+        return a.value, b.value
 
 
 class PackedQuery:
@@ -252,6 +280,7 @@ class PackedQuery:
                                       self.image.data_ptr(), self.image.numel(), _stream_ptr(qry.device))
         _lib.check(rc, "manet_query_pack")
         self.device = qry.device
+        self.raw = query_embeddings  # (compute="bf16r": the exact re-rank reads the embedding itself)
 
 
 class PreparedFrame:
@@ -260,8 +289,9 @@ class PreparedFrame:
     embedding, once per frame: a propagated frame then needs no pack pass and no pooling pass, and the previous frame's
     embedding is not read at all (its plane was made when it was the current frame, test.py:259)."""
 
-    def __init__(self, ws, h, w, C, compute, max_distance, keep=None):
+    def __init__(self, ws, h, w, C, compute, max_distance, keep=None, raw=None):
         self.ws, self.h, self.w, self.C, self.compute, self.max_distance = ws, h, w, C, compute, max_distance
+        self.raw = raw  # the [C, h, w] embedding as an [h, w, C] view (compute="bf16r" re-ranks from it)
         self.N = h * w
         self.image = ws  # the operand image sits at the start of the frame workspace (a MANET_EMB_PACKED query)
         self.device = ws.device
@@ -309,7 +339,7 @@ def prepare_frames(embeddings, compute="f32", max_distance=-1, preset=None, pres
                                      emb.stride(1), B, h, w, C, cmp_, max_distance, ws.data_ptr(), per, fill_ptr,
                                      fill_words, fill_bits, _stream_ptr(emb.device))
     _lib.check(rc, "manet_frame_prepare")
-    frames = [PreparedFrame(ws[i], h, w, C, cmp_, max_distance) for i in range(B)]
+    frames = [PreparedFrame(ws[i], h, w, C, cmp_, max_distance, raw=emb[i].permute(1, 2, 0)) for i in range(B)]
     return frames[0] if single else frames
 
 
@@ -319,7 +349,7 @@ def local_match_frames(prev_frame, cur_frame, prev_frame_labels, n_ids, out=None
     embeddings the frames were prepared from."""
     lib = _lib.load()
     a, b = prev_frame, cur_frame
-    if (a.h, a.w, a.C, a.compute, a.max_distance) != (b.h, b.w, b.C, b.compute, b.max_distance):
+    if (a.h, a.w, a.C, _image_kind(a.compute), a.max_distance) != (b.h, b.w, b.C, _image_kind(b.compute), b.max_distance):
         raise ValueError("the two frames were prepared for different shapes / arithmetic / window radius")
     if b.max_distance < 0:
         raise ValueError("the frames were prepared without a pooled plane (max_distance < 0)")

@@ -59,6 +59,12 @@ typedef void *manet_stream_t; /* a hipStream_t */
 #define MANET_COMPUTE_F32 0     /* v_mfma_f32_32x32x2_f32, exact fp32 (bit-equal to an fmaf chain) */
 #define MANET_COMPUTE_BF16 1    /* v_mfma_f32_32x32x16_bf16 on inputs rounded to bf16, fp32 accumulate */
 #define MANET_COMPUTE_BF16X3 2  /* split-bf16 (hi+lo, 3 MFMAs): fp32-class accuracy at bf16 rate */
+/* bf16 filter + exact fp32 re-rank (k_nn = 1, C <= 106): IntVOS.py:81-85 is a minimum, so a filter that provably keeps the
+ * arg-min row may drop every other one.  A bf16 pre-pass over a quarter of the bank bounds the minimum, a bf16 pass over
+ * the whole bank keeps the rows whose bf16 distance is within the rounding bound of that, and those few are re-evaluated in
+ * the reference's fp32 arithmetic (the fmaf chains of MANET_COMPUTE_F32): the result EQUALS MANET_COMPUTE_F32's bit for bit
+ * at about 1.4x the cost of MANET_COMPUTE_BF16.  (NaN embeddings: unsupported in this mode.) */
+#define MANET_COMPUTE_BF16_REFINE 3
 
 /* storage type of an embedding operand of the *_ex entry points (take the producer's layout) */
 #define MANET_EMB_F32 0    /* float */
@@ -165,6 +171,19 @@ int manet_frame_prepare(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y
                         int n_frames, int h, int w, int C, int compute, int max_distance, void *frames_ws,
                         size_t frame_ws_stride, void *fill_ptr, int64_t fill_words, uint32_t fill_value,
                         manet_stream_t stream);
+
+/* MANET_COMPUTE_BF16_REFINE on a prepared bank when the query's packed image exists already (manet_frame_prepare /
+ * manet_query_pack with MANET_COMPUTE_BF16 or _BF16_REFINE): the fp32 re-rank also needs the query as stored, so this entry
+ * point takes both.  query_image == NULL: same as manet_global_match_prepared_ex(..., MANET_COMPUTE_BF16_REFINE, ...).
+ * manet_global_match_refine_stats reads back (blocking copy -- tests / benchmarks) what the last call on `match_ws` did:
+ * candidate rows re-evaluated in fp32, and (query, object) pairs whose candidate list overflowed (those scan their object's
+ * rows: exact, slow). */
+int manet_global_match_refine(const void *query, int emb_dtype, int64_t q_stride_n, int64_t q_stride_c,
+                              const void *query_image, const void *bank_ws, int64_t N, int64_t M0, int C, int n_ids,
+                              float *out, float *mem_inout, int epilogue_flags, void *match_ws, size_t match_ws_bytes,
+                              manet_stream_t stream);
+int manet_global_match_refine_stats(const void *match_ws, int64_t N, int C, int n_ids, int64_t *candidates,
+                                    int64_t *overflowed_pairs);
 
 /* Stand-alone normalise / min-merge (IntVOS.py:611-622, :718-723), in place on x[n]
  * (and on mem_inout[n] when not NULL). */
