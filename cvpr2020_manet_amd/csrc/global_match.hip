@@ -46,7 +46,8 @@ constexpr int META_KMAX = 200;     // [200]      max |k|^2 over the bank's rows,
 // bf16 pass then keeps, per (query, object), the bank rows that could beat it; up to REFINE_CAP of them are re-evaluated in
 // the reference's fp32 arithmetic
 constexpr int REFINE_SUB = 4;
-constexpr int REFINE_CAP = 8;
+constexpr int REFINE_CAP = 16;  // capacity of the flat candidate list, in rows per (query, object) pair ON AVERAGE
+constexpr int REFINE_LDS_LIST = 2048;  // candidate entries a filter workgroup collects in LDS before it appends them in bulk
 
 // Packed operand image of one row block: `units` 16-byte units per row, stored [unit][row][16 B].
 //   f32    unit u = 2g+h holds k = 8g + 2j + h, j = 0..3 (4 floats)      -> v_mfma_f32_32x32x2_f32
@@ -166,9 +167,10 @@ struct MatchLayout {
     long N_pad;
     int nQT;
     size_t qblk_bytes, off_q, off_keys, off_topk, total;
-    // MANET_COMPUTE_BF16_REFINE: per (object, query) threshold / candidate count / candidate slots, and two counters
-    // (candidates kept, pairs that overflowed REFINE_CAP)
-    size_t off_thr, off_cnt, off_cand, off_stats;
+    // MANET_COMPUTE_BF16_REFINE: per (object, query) threshold and exact-distance key, the flat candidate list
+    // {pair, bank slot} with its capacity, and two counters (candidates appended, list overflowed)
+    size_t off_thr, off_slack, off_keys2, off_list, off_stats;
+    long list_cap;
 };
 
 constexpr int TOPK_SPLITS = 16;  // the top-k path trades a little tail balance for a bounded workspace
@@ -188,13 +190,16 @@ MatchLayout match_layout(int64_t N, int C, int n_ids, int compute, int k_nn = 1,
         L.total = manet_align_up(L.off_topk + (size_t)TOPK_SPLITS * n_ids * L.N_pad * MANET_MAX_KNN * sizeof(float), 1024);
     if (arg)  // 64-bit (distance key, bank slot) pairs of the arg-min form live where the top-k lists would
         L.total = manet_align_up(L.off_topk + (size_t)n_ids * L.N_pad * sizeof(unsigned long long), 1024);
-    L.off_thr = L.off_cnt = L.off_cand = L.off_stats = 0;
+    L.off_thr = L.off_slack = L.off_keys2 = L.off_list = L.off_stats = 0;
+    L.list_cap = 0;
     if (compute == MANET_COMPUTE_BF16_REFINE) {
         const size_t pairs = (size_t)n_ids * L.N_pad;
+        L.list_cap = (long)pairs * REFINE_CAP;
         L.off_thr = L.off_topk;
-        L.off_cnt = manet_align_up(L.off_thr + pairs * sizeof(float), 256);
-        L.off_cand = manet_align_up(L.off_cnt + pairs * sizeof(int), 256);
-        L.off_stats = manet_align_up(L.off_cand + pairs * REFINE_CAP * sizeof(int), 256);
+        L.off_slack = manet_align_up(L.off_thr + pairs * sizeof(float), 256);
+        L.off_keys2 = manet_align_up(L.off_slack + pairs * sizeof(float), 256);
+        L.off_list = manet_align_up(L.off_keys2 + pairs * sizeof(unsigned), 256);
+        L.off_stats = manet_align_up(L.off_list + (size_t)L.list_cap * sizeof(uint2), 256);
         L.total = manet_align_up(L.off_stats + 256, 1024);
     }
     return L;
@@ -718,11 +723,16 @@ __device__ __forceinline__ bool split_of_block(int b, int nQT, int S, int T, int
         t1 = (int)((long)(s + 1) * T / S2);
         return t0 < t1;
     }
-    if (bm == 0) {
+    if (bm == 0 || bm == 3) {
         const int xcd = b & 7;
         const int idx = b >> 3;
         qt = idx % nQT;
         s = xcd + 8 * (idx / nQT);
+        // bm == 3 (the FILTER pass of MANET_COMPUTE_BF16_REFINE; S is a multiple of 8): XCD x walks the CONTIGUOUS splits
+        // x S/8 .. (x+1) S/8 - 1 one after the other instead of x, x + 8, ...: at any time the eight resident splits are
+        // spread over the whole bank, i.e. over all objects, so most of an object's splits start after earlier ones of the
+        // same object have published their tightened thresholds
+        if (bm == 3 && (S & 7) == 0) s = xcd * (S >> 3) + idx / nQT;
     } else if (bm == 1) {
         qt = b % nQT;
         s = b / nQT;
@@ -1508,8 +1518,8 @@ void global_match_bf16_pipe_kernel(const char *__restrict__ qpack, const char *_
 //   the MFMAs that consumed them; the step's barrier sits before the LAST pass (its fragments are already in
 //   registers): it publishes the next step's buffer and frees the current one for the LDS-DMA of step + 2.
 // FILTER (MANET_COMPUTE_BF16_REFINE, second pass): instead of reducing to a minimum, every bank row whose bf16 distance is
-// within the query's threshold thr[object][query] is appended to the pair's candidate list (cnt / cand, REFINE_CAP slots;
-// cnt keeps counting past the capacity: overflow).  A pass's 16 distances per lane are first reduced to their minimum --
+// within the query's threshold thr[object][query] is appended to the flat candidate list {pair, bank slot} (stats[0] = its
+// fill count; an entry that does not fit raises stats[1]).  A pass's 16 distances per lane are first reduced to their minimum --
 // the same eight v_minimum3 the plain kernel spends -- and only a wave in which some lane's minimum passes its threshold
 // takes the slow path that looks at the individual rows.
 template <int KSB, int ABL, bool FILTER = false>
@@ -1518,8 +1528,10 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
                                                                         const int *__restrict__ meta, int n_ids,
                                                                         int nQT, int S, long N_pad,
                                                                         unsigned *__restrict__ keys, int block_map,
-                                                                        int young_prio, const float *__restrict__ thr,
-                                                                        int *__restrict__ cnt, int *__restrict__ cand)
+                                                                        int young_prio, unsigned *__restrict__ thr,
+                                                                        const float *__restrict__ slack,
+                                                                        unsigned long long *__restrict__ stats,
+                                                                        uint2 *__restrict__ list, long list_cap)
 {
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     constexpr int NW = 4, TPS = 2, NQB = 4;  // waves, tiles per step, query blocks per wave
@@ -1576,16 +1588,32 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     while (meta[META_SEG + o + 1] <= t0) ++o;
     int seg_end = meta[META_SEG + o + 1];
     float ma[NQB], mb[NQB];  // two running minima per query block (even / odd accumulator registers)
-    float tq[NQB];           // FILTER: this lane's four queries' thresholds for the current object
+    // FILTER: this lane's four queries' thresholds for the current object.  tq starts at the pair's current global
+    // threshold -- the pre-pass's bound + slack, already tightened by the workgroups that finished before this one -- and
+    // tightens to (smallest bf16 distance this lane meets) + slack: any row's bf16 distance bounds the minimum the same way
+    // the pre-pass's does, and the slack 2.1 E(U) only shrinks with U.  Leaving an object, the lane publishes its threshold
+    // (atomicMin on the key): the later rounds of workgroups filter against nearly the final minimum, which is what keeps
+    // the candidate lists short.
+    float tq[NQB], sq[NQB];
 #pragma unroll
     for (int j = 0; j < NQB; ++j) ma[j] = mb[j] = MANET_WRONG_LABEL_PADDING_DISTANCE;
     auto load_thr = [&](int obj) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < NQB; ++j) tq[j] = FILTER ? thr[(size_t)obj * N_pad + qbase + 32 * j] : 0.0f;
+        for (int j = 0; j < NQB; ++j) {
+            tq[j] = FILTER ? float_of(thr[(size_t)obj * N_pad + qbase + 32 * j]) : 0.0f;
+            sq[j] = FILTER ? slack[(size_t)obj * N_pad + qbase + 32 * j] : 0.0f;
+        }
     };
     if (FILTER) load_thr(o);
     auto flush = [&](int obj) {
-        if (FILTER) return;
+        if (FILTER) {
+#pragma unroll
+            for (int j = 0; j < NQB; ++j) {
+                const float a = fminf(tq[j], __shfl_xor(tq[j], 32));
+                if (h == 0 && a == a) atomicMin(thr + (size_t)obj * N_pad + qbase + 32 * j, key_of(a));
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NQB; ++j) {
             const float v = min3p(ma[j], mb[j], mb[j]);
@@ -1611,14 +1639,34 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         for (int r = 3; r < 15; r += 2) p = min3p(p, c[r], c[r + 1]);
         return min3p(p, c[15], c[15]);
     };
+    // A qualifying row goes to the WAVE's own LDS list first -- its fill count lives in a scalar register, a hit costs a
+    // ballot, a population count and a ds_write, no atomic (a returning global atomic per row stalled the wave for a memory
+    // round trip: 2x the kernel's time; a returning LDS atomic: +45 %) -- and reaches the global list in bulk when the wave
+    // is done; rows beyond the wave's capacity are appended directly.
+    constexpr int WL = REFINE_LDS_LIST / NW;  // entries per wave
+    uint2 *fl = (uint2 *)(smem + 2 * STEP_BYTES) + wave * WL;
+    int wl_n = 0;  // (wave-uniform)
+    auto append_global = [&](int obj, long n, int slot) __attribute__((always_inline)) {
+        const unsigned long long idx = atomicAdd(&stats[0], 1ull);
+        if (idx < (unsigned long long)list_cap) list[idx] = make_uint2((unsigned)((size_t)obj * N_pad + n), (unsigned)slot);
+        else stats[1] = 1ull;
+    };
     auto emit = [&](const f32x16 &c, float t, int j, int row0) __attribute__((always_inline)) {
-        int *pc = cnt + (size_t)o * N_pad + qbase + 32 * j;
+        const unsigned lq = (unsigned)(wave * (NQB * QB) + l31 + 32 * j);  // query inside the workgroup's 512
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (c[r] <= t) {
-                const int idx = atomicAdd(pc, 1);
-                if (idx < REFINE_CAP) cand[((size_t)o * N_pad + qbase + 32 * j) * REFINE_CAP + idx] = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        for (int r = 0; r < 16; ++r) {
+            const bool hit = c[r] <= t;
+            const unsigned long long m = __ballot(hit);
+            if (m) {  // wave-uniform: most registers hold no qualifying row for any lane
+                const int slot = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int idx = wl_n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (hit) {
+                    if (idx < WL) fl[idx] = make_uint2(((unsigned)o << 16) | lq, (unsigned)slot);
+                    else append_global(o, (long)qt * QTB + lq, slot);
+                }
+                wl_n += __popcll(m);
             }
+        }
     };
 
     // this lane's fragment offset inside a tile image: unit (2k + h), row rb * 32 + l31
@@ -1644,12 +1692,16 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         }                                                                                          \
         if (FILTER) {                                                                              \
             const float p0 = min16(c0), p1 = min16(c1), p2 = min16(c2), p3 = min16(c3);            \
-            const bool hit = (p0 <= tq[0]) | (p1 <= tq[1]) | (p2 <= tq[2]) | (p3 <= tq[3]);         \
-            if (__ballot(hit)) { /* wave-uniform, rare */                                          \
-                if (p0 <= tq[0]) emit(c0, tq[0], 0, (row0_));                                      \
-                if (p1 <= tq[1]) emit(c1, tq[1], 1, (row0_));                                      \
-                if (p2 <= tq[2]) emit(c2, tq[2], 2, (row0_));                                      \
-                if (p3 <= tq[3]) emit(c3, tq[3], 3, (row0_));                                      \
+            tq[0] = fminf(tq[0], p0 + sq[0]);                                                      \
+            tq[1] = fminf(tq[1], p1 + sq[1]);                                                      \
+            tq[2] = fminf(tq[2], p2 + sq[2]);                                                      \
+            tq[3] = fminf(tq[3], p3 + sq[3]);                                                      \
+            const bool h0 = p0 <= tq[0], h1 = p1 <= tq[1], h2 = p2 <= tq[2], h3 = p3 <= tq[3];     \
+            if (__ballot(h0 | h1 | h2 | h3)) { /* wave-uniform */                                  \
+                if (__ballot(h0)) emit(c0, tq[0], 0, (row0_));                                     \
+                if (__ballot(h1)) emit(c1, tq[1], 1, (row0_));                                     \
+                if (__ballot(h2)) emit(c2, tq[2], 2, (row0_));                                     \
+                if (__ballot(h3)) emit(c3, tq[3], 3, (row0_));                                     \
             }                                                                                      \
         } else {                                                                                   \
         _Pragma("unroll") for (int r = 0; r < ((ABL & 4) ? 2 : 16); r += 4)                        \
@@ -1697,12 +1749,32 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         if (t + 2 * TPS < t1) stage_dma(t + 2 * TPS, buf);
         // ---- tile B rows 32-63 (refill: first pass of the next step; a stale read if there is none)
         if (has_b) MANET_PASS(nxt, (t + 1) * BT + 32);
+        if (FILTER && (((t - t0) / TPS) & 3) == 3) {
+            // every fourth step: publish this wave's thresholds and pick up what the workgroups running beside it on the
+            // same queries and object have found (non-returning atomics + four loads per lane)
+            flush(o);
+#pragma unroll
+            for (int j = 0; j < NQB; ++j) tq[j] = fminf(tq[j], float_of(thr[(size_t)o * N_pad + qbase + 32 * j]));
+        }
     }
 #undef MANET_PASS
 #undef MANET_LOADF
 #undef MANET_MFMA
 #undef MANET_BF
     flush(o);
+    if (FILTER) {  // the wave's candidates -> the global list: ONE returning atomic reserves their places
+        const int total = wl_n < WL ? wl_n : WL;
+        unsigned long long base = 0ull;
+        if (lane == 0 && total) base = atomicAdd(&stats[0], (unsigned long long)total);
+        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
+               (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)base);
+        for (int i = lane; i < total; i += 64) {
+            const uint2 e = fl[i];  // (this wave's own ds_writes: ordered behind them in the LDS queue)
+            if (base + i < (unsigned long long)list_cap)
+                list[base + i] = make_uint2((unsigned)((size_t)(e.x >> 16) * N_pad + (size_t)qt * QTB + (e.x & 0xffffu)), e.y);
+            else stats[1] = 1ull;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1795,15 +1867,16 @@ __device__ __forceinline__ float query_norm_from_image(const char *qimg, long qb
 
 __global__ void refine_threshold_kernel(const unsigned *__restrict__ keys, const char *__restrict__ qimg, long qblk_bytes,
                                         int C, const int *__restrict__ meta, long N, long N_pad, int n_ids,
-                                        float *__restrict__ thr, int *__restrict__ cnt, unsigned long long *__restrict__ stats)
+                                        unsigned *__restrict__ thr, float *__restrict__ slack, unsigned *__restrict__ keys2,
+                                        unsigned long long *__restrict__ stats)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) stats[0] = stats[1] = 0ull;
     if (i >= (long)n_ids * N_pad) return;
     const long n = i % N_pad;
-    cnt[i] = 0;
+    keys2[i] = 0xffffffffu;  // "no row": the exact distances meet here by atomicMin
     const unsigned k = keys[i];
-    float t = -INFINITY;  // no row of this object anywhere: no candidates, the result is the padding distance
+    float t = -INFINITY, sl = 0.0f;  // no row of this object anywhere: no candidates, the result is the padding distance
     if (k != 0xffffffffu && n < N) {
         const float U = float_of(k);
         const float u = 0.001953125f;  // 2^-9
@@ -1813,75 +1886,81 @@ __global__ void refine_threshold_kernel(const unsigned *__restrict__ keys, const
         const float a = 8.0f * (float)(C + 8) * 5.9604645e-8f * s2;
         const float E0 = (2.0f * u + u * u) * s2 + a;
         const float E = 2.0f * u * s * sqrtf(fmaxf(U, 0.0f) + E0 + a) + u * u * s2 + a;
-        t = U + 2.1f * E;  // (NaN stays NaN: no candidates)
+        sl = 2.1f * E;
+        t = U + sl;  // (NaN stays NaN: no candidates)
     }
-    thr[i] = t;
+    thr[i] = key_of(t);  // as an order-preserving key: the filter pass's workgroups tighten it by atomicMin
+    slack[i] = sl;       // ... to (smallest bf16 distance they met) + slack: E only shrinks with U
 }
 
-// exact re-rank + the usual epilogue (decode / normalise / min-merge); lanes along the queries, grid.y = object
+// exact re-rank: one thread per candidate {pair, bank slot}: the reference's fp32 distance (the oracle's fmaf chains,
+// IntVOS.py:32-39) of that (query, bank row), reduced per pair by atomicMin on the order-preserving key; the usual finish
+// kernel decodes the keys.  (The candidates of a filter workgroup sit together and belong to its 512 queries: for a fixed
+// channel a wave's query reads fall into a 2 KiB window of the C-major embedding.)
 template <typename SRC>
 __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restrict__ q, long q_sn, long q_sc,
                                                             const float *__restrict__ rows, const float *__restrict__ norms,
-                                                            const int *__restrict__ meta, const int *__restrict__ cnt,
-                                                            const int *__restrict__ cand, long N, long N_pad, int C, int n_ids,
-                                                            int flags, float *__restrict__ out, float *__restrict__ mem,
-                                                            unsigned long long *__restrict__ stats)
+                                                            const uint2 *__restrict__ list, long list_cap, long N_pad, int C,
+                                                            unsigned *__restrict__ keys2,
+                                                            const unsigned long long *__restrict__ stats)
 {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)(stats[0] < (unsigned long long)list_cap ? stats[0] : (unsigned long long)list_cap);
+    if (i >= total) return;
+    const uint2 e = list[i];
+    const long n = (long)(e.x % (unsigned long)N_pad);
+    const SRC *qr = q + n * q_sn;
+    const float *kr = rows + (long)e.y * C;
+    float xs = 0.0f, mm = 0.0f;
+    int k = 0;
+    for (; (C & 3) == 0 && k + 4 <= C; k += 4) {  // (four loads in flight; the chains stay in ascending k)
+        const float x0 = emb_load(qr, (long)k * q_sc), x1 = emb_load(qr, (long)(k + 1) * q_sc);
+        const float x2 = emb_load(qr, (long)(k + 2) * q_sc), x3 = emb_load(qr, (long)(k + 3) * q_sc);
+        const f32x4 y4 = *(const f32x4 *)(kr + k);  // (rows are 16-byte aligned: C % 4 == 0 here, else the scalar tail)
+        const float y0 = y4[0], y1 = y4[1], y2 = y4[2], y3 = y4[3];
+        xs = fmaf(x0, x0, xs); mm = fmaf(x0, y0, mm);
+        xs = fmaf(x1, x1, xs); mm = fmaf(x1, y1, mm);
+        xs = fmaf(x2, x2, xs); mm = fmaf(x2, y2, mm);
+        xs = fmaf(x3, x3, xs); mm = fmaf(x3, y3, mm);
+    }
+    for (; k < C; ++k) {
+        const float x = emb_load(qr, (long)k * q_sc);
+        xs = fmaf(x, x, xs);
+        mm = fmaf(x, kr[k], mm);
+    }
+    atomicMin(keys2 + e.x, key_of(fmaf(-2.0f, mm, xs + norms[e.y])));  // IntVOS.py:39
+}
+
+// The candidate list overflowed (duplicated bank rows, a pathological threshold ...): every pair scans its object's rows in
+// the same arithmetic instead -- exact, slow, and never on the path of a sane input.  Launched always, returns at once
+// unless stats[1] is set.  Lanes along the queries: every lane of a wave walks the same bank rows (uniform reads).
+template <typename SRC>
+__global__ __launch_bounds__(256) void refine_rescue_kernel(const SRC *__restrict__ q, long q_sn, long q_sc,
+                                                            const float *__restrict__ rows, const float *__restrict__ norms,
+                                                            const int *__restrict__ meta, long N, long N_pad, int C,
+                                                            unsigned *__restrict__ keys2,
+                                                            const unsigned long long *__restrict__ stats)
+{
+    if (stats[1] == 0ull) return;
     const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int o = blockIdx.y;
     if (n >= N) return;
-    const long pair = (long)o * N_pad + n;
-    const int c = cnt[pair];
     const SRC *qr = q + n * q_sn;
-    float best = MANET_WRONG_LABEL_PADDING_DISTANCE;  // IntVOS.py:81-83: an object without rows
-    if (c > REFINE_CAP) {
-        // more qualifying rows than the list holds (duplicated bank rows, ...): scan the object's rows.  Every lane of the
-        // wave walks the same rows: the bank reads are wave-uniform.
-        float xs = 0.0f;
-        for (int k = 0; k < C; ++k) {
-            const float x = emb_load(qr, (long)k * q_sc);
-            xs = fmaf(x, x, xs);
-        }
-        const long r0 = (long)meta[META_SEG + o] * BT, r1 = r0 + meta[META_CNT + o];
-        best = INFINITY;
-        for (long r = r0; r < r1; ++r) {
-            const float *kr = rows + r * C;
-            float mm = 0.0f;
-            for (int k = 0; k < C; ++k) mm = fmaf(emb_load(qr, (long)k * q_sc), kr[k], mm);
-            best = __builtin_elementwise_minimum(best, fmaf(-2.0f, mm, xs + norms[r]));
-        }
-        atomicAdd(&stats[1], 1ull);
-    } else if (c > 0) {
-        int slot[REFINE_CAP];
-        float mm[REFINE_CAP];
-#pragma unroll
-        for (int j = 0; j < REFINE_CAP; ++j) {
-            slot[j] = cand[pair * REFINE_CAP + (j < c ? j : 0)];
-            mm[j] = 0.0f;
-        }
-        float xs = 0.0f;
-        for (int k = 0; k < C; ++k) {
-            const float x = emb_load(qr, (long)k * q_sc);
-            xs = fmaf(x, x, xs);
-#pragma unroll
-            for (int j = 0; j < REFINE_CAP; ++j)
-                if (j < c) mm[j] = fmaf(x, rows[(long)slot[j] * C + k], mm[j]);
-        }
-        best = INFINITY;
-#pragma unroll
-        for (int j = 0; j < REFINE_CAP; ++j)
-            if (j < c) best = __builtin_elementwise_minimum(best, fmaf(-2.0f, mm[j], xs + norms[slot[j]]));  // IntVOS.py:39
-        atomicAdd(&stats[0], (unsigned long long)c);
+    float xs = 0.0f;
+    for (int k = 0; k < C; ++k) {
+        const float x = emb_load(qr, (long)k * q_sc);
+        xs = fmaf(x, x, xs);
     }
-    float g = best;
-    if (flags & MANET_EPI_NORMALIZE) g = manet_normalize_dist(g);
-    const long i = n * n_ids + o;
-    if (mem) {
-        const float mv = mem[i];
-        g = (g <= mv) ? g : mv;
-        mem[i] = g;
+    const long r0 = (long)meta[META_SEG + o] * BT, r1 = r0 + meta[META_CNT + o];
+    unsigned best = 0xffffffffu;
+    for (long r = r0; r < r1; ++r) {
+        const float *kr = rows + r * C;
+        float mm = 0.0f;
+        for (int k = 0; k < C; ++k) mm = fmaf(emb_load(qr, (long)k * q_sc), kr[k], mm);
+        const unsigned key = key_of(fmaf(-2.0f, mm, xs + norms[r]));
+        best = key < best ? key : best;
     }
-    out[i] = g;
+    atomicMin(keys2 + (size_t)o * N_pad + n, best);
 }
 
 // decode + (sigmoid-0.5)*2 (IntVOS.py:611-612) + min-merge with the stored map (IntVOS.py:620-622)
@@ -2168,12 +2247,15 @@ void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int
         }
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int bm = block_map_arg(nQT, narrow ? 256 : 512);
-        const float *no_thr = nullptr;
-        int *no_cnt = nullptr, *no_cand = nullptr;
-        // (the narrow kernel takes the first ten arguments; the wide one also the FILTER form's three, unused here)
+        unsigned *no_thr = nullptr;
+        const float *no_slack = nullptr;
+        unsigned long long *no_stats = nullptr;
+        uint2 *no_list = nullptr;
+        long no_cap = 0;
+        // (the narrow kernel takes the first ten arguments; the wide one also the FILTER form's five, unused here)
         void *args[] = {(void *)&qpack, (void *)&bpack, (void *)&meta, (void *)&n_ids, (void *)&nQT, (void *)&S,
-                        (void *)&N_pad, (void *)&keys, (void *)&bm, (void *)&prio, (void *)&no_thr, (void *)&no_cnt,
-                        (void *)&no_cand};
+                        (void *)&N_pad, (void *)&keys, (void *)&bm, (void *)&prio, (void *)&no_thr, (void *)&no_slack,
+                        (void *)&no_stats, (void *)&no_list, (void *)&no_cap};
         manet_profile_record(st, true, prof_channel);
         (void)hipLaunchKernel(fn, dim3((unsigned)(nQT * S)), dim3(threads), args, lds, st);
         manet_profile_record(st, false, prof_channel);
@@ -2194,44 +2276,56 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
                char *mws, const MatchLayout &ML, long N, int C, int n_ids, float *out, float *mem, int flags, hipStream_t st)
 {
     const int *meta = (const int *)(bws + BL.off_meta), *sub_meta = (const int *)(bws + BL.off_sub_meta);
-    unsigned *keys = (unsigned *)(mws + ML.off_keys);
-    float *thr = (float *)(mws + ML.off_thr);
-    int *cnt = (int *)(mws + ML.off_cnt), *cand = (int *)(mws + ML.off_cand);
+    unsigned *keys = (unsigned *)(mws + ML.off_keys), *keys2 = (unsigned *)(mws + ML.off_keys2);
+    unsigned *thr = (unsigned *)(mws + ML.off_thr);
+    float *slack = (float *)(mws + ML.off_slack);
+    uint2 *list = (uint2 *)(mws + ML.off_list);
     unsigned long long *stats = (unsigned long long *)(mws + ML.off_stats);
     // 1. pre-pass over the sub-sampled bank -> keys = U
     const int S1 = pick_splits(ML.nQT, BL.T_sub_max, 512);
     if (ML.G.steps == 2) launch_main_bf16<2, false>(qimg, bws + BL.off_sub_pack, sub_meta, n_ids, ML.nQT, S1, ML.N_pad, keys, st, 3);
     else launch_main_bf16<7, false>(qimg, bws + BL.off_sub_pack, sub_meta, n_ids, ML.nQT, S1, ML.N_pad, keys, st, 3);
-    // 2. thresholds, counters
+    // 2. thresholds; exact keys and counters reset
     const long pairs = (long)n_ids * ML.N_pad;
     hipLaunchKernelGGL(refine_threshold_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, (const unsigned *)keys,
-                       qimg, (long)ML.qblk_bytes, C, meta, N, ML.N_pad, n_ids, thr, cnt, stats);
-    // 3. filter pass over the whole bank
+                       qimg, (long)ML.qblk_bytes, C, meta, N, ML.N_pad, n_ids, thr, slack, keys2, stats);
+    // 3. filter pass over the whole bank -> candidate list
     {
         const int S = pick_splits(ML.nQT, BL.T_max, 512);
-        const size_t lds = (size_t)2 * 2 * bank_tile_bytes_u(2 * ML.G.steps, false);
+        const size_t lds = (size_t)2 * 2 * bank_tile_bytes_u(2 * ML.G.steps, false) + (size_t)REFINE_LDS_LIST * 8;
         const void *fn = ML.G.steps == 2 ? (const void *)global_match_bf16_wide_kernel<2, 0, true>
                                          : (const void *)global_match_bf16_wide_kernel<7, 0, true>;
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const char *bpack = bws + BL.off_pack;
         int nQT = ML.nQT, Sv = S, bm = block_map_arg(ML.nQT, 512), prio = 0;
-        long N_pad = ML.N_pad;
-        const float *thr_c = thr;
+        if ((bm & 0xff) == 0) bm |= 3;  // (see split_of_block)
+        long N_pad = ML.N_pad, cap = ML.list_cap;
+        unsigned *thr_c = thr;
+        const float *slack_c = slack;
         void *args[] = {(void *)&qimg, (void *)&bpack, (void *)&meta, (void *)&n_ids, (void *)&nQT, (void *)&Sv,
-                        (void *)&N_pad, (void *)&keys, (void *)&bm, (void *)&prio, (void *)&thr_c, (void *)&cnt, (void *)&cand};
+                        (void *)&N_pad, (void *)&keys, (void *)&bm, (void *)&prio, (void *)&thr_c, (void *)&slack_c, (void *)&stats,
+                        (void *)&list, (void *)&cap};
         manet_profile_record(st, true, 0);
         (void)hipLaunchKernel(fn, dim3((unsigned)(nQT * S)), dim3(256), args, lds, st);
         manet_profile_record(st, false, 0);
     }
-    // 4. exact re-rank + epilogue
-    const dim3 grid((unsigned)((N + 255) / 256), (unsigned)n_ids);
+    // 4. exact re-rank of the candidates (+ the rescue scan, a no-op unless the list overflowed), then the usual finish
     const float *rows = (const float *)(bws + BL.off_rows), *norms = (const float *)(bws + BL.off_norms);
-    if (q_dtype == MANET_EMB_F32)
-        hipLaunchKernelGGL(refine_rerank_kernel<float>, grid, dim3(256), 0, st, (const float *)qraw, q_sn, q_sc, rows, norms, meta,
-                           (const int *)cnt, (const int *)cand, N, ML.N_pad, C, n_ids, flags, out, mem, stats);
-    else
-        hipLaunchKernelGGL(refine_rerank_kernel<unsigned short>, grid, dim3(256), 0, st, (const unsigned short *)qraw, q_sn, q_sc,
-                           rows, norms, meta, (const int *)cnt, (const int *)cand, N, ML.N_pad, C, n_ids, flags, out, mem, stats);
+    const dim3 rgrid((unsigned)((ML.list_cap + 255) / 256)), sgrid((unsigned)((N + 255) / 256), (unsigned)n_ids);
+    if (q_dtype == MANET_EMB_F32) {
+        hipLaunchKernelGGL(refine_rerank_kernel<float>, rgrid, dim3(256), 0, st, (const float *)qraw, q_sn, q_sc, rows, norms,
+                           (const uint2 *)list, ML.list_cap, ML.N_pad, C, keys2, (const unsigned long long *)stats);
+        hipLaunchKernelGGL(refine_rescue_kernel<float>, sgrid, dim3(256), 0, st, (const float *)qraw, q_sn, q_sc, rows, norms, meta,
+                           N, ML.N_pad, C, keys2, (const unsigned long long *)stats);
+    } else {
+        hipLaunchKernelGGL(refine_rerank_kernel<unsigned short>, rgrid, dim3(256), 0, st, (const unsigned short *)qraw, q_sn, q_sc,
+                           rows, norms, (const uint2 *)list, ML.list_cap, ML.N_pad, C, keys2, (const unsigned long long *)stats);
+        hipLaunchKernelGGL(refine_rescue_kernel<unsigned short>, sgrid, dim3(256), 0, st, (const unsigned short *)qraw, q_sn, q_sc,
+                           rows, norms, meta, N, ML.N_pad, C, keys2, (const unsigned long long *)stats);
+    }
+    const long total = N * n_ids;
+    hipLaunchKernelGGL(global_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, keys2, N, ML.N_pad, n_ids,
+                       flags & ~MANET_EPI_KEYS_ARMED, out, mem);
     return manet_check_launch("manet_global_match (bf16 filter + fp32 re-rank)");
 }
 
@@ -2676,7 +2770,7 @@ int manet_global_match_refine(const void *query, int emb_dtype, int64_t q_stride
 }
 
 int manet_global_match_refine_stats(const void *match_ws, int64_t N, int C, int n_ids, int64_t *candidates,
-                                    int64_t *overflowed_pairs)
+                                    int64_t *list_overflowed)
 {
     if (!match_ws) return manet_set_error(MANET_E_INVALID, "null pointer");
     int rc = check_common(N, 0, C, n_ids, 1, MANET_COMPUTE_BF16_REFINE);
@@ -2686,7 +2780,7 @@ int manet_global_match_refine_stats(const void *match_ws, int64_t N, int C, int 
     if (hipMemcpy(h, (const char *)match_ws + ML.off_stats, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)  // (blocks)
         return manet_set_error(MANET_E_LAUNCH, "reading the statistics failed");
     if (candidates) *candidates = (int64_t)h[0];
-    if (overflowed_pairs) *overflowed_pairs = (int64_t)h[1];
+    if (list_overflowed) *list_overflowed = (int64_t)h[1];
     return MANET_OK;
 }
 

@@ -249,8 +249,8 @@ class PreparedBank:
         return out
 
     def refine_stats(self):
-        """compute='bf16r': (candidate rows re-evaluated in fp32, (query, object) pairs whose candidate list overflowed) of
-        the LAST match() on this bank; synchronises."""
+        """compute='bf16r': (candidate rows the filter pass appended, 1 if the candidate list overflowed and every pair
+        scanned its object's rows instead) of the LAST match() on this bank; synchronises."""
         import ctypes
         if self.compute != _lib.COMPUTE_BF16_REFINE or getattr(self, "_last", None) is None:
             raise RuntimeError("refine_stats: no compute='bf16r' match has run on this bank")
