@@ -74,7 +74,9 @@ class Workload:
         self.emb_dtype = torch.bfloat16 if emb == "bf16" else torch.float32
         gen = torch.Generator(device=device).manual_seed(20200614 + 2 + 1000 * rank)
         self.n_local = n_local
-        n_res = min(n_local, 8)  # resident frames, cycled: 8 x 10.3 MB (fp32, 480p)
+        # resident frames, cycled: 8 x 10.3 MB (fp32, 480p); at least T + 2 when the clip allows, so that the resident set
+        # holds a frame that is not in the bank (the parity probe)
+        n_res = min(n_local, max(8, c["T"] + 2))
         f32 = [torch.relu(torch.randn(C, self.H, self.W, generator=gen, device=device)) * 0.1 for _ in range(n_res)]
         # C-major embeddings as extract_feature produces them (post-ReLU), stored in the producer's type
         self.local_emb = torch.stack([f.to(self.emb_dtype) for f in f32]).contiguous()
@@ -270,7 +272,7 @@ def run_leg(wl, K, Wm, args, lib, use_dist=False, one_shot=False, prepacked=Fals
     kern_ms = float(np.mean([ms[i] for i in range(nrec.value)])) if nrec.value else float("nan")
     local_ms = float(np.mean([lms[i] for i in range(nloc.value)])) if nloc.value else float("nan")
     return {"elapsed": elapsed, "kern_ms": kern_ms, "local_ms": local_ms, "prep_ms": prep_ms, "bank_rows": bank_rows,
-            "bank_lab": bank_lab, "collective": timing["collective"]}
+            "bank_lab": bank_lab, "collective": timing["collective"], "bank": bank}
 
 
 def roofline_blocks(wl, kern_ms, local_ms, overlap=False, prep_ms=None):
@@ -440,7 +442,7 @@ def bf16_parity(wl, bank_rows, bank_lab, budget_s=4.0):
 
 def also_leg(cfg, compute, device, lib, args):
     """A GPU-only leg of another single-GPU BASELINE config (a few steps) + its parity figures."""
-    wl = Workload(cfg, compute, "bf16" if compute != "f32" else "f32", device, n_local=8, keep_f32=True)
+    wl = Workload(cfg, compute, "bf16" if compute != "f32" else "f32", device, n_local=CONFIGS[cfg]["T"] + 2, keep_f32=True)
     K, Wm = args.also_steps, 2
     r = run_leg(wl, K, Wm, args, lib)
     roof, local = roofline_blocks(wl, r["kern_ms"], r["local_ms"], prep_ms=r["prep_ms"])
@@ -458,6 +460,18 @@ def also_leg(cfg, compute, device, lib, args):
                               wl.frame_emb(p).float().permute(1, 2, 0).cpu().numpy(), wl.prev_labs[0].cpu().numpy(),
                               wl.n_ids, wl.d)
         leg["parity"]["local_map_max_abs_err"] = float(np.abs(l_chk.cpu().numpy() - loc.reshape(wl.H, wl.W, wl.n_ids)).max())
+    # the mode that meets north_star's 1e-3 WHATEVER the embeddings' scale, on fp32-stored embeddings (plain bf16 meets it on
+    # this benchmark's distribution only, tests/test_bf16_error_bound.py): bf16 filter + exact fp32 re-rank = the fp32
+    # kernel's result bit for bit
+    del wl, r
+    torch.cuda.empty_cache()
+    wx = Workload(cfg, "bf16r", "f32", device, n_local=CONFIGS[cfg]["T"] + 2)
+    rx = run_leg(wx, K, Wm, args, lib)
+    cands, over = rx["bank"].refine_stats()
+    leg["exact_mode"] = {"dtype": "bf16r", "embeddings": "f32-stored", "value": K / rx["elapsed"], "unit": "frames/s",
+                         "ms_per_step": rx["elapsed"] / K * 1e3, "filter_kernel_ms": rx["kern_ms"],
+                         "result": "bit-equal to compute='f32' (tests/test_bf16_refine.py)",
+                         "candidate_rows_per_pair": cands / float(wx.H * wx.W * wx.n_ids), "candidate_list_overflowed": int(over)}
     return leg
 
 
