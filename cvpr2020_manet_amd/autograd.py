@@ -66,18 +66,27 @@ class GlobalMatchFn(torch.autograd.Function):
         N = qry.shape[0]
         dev = qry.device
         g = grad_out.contiguous().float()
-        # gradients in the inputs' own memory order (C-major embeddings stay C-major)
-        gq = torch.empty_strided(qry.shape, qry.stride(), dtype=torch.float32, device=dev) \
-            if _dense(qry) else torch.empty(qry.shape, dtype=torch.float32, device=dev)
-        gr = torch.empty_strided(ref.shape, ref.stride(), dtype=torch.float32, device=dev) \
-            if _dense(ref) else torch.empty(ref.shape, dtype=torch.float32, device=dev)
+        need_ref, need_qry = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_ref or need_qry):
+            return None, None, None, None
+        # gradients in the inputs' own memory order (C-major embeddings stay C-major); a gradient nobody asked for (the
+        # frozen reference frame of fine-tuning) is neither zero-filled nor scattered into
+        gq = gr = None
+        if need_qry:
+            gq = torch.empty_strided(qry.shape, qry.stride(), dtype=torch.float32, device=dev) \
+                if _dense(qry) else torch.empty(qry.shape, dtype=torch.float32, device=dev)
+        if need_ref:
+            gr = torch.empty_strided(ref.shape, ref.stride(), dtype=torch.float32, device=dev) \
+                if _dense(ref) else torch.empty(ref.shape, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             rc = lib.manet_global_match_backward_f32(qry.data_ptr(), qry.stride(0), qry.stride(1), ref.data_ptr(),
                                                      ref.stride(0) if M0 > 0 else C, ref.stride(1) if M0 > 0 else 1,
                                                      arg.data_ptr(), g.data_ptr(), N, M0, C, ctx.n_ids,
-                                                     gq.data_ptr(), gq.stride(0), gq.stride(1), gr.data_ptr(),
-                                                     gr.stride(0) if M0 > 0 else C, gr.stride(1) if M0 > 0 else 1,
-                                                     _stream_ptr(dev))
+                                                     None if gq is None else gq.data_ptr(),
+                                                     C if gq is None else gq.stride(0), 1 if gq is None else gq.stride(1),
+                                                     None if gr is None else gr.data_ptr(),
+                                                     C if (gr is None or M0 == 0) else gr.stride(0),
+                                                     1 if (gr is None or M0 == 0) else gr.stride(1), _stream_ptr(dev))
         _lib.check(rc, "manet_global_match_backward_f32")
         return gr, gq, None, None
 
@@ -151,13 +160,19 @@ class LocalMatchFn(torch.autograd.Function):
 
 
 class CorrelationFn(torch.autograd.Function):
-    """correlation_package's CorrelationFunction (correlation.py:7-45) on the HIP kernels."""
+    """correlation_package's CorrelationFunction (correlation.py:7-45) on the HIP kernels.  The output (and the gradients)
+    have the inputs' dtype, as the reference's op (float / half; the forward computes in that type exactly like the no-grad
+    path).  The backward kernels are fp32: half gradients are computed in fp32 and rounded once; double inputs are refused
+    under grad (the reference dispatches a double backward, correlation_cuda_kernel.cu:495-541 -- not built here)."""
 
     @staticmethod
     def forward(ctx, input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2):
         from . import ops
-        a = input1.float().contiguous()
-        b = input2.float().contiguous()
+        if input1.dtype == torch.float64 or input2.dtype == torch.float64:
+            raise RuntimeError("cvpr2020_manet_amd: the correlation backward exists for float32 / float16 inputs; "
+                               "float64 inputs that require grad are not supported (call under torch.no_grad())")
+        a = input1.contiguous()
+        b = input2.contiguous()
         ctx.save_for_backward(a, b)
         ctx.params = (pad_size, kernel_size, max_displacement, stride1, stride2)
         with torch.no_grad():
@@ -166,7 +181,8 @@ class CorrelationFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         lib = _lib.load()
-        a, b = ctx.saved_tensors
+        a0, b0 = ctx.saved_tensors
+        a, b = a0.float(), b0.float()
         B, C, H, W = a.shape
         pad_size, kernel_size, max_displacement, stride1, stride2 = ctx.params
         g = grad_out.contiguous().float()
@@ -176,4 +192,4 @@ class CorrelationFn(torch.autograd.Function):
                                                     kernel_size, max_displacement, stride1, stride2, ga.data_ptr(),
                                                     gb.data_ptr(), _stream_ptr(a.device))
         _lib.check(rc, "manet_correlation_backward_f32")
-        return ga, gb, None, None, None, None, None
+        return ga.to(a0.dtype), gb.to(b0.dtype), None, None, None, None, None

@@ -2125,9 +2125,9 @@ __global__ void global_match_backward_kernel(const float *__restrict__ q, long q
         if (m < 0 || g == 0.0f) continue;
         const float t = 2.0f * g * (qv - k[(long)m * k_sm + (long)c * k_sc]);
         acc += t;
-        atomicAdd(gk + (long)m * gk_sm + (long)c * gk_sc, -t);
+        if (gk) atomicAdd(gk + (long)m * gk_sm + (long)c * gk_sc, -t);  // (NULL: the bank needs no gradient)
     }
-    gq[n * gq_sn + (long)c * gq_sc] = acc;
+    if (gq) gq[n * gq_sn + (long)c * gq_sc] = acc;
 }
 
 __global__ void zero_strided_kernel(float *__restrict__ p, long n0, long n1, long s0, long s1)
@@ -2729,10 +2729,10 @@ int manet_global_match_backward_f32(const float *query, int64_t q_stride_n, int6
 {
     int rc = check_common(N, M0, C, n_ids, 1, MANET_COMPUTE_F32);
     if (rc) return rc;
-    if (!query || !arg || !grad_out || !grad_query || (M0 > 0 && (!bank || !grad_bank)))
+    if (!query || !arg || !grad_out || (!grad_query && !grad_bank) || (M0 > 0 && !bank))
         return manet_set_error(MANET_E_INVALID, "null pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (M0 > 0) {
+    if (M0 > 0 && grad_bank) {
         long tb = (long)M0 * C;
         hipLaunchKernelGGL(zero_strided_kernel, dim3((unsigned)((tb + 255) / 256)), dim3(256), 0, st, grad_bank, (long)M0,
                            (long)C, (long)gb_stride_m, (long)gb_stride_c);

@@ -318,7 +318,8 @@ int manet_conv1x1_f32(const float *in, int64_t in_batch_stride, int B, int Cin, 
  *   grad_query[n] = sum_o 2 g (q_n - k_m*),  grad_bank[m] = sum over (n,o) with m* = m of 2 g (k_m - q_n)
  *   (d = |q|^2 + |k|^2 - 2 q.k, IntVOS.py:32-39).  Both gradient tensors take element strides and are
  *   fully overwritten (grad_bank is zeroed, then accumulated with atomicAdd: summation order is not
- *   deterministic, like torch's own scatter-add backward). */
+ *   deterministic, like torch's own scatter-add backward).  Either of grad_query / grad_bank may be NULL: that
+ *   gradient is not computed (a frozen reference frame needs no zero-fill and no scatter). */
 int manet_global_match_arg_workspace_bytes(int64_t N, int64_t M0, int C, int n_ids, size_t *bytes);
 int manet_global_match_arg_f32(const float *query, int64_t q_stride_n, int64_t q_stride_c,
                                const float *bank, int64_t b_stride_m, int64_t b_stride_c,
