@@ -1,23 +1,27 @@
 #!/bin/bash
-# Runs on the GPU box: the round's tracked evidence.  usage: tools/capture_profiles.sh RTAG   (e.g. r02)
-#   for each of: cfg2 f32 (headline), cfg3 bf16, cfg5 bf16
-#     profiles/RTAG_cfgN_<compute>_bench_line.json        un-profiled `python bench.py ...` line
-#     gpurun_out/RTAG_cfgN_<compute>/...                  rocprofv3 kernel stats + PMC passes (tools/profile_gpu.sh)
-# The caller copies the summaries from gpurun_out/ into profiles/ (gpurun merges only gpurun_out/ back).
+# Runs on the GPU box: the round's tracked evidence.  usage: tools/capture_profiles.sh RTAG   (e.g. r03)
+#   gpurun_out/RTAG/RTAG_bench_line.json                 the default `python bench.py` line (headline + `also` legs + cpu baseline)
+#   for each of: cfg2 f32 (headline), cfg3 bf16, cfg5 bf16, cfg3 bf16r (fp32-stored embeddings)
+#     gpurun_out/RTAG/RTAG_cfgN_<compute>_{bench_line_under_rocprof.json,kernel_stats.csv,pmc_summary.csv}
+#                                                        rocprofv3 kernel stats + separate --pmc passes (tools/profile_gpu.sh)
+#   gpurun_out/RTAG/RTAG_local_pmc_summary.csv           the local-window stage alone (tools/local_pmc.sh)
+# tools/publish_profiles.sh copies them into the tracked profiles/ and regenerates profiles/traffic_cfg*.json from the SAME
+# capture (the r2 bench lines quoted an older capture's traffic).
 R=$1
 mkdir -p gpurun_out/$R
-for c in "2 f32" "3 bf16" "5 bf16"; do
+python bench.py > gpurun_out/$R/${R}_bench_line.json 2> gpurun_out/$R/${R}_bench.err
+for c in "2 f32 auto" "3 bf16 auto" "5 bf16 auto" "3 bf16r f32"; do
   set -- $c
   tag=${R}_cfg$1_$2
-  if [ "$1" = "2" ]; then
-    python bench.py --cfg $1 --compute $2 --steps 40 > gpurun_out/$R/${tag}_bench_line.json 2> gpurun_out/$R/${tag}_bench.err
-  else
-    python bench.py --cfg $1 --compute $2 --steps 40 > gpurun_out/$R/${tag}_bench_line.json 2> gpurun_out/$R/${tag}_bench.err
-  fi
-  tools/profile_gpu.sh ${R}/$tag --cfg $1 --compute $2 --steps 20 > gpurun_out/$R/${tag}_profile.log 2>&1
+  tools/profile_gpu.sh ${R}/$tag --cfg $1 --compute $2 --emb $3 --steps 20 --no-also > gpurun_out/$R/${tag}_profile.log 2>&1
   cp gpurun_out/${R}/$tag/pmc_summary.csv gpurun_out/$R/${tag}_pmc_summary.csv
   cp $(find gpurun_out/${R}/$tag/stats -name "*kernel_stats.csv" | head -1) gpurun_out/$R/${tag}_kernel_stats.csv
   cp gpurun_out/${R}/$tag/bench_line_under_rocprof.json gpurun_out/$R/${tag}_bench_line_under_rocprof.json
   rm -rf gpurun_out/${R}/$tag/stats gpurun_out/${R}/$tag/pmc_*   # keep the merge small
-  tail -c 600 gpurun_out/$R/${tag}_bench_line.json | head -c 300; echo
+  head -c 300 gpurun_out/$R/${tag}_bench_line_under_rocprof.json; echo
 done
+tools/local_pmc.sh $R/local > gpurun_out/$R/${R}_local.log 2>&1
+cp gpurun_out/$R/local/pmc_summary.csv gpurun_out/$R/${R}_local_pmc_summary.csv
+tools/e2e_launch_count.sh $R/e2e > gpurun_out/$R/${R}_e2e.log 2>&1
+cp gpurun_out/$R/e2e/per_frame_kernels.csv gpurun_out/$R/${R}_e2e_per_frame_kernels.csv
+tail -3 gpurun_out/$R/${R}_e2e.log

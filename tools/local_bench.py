@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Local-window stage alone on synthetic 480p-grid embeddings (the configurations bench.py's cfg3 / cfg2 use):
-HIP-event time per call.  Run it under rocprofv3 (tools/local_pmc.sh) for per-kernel durations and PMC counters."""
+HIP-event time per call.  Run it under rocprofv3 (tools/local_pmc.sh: the program after `--` is python3, never this
+script itself) for per-kernel durations and PMC counters."""
 import os
 import sys
 
@@ -30,6 +31,14 @@ def main():
         torch.cuda.synchronize()
         print("d=%d %s n_ids=%d: %.1f us per call (pooling pass + fused kernel back to back from Python: HOST-bound at this size -- read kernel durations from rocprofv3, tools/local_pmc.sh)"
               % (d, str(dt).split(".")[-1], nid, e0.elapsed_time(e1) * 1e3 / reps))
+        # the prepared path of a propagation loop (r3): ONE frame prepare (query operand + pooled plane) + the fused kernel
+        # on the two prepared frames -- lf_pool_pad_kernel / pack_rows_kernel<32,32> are gone from the frame
+        emb_prev, emb_cur = prev.permute(2, 0, 1), cur.permute(2, 0, 1)
+        fprev = ops.prepare_frames(emb_prev, compute="f32" if dt == torch.float32 else "bf16", max_distance=d)
+        for _ in range(reps):
+            fcur = ops.prepare_frames(emb_cur, compute="f32" if dt == torch.float32 else "bf16", max_distance=d)
+            ops.local_match_frames(fprev, fcur, lab, nid)
+        torch.cuda.synchronize()
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ done
 cd $REPO
 cat $OUT/stats.log | grep "us per call"
 f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
-grep -E "local_fused|lf_pool" "$f" | cut -d, -f1-4 | cut -c1-150
+grep -E "local_fused|lf_pool|frame_prepare" "$f" | cut -d, -f1-4 | cut -c1-150
 python3 tools/pmc_summary.py $(find $OUT -path "*pmc_*" -name "*counter_collection.csv" | sort) > $OUT/pmc_summary.csv
-grep -E "local_fused|lf_pool|kernel,counter" $OUT/pmc_summary.csv
+grep -E "local_fused|lf_pool|frame_prepare|kernel,counter" $OUT/pmc_summary.csv
 rm -rf $OUT/pmc_*/ $OUT/stats

@@ -5,7 +5,9 @@ for gfx950: FETCH_SIZE (KiB) counts a wide coalesced stream at half its bytes ->
 usage: make_traffic_json.py gpurun_out/TAG/pmc_summary.csv KERNEL_SUBSTRING cfg compute "bench args" > out.json"""
 import csv
 import datetime
+import hashlib
 import json
+import os
 import subprocess
 import sys
 
@@ -27,8 +29,11 @@ def main():
         head = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
     except Exception:
         head = "unknown"
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cvpr2020_manet_amd", "csrc", "global_match.hip")
     json.dump({
         "kernel": name,
+        # bench.py compares this with the source of the library it runs: a mismatch marks the figure `stale`
+        "kernel_source_sha": hashlib.sha256(open(src, "rb").read()).hexdigest()[:12],
         "cfg": int(cfg), "compute": compute,
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_gpu.sh) of "
                   "`python3 bench.py %s --steps 6 --warmup 2 --no-cpu-baseline`; summary in %s" % (cmd, path),

@@ -11,7 +11,7 @@ csv.field_size_limit(1 << 30)
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"\s*([A-Za-z0-9_:]+(<[0-9, ]+>)?)", name)
+    m = re.match(r"\s*([A-Za-z0-9_:]+(<[0-9a-z_, ]+>)?)", name)
     return (m.group(1) if m else name)[:60]
 
 
