@@ -388,7 +388,7 @@ __global__ void lf_pool_pad_kernel(const SRC *__restrict__ a, long a_sy, long a_
 #ifdef MANET_LF_TIMELINE
 __device__ unsigned long long lf_dbg[8192 * 8];
 extern "C" int manet_dbg_read(unsigned long long *host, size_t n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(lf_dbg), n * 8); }
-#define LF_T(k) if (threadIdx.x == 0) lf_dbg[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64();
+#define LF_T(k) if (threadIdx.x == 0) lf_dbg[blockIdx.x * 8 + (k)] = wall_clock64();
 #else
 #define LF_T(k)
 #endif
@@ -397,7 +397,8 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
                                                                const float *__restrict__ prevp, int WS, long PS,
                                                                const int *__restrict__ labels, int h, int w, int C,
                                                                int n_ids, float *__restrict__ out,
-                                                               const int *__restrict__ tab, int abl)
+                                                               const int *__restrict__ tab, int abl, int ntx, int nty,
+                                                               int rw, int rh)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int P = 2 * D + 1, NT = lf_nt(D), ND = lf_nd(D), NDG = lf_ndg(D), SY = lf_sy(D), TY = SY - 1;
@@ -413,8 +414,16 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     const int tid = threadIdx.x;
     LF_T(0)
     const int hp = h / 2, wp = w / 2;
-    const int a = blockIdx.y * TY, b0 = blockIdx.x * TX;  // pooled origin of S
-    const int dy0 = blockIdx.z * ND;                       // first window row of this workgroup
+    // XCD-aware block -> (tile column, tile row, window-row group): block L runs on XCD L % 8 (observed, used for speed
+    // only), whose L2 serves the staging DMA.  Each XCD gets a compact rw x rh block of tiles (4 x 2 such regions cover the
+    // grid) with all their window-row groups: its L2 then holds about a fifth of each pooled plane (region + halo) instead
+    // of a full-height strip per tile column -- r3 PMC at 480p, d=12: the kernel's fabric fetch 33 -> 22 MB.
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tix = (xcd & 3) * rw + idx % rw, tmp_ = idx / rw;
+    const int tiy = (xcd >> 2) * rh + tmp_ % rh, tiz = tmp_ / rh;
+    if (tix >= ntx || tiy >= nty) return;  // (the regions' padding)
+    const int a = tiy * TY, b0 = tix * TX;  // pooled origin of S
+    const int dy0 = tiz * ND;               // first window row of this workgroup
 
     // ---- phase 1: distances on S for window rows dy0 .. dy0+ND-1 ---------------------------------
     // Staging by LDS-DMA (lds_dma16: 64 lanes x 16 bytes land in 1 KiB of LDS, no VGPR hop, no ds_write): a stage is
@@ -566,8 +575,8 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     LF_T(1)
     // full-resolution pixels of this tile: rows with i0(y) in [a, a+TY), columns with j0(x) in [b0, b0+TX) -- the
     // pooling pass left the ranges in `tab`
-    const int ya = tab[blockIdx.y], yb = tab[blockIdx.y + 1];
-    const int xa = tab[gridDim.y + 1 + blockIdx.x], xb = tab[gridDim.y + 2 + blockIdx.x];
+    const int ya = tab[tiy], yb = tab[tiy + 1];
+    const int xa = tab[nty + 1 + tix], xb = tab[nty + 2 + tix];
     const int ny = yb - ya, nx = xb - xa;
     if (ny > 2 * TY + 4 || nx > 2 * TX + 4) __builtin_trap();  // cannot happen (ratio (hp-1)/(h-1) < 1/2): fail loudly, never overrun L
     // the previous frame's labels around the tile: rows ya + 2(dy0 - D) .., columns xa - 2D ..; outside the image = 0
@@ -718,11 +727,13 @@ static void launch_fused_d(hipStream_t st, const float *ap, const float *bp, con
 {
     constexpr int TY = lf_sy(D) - 1, TX = LF_SX - 1;
     // i0 runs over 0..hp-1 (the last value only for the last row); tiles cover all of them
-    dim3 grid((unsigned)((G.wp + TX - 1) / TX), (unsigned)((G.hp + TY - 1) / TY), (unsigned)lf_ndg(D));
+    const int ntx = (G.wp + TX - 1) / TX, nty = (G.hp + TY - 1) / TY;
+    const int rw = (ntx + 3) / 4, rh = (nty + 1) / 2;  // tiles per XCD region (4 x 2 regions)
+    dim3 grid((unsigned)(8 * rw * rh * lf_ndg(D)));
     const size_t lds = lf_lds_bytes(D);
     (void)hipFuncSetAttribute((const void *)local_fused_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(local_fused_kernel<D>, grid, dim3(lf_nt(D)), lds, st, ap, bp, G.WS, G.plane, labels, h, w, C, n_ids,
-                       out, tab, manet_tune_get(MANET_TUNE_ABLATION, 0));
+                       out, tab, manet_tune_get(MANET_TUNE_ABLATION, 0), ntx, nty, rw, rh);
 }
 
 __global__ void fill_f32_kernel(float *__restrict__ p, float v, long n)

@@ -245,7 +245,9 @@ constexpr int PW_P = 64, PW_KC = 16, PW_CO = 256, PW_NT = 256;
 __global__ __launch_bounds__(PW_NT, 3) void conv1x1_mfma_kernel(const float *__restrict__ in, long in_bs, int Cin, long HW,
                                                                 const float *__restrict__ w2t,
                                                                 const float *__restrict__ b2, int relu_out,
-                                                                float *__restrict__ out)
+                                                                float *__restrict__ out, const float *__restrict__ head_w,
+                                                                const float *__restrict__ head_b,
+                                                                float *__restrict__ head_out)
 {
     __shared__ __attribute__((aligned(1024))) float wbuf[2][PW_KC * PW_CO];
     __shared__ __attribute__((aligned(1024))) float xbuf[2][PW_KC * PW_P];
@@ -315,6 +317,35 @@ __global__ __launch_bounds__(PW_NT, 3) void conv1x1_mfma_kernel(const float *__r
         __syncthreads();
     }
     // C/D layout: column = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (output channel)
+    if (head_w) {
+        // DynamicSegHead's output layer fused in (IntVOS.py:519,525: conv = Conv2d(256, 1, 1) on layer4's ReLU output):
+        //   head_out[b][p] = head_b + sum_co head_w[co] * max(acc[co][p] + b2[co], 0)
+        // the [B,256,h,w] activation of layer4 is neither written nor read back.  Per pixel: each lane sums its 32
+        // channels (ascending fmaf chain), the two lane halves meet by a shuffle, the four waves in LDS.
+        float *red = &xbuf[0][0];  // (free: everyone is past the loop's last barrier)
+        float sp[2];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            float a = 0.0f;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    a = fmaf(fmaxf(acc[cb][pb][r] + bsh[co], 0.0f), head_w[co], a);
+                }
+            sp[pb] = a + __shfl_xor(a, 32);
+        }
+        if (lane < 32) {
+            red[wave * PW_P + lane] = sp[0];
+            red[wave * PW_P + 32 + lane] = sp[1];
+        }
+        __syncthreads();
+        if (tid < PW_P && p0 + tid < HW)
+            head_out[(long)b * HW + p0 + tid] =
+                ((red[tid] + red[PW_P + tid]) + (red[2 * PW_P + tid] + red[3 * PW_P + tid])) + (head_b ? head_b[0] : 0.0f);
+        return;
+    }
     float *dst = out + (long)b * PW_CO * HW;
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
@@ -373,7 +404,15 @@ extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, 
 extern "C" int manet_conv1x1_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const float *w2t,
                                  const float *b2, int Cout, int relu_out, float *out, manet_stream_t stream)
 {
-    if (!in || !w2t || !b2 || !out || B <= 0 || B > 65535 || Cin <= 0 || HW <= 0)
+    return manet_conv1x1_head_f32(in, in_batch_stride, B, Cin, HW, w2t, b2, Cout, relu_out, out, nullptr, nullptr, nullptr, stream);
+}
+
+// ... optionally with DynamicSegHead's output layer fused into the epilogue (head_w != NULL: `out` is not written)
+extern "C" int manet_conv1x1_head_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const float *w2t,
+                                      const float *b2, int Cout, int relu_out, float *out, const float *head_w,
+                                      const float *head_b, float *head_out, manet_stream_t stream)
+{
+    if (!in || !w2t || !b2 || (!out && !head_w) || (head_w && !head_out) || B <= 0 || B > 65535 || Cin <= 0 || HW <= 0)
         return manet_set_error(MANET_E_INVALID, "bad arguments");
     if (Cout != PW_CO) return manet_set_error(MANET_E_INVALID, "Cout=%d (this kernel is built for %d output channels)", Cout, PW_CO);
     if (Cin % 4 != 0 || HW % 4 != 0 || HW < 4)
@@ -382,6 +421,6 @@ extern "C" int manet_conv1x1_f32(const float *in, int64_t in_batch_stride, int B
         return manet_set_error(MANET_E_INVALID, "in / w2t must be 16-byte aligned, the batch stride a multiple of 4 elements");
     dim3 grid((unsigned)((HW + PW_P - 1) / PW_P), (unsigned)B);
     hipLaunchKernelGGL(conv1x1_mfma_kernel, grid, dim3(PW_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin, (long)HW,
-                       w2t, b2, relu_out, out);
+                       w2t, b2, relu_out, out, head_w, head_b, head_out);
     return manet_check_launch("manet_conv1x1_f32");
 }

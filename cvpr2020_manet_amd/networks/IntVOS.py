@@ -252,14 +252,19 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         z = F.conv2d(y, k[w], k["b2"] if bias else None)
         return z.relu_() if relu else z
 
-    def forward(self, x, relu_in=False, defer_relu=False):
+    def forward(self, x, relu_in=False, defer_relu=False, head=None):
         """relu_in / defer_relu (inference fast path only, used by DynamicSegHead): the block's last ReLU is left to the
         NEXT block, whose fused depthwise kernel reads its input through max(x, 0) -- one elementwise pass over the
-        activation less per block, same values."""
+        activation less per block, same values.  head = (weight, bias) of DynamicSegHead's output layer: fused into this
+        block's 1x1 kernel when it runs on the MFMA path (returns [B, 1, h, w]), else applied behind it."""
         if self._fast(x):
             k = self._folded()
             x = ops.dwconv7x7_bn_relu(x, self.conv1.weight, self.conv1.bias, scale=k["scale1"], shift=k["shift1"],
                                       relu_in=relu_in)
+            if head is not None:
+                if "w2t" in k and ops.conv1x1_mfma_ok(x, self.conv2.out_channels):
+                    return ops.conv1x1_mfma(x, k["w2t"], k["b2"], head_weight=head[0], head_bias=head[1])
+                return ops.relu_conv1x1_c1(self._pointwise(x, k, "all", True, False), head[0], head[1])
             return self._pointwise(x, k, "all", True, not defer_relu)
         assert not relu_in and not defer_relu
         x = self.relu1(self.bn1(self.conv1(x)))
@@ -300,8 +305,9 @@ class DynamicSegHead(nn.Module):  # reference IntVOS.py:509-525
         x = self.layer2(x, relu_in=True, defer_relu=True)
         x = self.layer3(x, relu_in=True, defer_relu=True)
         if self.conv.kernel_size == (1, 1) and self.conv.out_channels == 1:
-            # output layer fused with layer4's ReLU: one pass over the activation (ops.relu_conv1x1_c1)
-            return ops.relu_conv1x1_c1(self.layer4(x, relu_in=True, defer_relu=True), self.conv.weight, self.conv.bias)
+            # output layer fused with layer4's ReLU -- into the epilogue of layer4's own 1x1 kernel when that runs on the
+            # MFMA path (layer4's activation is never written), else one pass over it (ops.relu_conv1x1_c1)
+            return self.layer4(x, relu_in=True, defer_relu=True, head=(self.conv.weight, self.conv.bias))
         return self.conv(self.layer4(x, relu_in=True))
 
     def forward(self, x):

@@ -588,10 +588,12 @@ def conv1x1_mfma_ok(x, cout):
             and x.shape[2] * x.shape[3] >= 4)
 
 
-def conv1x1_mfma(x, w2t, b2, relu_out=False):
+def conv1x1_mfma(x, w2t, b2, relu_out=False, head_weight=None, head_bias=None):
     """conv2 -> bn2 [-> relu2] of a _split_separable_conv2d block (IntVOS.py:494,503-505) as an fp32-MFMA contraction fed by
-    LDS-DMA (manet_conv1x1_f32).  x [B, Cin, h, w] fp32; w2t [Cin, 256], b2 [256] from fold_pointwise -> [B, 256, h, w]."""
-    _refuse_autograd("conv1x1_mfma", x, w2t, b2)
+    LDS-DMA (manet_conv1x1_f32).  x [B, Cin, h, w] fp32; w2t [Cin, 256], b2 [256] from fold_pointwise -> [B, 256, h, w].
+    head_weight [1, 256, 1, 1] (+ head_bias [1]): DynamicSegHead's output layer Conv2d(256, 1, 1)(relu(.)) (IntVOS.py:519,525)
+    fused into the epilogue -- returns [B, 1, h, w], the 256-channel activation is never written."""
+    _refuse_autograd("conv1x1_mfma", x, w2t, b2, head_weight, head_bias)
     lib = _lib.load()
     _need_gpu(x, "x")
     x = x.float().contiguous()
@@ -601,6 +603,18 @@ def conv1x1_mfma(x, w2t, b2, relu_out=False):
     if not conv1x1_mfma_ok(x, PW_COUT):
         raise ValueError("conv1x1_mfma needs Cin and h*w to be multiples of 4")
     w2t, b2 = w2t.detach().float().contiguous(), b2.detach().float().contiguous()
+    if head_weight is not None:
+        if head_weight.numel() != PW_COUT:
+            raise ValueError("head_weight must be [1, %d, 1, 1]" % PW_COUT)
+        hw = head_weight.detach().float().contiguous()
+        hb = None if head_bias is None else head_bias.detach().float().contiguous()
+        hout = torch.empty((B, 1, h, w), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.manet_conv1x1_head_f32(x.data_ptr(), cin * h * w, B, cin, h * w, w2t.data_ptr(), b2.data_ptr(), PW_COUT,
+                                            0, None, hw.data_ptr(), None if hb is None else hb.data_ptr(), hout.data_ptr(),
+                                            _stream_ptr(x.device))
+        _lib.check(rc, "manet_conv1x1_head_f32")
+        return hout
     out = torch.empty((B, PW_COUT, h, w), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         rc = lib.manet_conv1x1_f32(x.data_ptr(), cin * h * w, B, cin, h * w, w2t.data_ptr(), b2.data_ptr(), PW_COUT,

@@ -302,6 +302,13 @@ int manet_relu_conv1x1_c1_f32(const float *in, int B, int C, long HW, const floa
  * The sum is the ascending-channel fp32 fmaf chain of v_mfma_f32_32x32x2_f32. */
 int manet_conv1x1_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const float *w2t,
                       const float *b2, int Cout, int relu_out, float *out, manet_stream_t stream);
+/* The same with DynamicSegHead's output layer (networks/IntVOS.py:519,525: Conv2d(256, 1, 1) on layer4's ReLU output) fused
+ * into the epilogue when head_w != NULL:  head_out[b][p] = head_b[0] + sum_co head_w[co] * max(out[b][co][p], 0);
+ * `out` is then NOT written (layer4's [B,256,h,w] activation never leaves the compute units); head_w [Cout], head_b [1] or
+ * NULL, head_out [B][HW].  head_w == NULL: exactly manet_conv1x1_f32. */
+int manet_conv1x1_head_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const float *w2t,
+                           const float *b2, int Cout, int relu_out, float *out, const float *head_w,
+                           const float *head_b, float *head_out, manet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Training path: what torch.autograd does for the reference's pure-PyTorch path

@@ -289,3 +289,37 @@ def test_cfg_defaults_equal_reference():
     assert mine == ref
     assert make_cfg([]).MODEL_MATCH_COMPUTE == "f32" and make_cfg([]).MODEL_EMB_DTYPE == "f32"
     assert make_cfg(["--TEST_MODE", "True", "--unknown-flag", "1"]).TEST_MODE is True
+
+
+def test_constructor_switches_and_cache_hooks_on_cpu():
+    """IntVOS(cfg, fe, compute=..., emb_dtype=...) / cfg.MODEL_MATCH_COMPUTE / cfg.MODEL_EMB_DTYPE, and
+    the cache invalidation hooks: host logic only, no device work."""
+    from cvpr2020_manet_amd.config import make_cfg
+    from cvpr2020_manet_amd.networks import IntVOS as M
+    m = M.IntVOS(tiny_cfg(), TinyExtractor())
+    assert m.compute == "f32" and m.emb_dtype == torch.float32
+    m = M.IntVOS(tiny_cfg(), TinyExtractor(), compute="bf16r", emb_dtype="bf16")
+    assert m.compute == "bf16r" and m.emb_dtype == torch.bfloat16
+    cfg = make_cfg(["--TEST_MODE", "True", "--MODEL_SEMANTIC_EMBEDDING_DIM", "12", "--MODEL_HEAD_EMBEDDING_DIM", "8",
+                    "--MODEL_ASPP_OUTDIM", "6", "--MODEL_MATCH_COMPUTE", "bf16x3", "--MODEL_EMB_DTYPE", "bf16"])
+    m = M.IntVOS(cfg, TinyExtractor())
+    assert m.compute == "bf16x3" and m.emb_dtype == torch.bfloat16
+    ref_cfg = argparse.Namespace(**{k: v for k, v in vars(tiny_cfg()).items()
+                                    if k not in ("MODEL_MATCH_COMPUTE", "MODEL_EMB_DTYPE")})
+    assert M.IntVOS(ref_cfg, TinyExtractor()).compute == "f32"  # a reference cfg object without the extension flags
+    with pytest.raises(ValueError):
+        M.IntVOS(tiny_cfg(), TinyExtractor(), compute="fp8")
+    with pytest.raises(ValueError):
+        M.IntVOS(tiny_cfg(), TinyExtractor(), emb_dtype="f16")
+    # extract_feature stores in emb_dtype (inference), keeps fp32 under autograd
+    with torch.no_grad():
+        assert m.extract_feature(torch.zeros(1, 3, 16, 16)).dtype == torch.bfloat16
+    assert m.extract_feature(torch.zeros(1, 3, 16, 16)).dtype == torch.float32
+    # the identity-keyed caches are dropped by train(), load_state_dict(), _apply() and invalidate_caches()
+    for hook in (lambda: m.train(), lambda: m.eval(), lambda: m.load_state_dict(m.state_dict()), lambda: m.float(),
+                 m.invalidate_caches):
+        m._bank_cache["s"] = ("key", None)
+        m._frame_cache["k"] = object()
+        m.dynamic_seghead.layer1._fold_cache = ("stale", {})
+        hook()
+        assert not m._bank_cache and not m._frame_cache and m.dynamic_seghead.layer1._fold_cache is None

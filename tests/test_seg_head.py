@@ -182,3 +182,25 @@ def test_mfma_pointwise_vs_framework_conv_and_literal_module():
         torch.testing.assert_close(shared, lit, rtol=1e-3, atol=1e-3)
         with pytest.raises(ValueError):
             ops.conv1x1_mfma(torch.randn(1, 6, 4, 4, device="cuda"), torch.zeros(6, 256, device="cuda"), b2)
+        # the head's output layer fused into layer4's pointwise kernel: Conv2d(256, 1, 1)(relu(z)) without z in memory
+        x = torch.randn(3, 256, 27, 36, device="cuda")
+        w2t = torch.randn(256, 256, device="cuda") * 0.05
+        b2 = torch.randn(256, device="cuda")
+        fin = torch.nn.Conv2d(256, 1, 1).cuda()
+        z = ops.conv1x1_mfma(x, w2t, b2)
+        torch.testing.assert_close(ops.conv1x1_mfma(x, w2t, b2, head_weight=fin.weight, head_bias=fin.bias), fin(torch.relu(z)),
+                                   rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(ops.conv1x1_mfma(x, w2t, b2, head_weight=fin.weight), fin(torch.relu(z)) - fin.bias.view(1, 1, 1, 1),
+                                   rtol=1e-4, atol=1e-4)
+        # the whole 256-channel head: fast path (dw kernels, MFMA 1x1, fused output layer) vs the reference's literal chain
+        head = M.DynamicSegHead(in_dim=103, embed_dim=256).cuda().eval()
+        for m in head.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 2.0); m.weight.data.normal_(1, 0.1); m.bias.data.normal_(0, 0.1)
+        xs = torch.randn(2, 103, 24, 30, device="cuda")
+        ref = xs
+        for layer in (head.layer1, head.layer2, head.layer3, head.layer4):
+            ref = layer.relu2(layer.bn2(layer.conv2(layer.relu1(layer.bn1(layer.conv1(ref))))))
+        ref = head.conv(ref)
+        scale = float(ref.abs().max())
+        torch.testing.assert_close(head(xs), ref, rtol=1e-3, atol=1e-3 * max(scale, 1.0))
