@@ -191,9 +191,10 @@ def run_leg(wl, K, Wm, args, lib, use_dist=False, one_shot=False, prepacked=Fals
     if prepacked:  # the producer's job: every resident frame prepared when its embedding was produced
         prepared_all = ops.prepare_frames(wl.local_emb, compute=wl.compute, max_distance=wl.d)
 
-    def prepare(bank_rows, bank_lab):
-        """the clip's one-off: sort + pack the memory bank (None in --one-shot mode)"""
-        return None if one_shot else ops.PreparedBank(bank_rows, bank_lab, wl.n_ids, compute=wl.compute)
+    def prepare(bank_rows, bank_lab, old=None):
+        """the clip's one-off: sort + pack the memory bank (None in --one-shot mode); a new clip takes over the previous
+        bank's workspace, as the drop-in module does between interaction rounds"""
+        return None if one_shot else ops.PreparedBank(bank_rows, bank_lab, wl.n_ids, compute=wl.compute, reuse=old)
 
     preset = wl.d >= 11  # the fused local kernel of wide windows wants `out` pre-set to 1.0: rides in the prepare launch
     state = {"prev": None}
@@ -257,7 +258,7 @@ def run_leg(wl, K, Wm, args, lib, use_dist=False, one_shot=False, prepacked=Fals
     barrier()
     t0 = time.perf_counter()
     bank_rows, bank_lab, halo = build_bank(True)
-    bank = prepare(bank_rows, bank_lab)
+    bank = prepare(bank_rows, bank_lab, bank)
     first_prev(halo)
     for i in range(K):
         step(i, bank, bank_rows, bank_lab, halo)
@@ -500,7 +501,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every CPU-oracle leg (baseline + parity)")
     ap.add_argument("--no-also", action="store_true", help="skip the extra cfg3 / cfg5 bf16 legs of the N=1 line")
-    ap.add_argument("--also-steps", type=int, default=10)
+    ap.add_argument("--also-steps", type=int, default=40)
     ap.add_argument("--tune", type=str, default="", help="experiments only: key=value,... for manet_tune_set")
     ap.add_argument("--compute", type=str, default="f32", choices=["f32", "bf16", "bf16x3", "bf16r"],
                     help="arithmetic of the QK^T contraction (headline = f32, BASELINE configs[1])")

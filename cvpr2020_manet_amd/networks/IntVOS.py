@@ -400,7 +400,8 @@ class IntVOS(nn.Module):
         if hit is not None and hit[0] == key:
             self._bank_cache.move_to_end(seq_name)
             return hit[1]
-        bank = ops.PreparedBank(ref_emb_hwc, ref_lab_flat, n_ids, compute=self.compute)
+        bank = ops.PreparedBank(ref_emb_hwc, ref_lab_flat, n_ids, compute=self.compute,
+                                reuse=hit[1] if hit is not None else None)  # (the stale bank's workspace is taken over)
         # keep the keyed tensors alive so that their storage pointers cannot be recycled under the key
         self._bank_cache[seq_name] = (key, bank, ref_emb_chw, ref_label)
         self._bank_cache.move_to_end(seq_name)

@@ -172,7 +172,9 @@ class PreparedBank:
     """A memory bank sorted by object id and packed for the MFMA loop, reusable across frames
     (test.py:237-259 matches every frame of a clip against the same annotated frame)."""
 
-    def __init__(self, reference_embeddings, reference_labels, n_ids, compute="f32"):
+    def __init__(self, reference_embeddings, reference_labels, n_ids, compute="f32", reuse=None):
+        """reuse: a PreparedBank that is no longer needed -- its workspace is taken over when it is large enough (a new
+        interaction round re-prepares a bank of the same size: no 50-100 MB allocation per round)"""
         import ctypes
         _refuse_autograd("PreparedBank", reference_embeddings)
         lib = _lib.load()
@@ -185,7 +187,11 @@ class PreparedBank:
         nbytes = ctypes.c_size_t(0)
         _lib.check(lib.manet_bank_workspace_bytes(M0, C, n_ids, self.compute, ctypes.byref(nbytes)),
                    "manet_bank_workspace_bytes")
-        self.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+        old = getattr(reuse, "ws", None)
+        if old is not None and old.device == self.device and old.numel() >= nbytes.value:
+            self.ws, reuse.ws = old, None
+        else:
+            self.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
             rc = lib.manet_bank_prepare_ex(ref.data_ptr(), _emb_code(ref), ref.stride(0) if M0 > 0 else C,
                                            ref.stride(1) if M0 > 0 else 1, lab.data_ptr(), M0, C, n_ids,
