@@ -363,6 +363,190 @@ __global__ __launch_bounds__(PW_NT, 3) void conv1x1_mfma_kernel(const float *__r
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same 1x1 stage in SPLIT-bf16 arithmetic (r3b): every fp32 factor is taken as hi + lo, two bf16 pieces (16
+// significand bits), and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the
+// dropped lo*lo term and the pieces' own rounding are <= 2^-16 relative per product (measured against the fp32-MFMA kernel:
+// tests/test_seg_head.py; for comparison, the reference's cuDNN path runs these layers in TF32 -- 10 significand bits --
+// wherever torch.backends.cudnn.allow_tf32 is left at its default).  The bf16 pipe retires a 32x32x16 block in 8 passes,
+// so the three products cost 3/16 of the fp32 pipe's time for the same block: the stage stops being matrix-bound
+// (fp32 kernel: 68 us of MFMA in a 111 us launch at 3 objects) and becomes what a 1x1 layer should be -- a stream: read
+// the activation once, write it once.
+//   workgroup = 128 pixels x 256 output channels, 4 waves = (pixel half) x (channel half), 128 accumulators per lane;
+//   weights: packed ONCE per fold (conv1x1_x3_pack_kernel) as the MFMA A operand, hi and lo, 16 KiB per 16 input channels,
+//     LDS-DMA'd chunk by chunk (shared by the 4 waves);
+//   activation: LDS-DMA'd as fp32 rows [16 k][128 px]; each lane reads its 8 k of a pixel column and splits them in
+//     registers (v_cvt_pk_bf16_f32: 5 VALU per pair) -- the depthwise kernel keeps writing plain fp32.
+//   any Cin >= 1 (rows past Cin are clamped reads against zero weight rows); h*w a multiple of 4 (16-byte DMA rows).
+//   `add` (layer1's shared-embedding half, [256][HW], the same for every batch entry) and the bias join in the epilogue.
+constexpr int X3_P = 128, X3_KC = 16, X3_NT = 256, X3_WCHUNK = 2 * 8 * 1024, X3_NB = 3;
+typedef __bf16 x3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void x3_split(float x0, float x1, unsigned &hi, unsigned &lo)
+{
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0, x1}, x3_bf16x2));
+    const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0 - h0, x1 - h1}, x3_bf16x2));
+}
+
+// w2t [Cin][256] fp32 -> A-operand image [chunk][hi | lo][co block 8][lane 64] x 16 bytes; lane l of block b holds
+// output channel 32 b + (l & 31), input channels 16 chunk + 8 (l >> 5) + 0..7 (zero past Cin)
+__global__ __launch_bounds__(256) void conv1x1_x3_pack_kernel(const float *__restrict__ w2t, int Cin, uint4 *__restrict__ wpk, int n_chunks)
+{
+    const int item = blockIdx.x * 256 + threadIdx.x;  // (chunk, block, lane)
+    if (item >= n_chunks * 8 * 64) return;
+    const int lane = item & 63, blk = (item >> 6) & 7, c = item >> 9;
+    const int co = 32 * blk + (lane & 31), k0 = 16 * c + 8 * (lane >> 5);
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ka = k0 + 2 * j, kb = ka + 1;
+        const float a = ka < Cin ? w2t[(long)ka * PW_CO + co] : 0.0f, b = kb < Cin ? w2t[(long)kb * PW_CO + co] : 0.0f;
+        x3_split(a, b, hi[j], lo[j]);
+    }
+    uint4 *dst = wpk + (long)c * (X3_WCHUNK / 16) + blk * 64 + lane;
+    dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    dst[8 * 64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+template <int ABL>
+__global__ __launch_bounds__(X3_NT, 2) void conv1x1_x3_kernel(const float *__restrict__ in, long in_bs, int Cin, long HW,
+                                                              const char *__restrict__ wpk, const float *__restrict__ b2,
+                                                              const float *__restrict__ add, int relu_out,
+                                                              float *__restrict__ out, const float *__restrict__ head_w,
+                                                              const float *__restrict__ head_b, float *__restrict__ head_out)
+{
+    __shared__ __attribute__((aligned(1024))) char wbuf[X3_NB][X3_WCHUNK];
+    __shared__ __attribute__((aligned(1024))) float xbuf[X3_NB][X3_KC * X3_P];
+    __shared__ float bsh[PW_CO];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave & 1, wc = wave >> 1;  // pixel half, output-channel half
+    const long p0 = (long)blockIdx.x * X3_P;
+    const int b = blockIdx.y;
+    const float *src = in + (long)b * in_bs;
+    const int n = (Cin + X3_KC - 1) / X3_KC;
+    const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&wbuf[0][0]);
+    const unsigned xbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&xbuf[0][0]);
+    long pix = p0 + 4 * (lane & 31);
+    if (pix > HW - 4) pix = HW - 4;  // the plane's last tile: clamped columns are computed and never stored
+    // chunk c -> ring slot c % X3_NB; 6 pieces per wave (4 weight + 2 activation).  Chunks are fetched TWO steps ahead and
+    // a step waits with vmcnt(6) -- the chunk issued in this step stays in flight: a step's matrix work (~0.6 us) is
+    // shorter than a fetch, even of the L2-resident weights (first form, one step ahead with vmcnt(0): every step waited
+    // out a whole fetch, 54 us).
+    auto dma = [&](int c) __attribute__((always_inline)) {
+        const unsigned slot = (unsigned)(c % X3_NB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave * 4 + i;
+            lds_dma16(wpk + (long)c * X3_WCHUNK + piece * 1024 + lane * 16, wbase + slot * (unsigned)X3_WCHUNK + (unsigned)piece * 1024u);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave * 2 + i;  // input rows 2 piece, 2 piece + 1 of the chunk
+            int row = c * X3_KC + 2 * piece + (lane >> 5);
+            row = row < Cin ? row : Cin - 1;  // past Cin: any finite row (its weights are zero)
+            lds_dma16(src + (long)row * HW + pix, xbase + slot * (unsigned)(X3_KC * X3_P * 4) + (unsigned)piece * 1024u);
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    bsh[tid] = b2[tid];
+    dma(0);
+    if (n > 1) {
+        dma(1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#define X3_MFMA(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3_bf16x8, a_), __builtin_bit_cast(x3_bf16x8, b_), c_, 0, 0, 0)
+    for (int c = 0; c < n; ++c) {
+        const bool more = c + 2 < n;
+        if (more && !(ABL & 4)) dma(c + 2);  // (its slot was last read in iteration c - 1: everyone is past that barrier)
+        if (ABL & 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            continue;
+        }
+        const float *X = &xbuf[c % X3_NB][8 * (lane >> 5) * X3_P + wq * 64 + (lane & 31)];
+        uint4 bh[2], bl[2];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = X[j * X3_P + pb * 32];
+            x3_split(v[0], v[1], bh[pb].x, bl[pb].x);
+            x3_split(v[2], v[3], bh[pb].y, bl[pb].y);
+            x3_split(v[4], v[5], bh[pb].z, bl[pb].z);
+            x3_split(v[6], v[7], bh[pb].w, bl[pb].w);
+        }
+        const uint4 *W = (const uint4 *)&wbuf[c % X3_NB][0] + (wc * 4) * 64 + lane;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const uint4 ah = W[blk * 64], al = W[(8 + blk) * 64];
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                X3_MFMA(ah, bl[pb], acc[blk][pb]);
+                X3_MFMA(al, bh[pb], acc[blk][pb]);
+                X3_MFMA(ah, bh[pb], acc[blk][pb]);
+            }
+        }
+        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef X3_MFMA
+    // C/D layout: column = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (output channel)
+    const int co0 = wc * 128;
+    if (head_w) {  // DynamicSegHead's output layer fused in (see conv1x1_mfma_kernel)
+        float *red = &xbuf[0][0];
+        float sp[2];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            float a = 0.0f;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    a = fmaf(fmaxf(acc[cb][pb][r] + bsh[co], 0.0f), head_w[co], a);
+                }
+            sp[pb] = a + __shfl_xor(a, 32);
+        }
+        if (lane < 32) {
+            red[wc * X3_P + wq * 64 + lane] = sp[0];
+            red[wc * X3_P + wq * 64 + 32 + lane] = sp[1];
+        }
+        __syncthreads();
+        if (tid < X3_P && p0 + tid < HW)
+            head_out[(long)b * HW + p0 + tid] = (red[tid] + red[X3_P + tid]) + (head_b ? head_b[0] : 0.0f);
+        return;
+    }
+    float *dst = out + (long)b * PW_CO * HW;
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        const long p = p0 + wq * 64 + pb * 32 + (lane & 31);
+        if (p >= HW || ((ABL & 1) && acc[0][pb][0] != 12345.0f)) continue;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[cb][pb][r] + bsh[co];
+                if (add) v += add[(long)co * HW + p];
+                if (relu_out) v = fmaxf(v, 0.0f);
+                dst[(long)co * HW + p] = v;
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int manet_relu_conv1x1_c1_f32(const float *in, int B, int C, long HW, const float *weight, const float *bias,
@@ -423,4 +607,47 @@ extern "C" int manet_conv1x1_head_f32(const float *in, int64_t in_batch_stride, 
     hipLaunchKernelGGL(conv1x1_mfma_kernel, grid, dim3(PW_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin, (long)HW,
                        w2t, b2, relu_out, out, head_w, head_b, head_out);
     return manet_check_launch("manet_conv1x1_f32");
+}
+
+// bytes of the packed split-bf16 weight image of a [Cin][256] 1x1 layer (manet_conv1x1_x3_pack)
+extern "C" int64_t manet_conv1x1_x3_weight_bytes(int Cin) { return Cin <= 0 ? 0 : (int64_t)((Cin + X3_KC - 1) / X3_KC) * X3_WCHUNK; }
+
+extern "C" int manet_conv1x1_x3_pack(const float *w2t, int Cin, int Cout, void *wpk, manet_stream_t stream)
+{
+    if (!w2t || !wpk || Cin <= 0) return manet_set_error(MANET_E_INVALID, "bad arguments");
+    if (Cout != PW_CO) return manet_set_error(MANET_E_INVALID, "Cout=%d (this kernel is built for %d output channels)", Cout, PW_CO);
+    if (((size_t)wpk & 15) != 0) return manet_set_error(MANET_E_INVALID, "wpk must be 16-byte aligned");
+    const int n = (Cin + X3_KC - 1) / X3_KC;
+    hipLaunchKernelGGL(conv1x1_x3_pack_kernel, dim3((unsigned)(n * 2)), dim3(256), 0, (hipStream_t)stream, w2t, Cin, (uint4 *)wpk, n);
+    return manet_check_launch("manet_conv1x1_x3_pack");
+}
+
+// 1x1 convolution with 256 output channels in split-bf16 arithmetic (conv1x1_x3_kernel); add: optional [256][HW] term
+// shared by every batch entry; head_w != NULL: DynamicSegHead's output layer fused (`out` is not written)
+extern "C" int manet_conv1x1_x3_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const void *wpk,
+                                    const float *b2, const float *add, int Cout, int relu_out, float *out, const float *head_w,
+                                    const float *head_b, float *head_out, manet_stream_t stream)
+{
+    if (!in || !wpk || !b2 || (!out && !head_w) || (head_w && !head_out) || B <= 0 || B > 65535 || Cin <= 0 || HW <= 0)
+        return manet_set_error(MANET_E_INVALID, "bad arguments");
+    if (Cout != PW_CO) return manet_set_error(MANET_E_INVALID, "Cout=%d (this kernel is built for %d output channels)", Cout, PW_CO);
+    if (HW % 4 != 0 || HW < 4) return manet_set_error(MANET_E_INVALID, "HW=%lld must be a multiple of 4 (16-byte LDS-DMA rows)", (long long)HW);
+    if (((size_t)wpk & 15) != 0 || ((size_t)in & 15) != 0 || (in_batch_stride & 3) != 0)
+        return manet_set_error(MANET_E_INVALID, "in / wpk must be 16-byte aligned, the batch stride a multiple of 4 elements");
+    if (head_w && add) return manet_set_error(MANET_E_INVALID, "add and the fused output layer are exclusive");
+    dim3 grid((unsigned)((HW + X3_P - 1) / X3_P), (unsigned)B);
+#define X3_LAUNCH(A_)                                                                                                        \
+    hipLaunchKernelGGL(conv1x1_x3_kernel<A_>, grid, dim3(X3_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin, (long)HW, \
+                       (const char *)wpk, b2, add, relu_out, out, head_w, head_b, head_out)
+    switch (manet_tune_get(MANET_TUNE_ABLATION, 0)) {  // timing experiments only (tools/pw_bench.py)
+    case 1: X3_LAUNCH(1); break;
+    case 2: X3_LAUNCH(2); break;
+    case 3: X3_LAUNCH(3); break;
+    case 4: X3_LAUNCH(4); break;
+    case 6: X3_LAUNCH(6); break;
+    case 7: X3_LAUNCH(7); break;
+    default: X3_LAUNCH(0);
+    }
+#undef X3_LAUNCH
+    return manet_check_launch("manet_conv1x1_x3_f32");
 }

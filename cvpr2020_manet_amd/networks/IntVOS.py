@@ -42,9 +42,17 @@ WRONG_LABEL_PADDING_DISTANCE = 1e20
 # IntVOS(cfg, ...) re-binds it to the cfg it is given.
 cfg = _default_cfg
 
-# the heads' 1x1 convolutions on the fp32-MFMA kernel (ops.conv1x1_mfma) when they have 256 output channels; False = the
-# framework's GEMM as in r2 (A/B switch: examples/propagate_clip.py --framework-gemm)
-MFMA_POINTWISE = True
+# the heads' 1x1 convolutions with 256 output channels (inference fast path):
+#   "split" : split-bf16 MFMA kernel (ops.conv1x1_split: fp32 factors as hi + lo bf16 pieces, fp32 accumulation; error
+#             <= 2^-16 relative per product -- between fp32 and the TF32 the reference's cuDNN path defaults to) -- the stage
+#             becomes a stream over its activation;
+#   "f32"   : the exact fp32-MFMA kernel (ops.conv1x1_mfma; True is accepted as an alias);
+#   False   : the framework's GEMM as in r2.          (A/B switch: examples/propagate_clip.py --pointwise)
+MFMA_POINTWISE = "split"
+
+
+def _pointwise_mode():
+    return "f32" if MFMA_POINTWISE is True else MFMA_POINTWISE
 
 # arithmetic of the QK^T contraction used by the MODULE-LEVEL functions: "f32" (exact fp32 MFMA) | "bf16" | "bf16x3" |
 # "bf16r".  An IntVOS instance carries its own (constructor argument / cfg.MODEL_MATCH_COMPUTE).
@@ -224,7 +232,7 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         its weights -- bn2(conv2(x)) == conv2'(x) -- the latter also split at input channel `cs` (forward_shared)."""
         src = [self.bn1.weight, self.bn1.bias, self.bn1.running_mean, self.bn1.running_var, self.bn2.weight,
                self.bn2.bias, self.bn2.running_mean, self.bn2.running_var, self.conv2.weight, self.conv2.bias]
-        key = (cs,) + tuple((t.data_ptr(), t._version) if t is not None else None for t in src)
+        key = (cs, _pointwise_mode()) + tuple((t.data_ptr(), t._version) if t is not None else None for t in src)
         hit = getattr(self, "_fold_cache", None)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -235,15 +243,26 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
             b2 = (self.conv2.bias.detach().float() * scale2 + shift2 if self.conv2.bias is not None else shift2).contiguous()
             val = {"scale1": scale1.contiguous(), "shift1": shift1.contiguous(), "w2": w2, "b2": b2,
                    "w2_shared": w2[:, :cs].contiguous(), "w2_object": w2[:, cs:].contiguous()}
-            if self.conv2.out_channels == ops.PW_COUT and MFMA_POINTWISE:  # ops.conv1x1_mfma: the weight transposed
+            mode = _pointwise_mode()
+            if self.conv2.out_channels == ops.PW_COUT and mode and w2.is_cuda:  # the weight transposed [Cin, Cout]
                 w2t = w2.reshape(w2.shape[0], w2.shape[1]).t().contiguous()
-                val["w2t"], val["w2t_shared"], val["w2t_object"] = w2t, w2t[:cs].contiguous(), w2t[cs:].contiguous()
+                if mode == "split":  # ops.conv1x1_split: packed hi / lo operand images
+                    val["sw"] = ops.SplitWeight(w2t)
+                    if 0 < cs < w2t.shape[0]:
+                        val["sw_shared"], val["sw_object"] = ops.SplitWeight(w2t[:cs]), ops.SplitWeight(w2t[cs:])
+                else:  # ops.conv1x1_mfma
+                    val["w2t"], val["w2t_shared"], val["w2t_object"] = w2t, w2t[:cs].contiguous(), w2t[cs:].contiguous()
+            val["mode"] = mode
         object.__setattr__(self, "_fold_cache", (key, val))  # plain attribute: not a buffer, not in the state dict
         return val
 
     def _pointwise(self, y, k, which, bias, relu):
         """bn2(conv2(y)) [+ relu2] on the depthwise stage's output: the fp32-MFMA 1x1 kernel when the shapes allow (256 output
         channels, Cin and h*w multiples of 4), else the framework's convolution with the same folded weights"""
+        skey = {"all": "sw", "shared": "sw_shared", "object": "sw_object"}[which]
+        if skey in k and ops.conv1x1_split_ok(y, self.conv2.out_channels):
+            b2 = k["b2"] if bias else k.setdefault("b2_zero", torch.zeros_like(k["b2"]))
+            return ops.conv1x1_split(y, k[skey], b2, relu_out=relu)
         wkey = {"all": "w2t", "shared": "w2t_shared", "object": "w2t_object"}[which]
         if wkey in k and ops.conv1x1_mfma_ok(y, self.conv2.out_channels):
             b2 = k["b2"] if bias else k.setdefault("b2_zero", torch.zeros_like(k["b2"]))
@@ -262,6 +281,8 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
             x = ops.dwconv7x7_bn_relu(x, self.conv1.weight, self.conv1.bias, scale=k["scale1"], shift=k["shift1"],
                                       relu_in=relu_in)
             if head is not None:
+                if "sw" in k and ops.conv1x1_split_ok(x, self.conv2.out_channels):
+                    return ops.conv1x1_split(x, k["sw"], k["b2"], head_weight=head[0], head_bias=head[1])
                 if "w2t" in k and ops.conv1x1_mfma_ok(x, self.conv2.out_channels):
                     return ops.conv1x1_mfma(x, k["w2t"], k["b2"], head_weight=head[0], head_bias=head[1])
                 return ops.relu_conv1x1_c1(self._pointwise(x, k, "all", True, False), head[0], head[1])
@@ -282,6 +303,11 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         w1, b1 = self.conv1.weight, self.conv1.bias
         s1 = ops.dwconv7x7_bn_relu(shared, w1[:cs], b1[:cs], scale=scale[:cs], shift=shift[:cs])
         p1 = ops.dwconv7x7_bn_relu(per_object, w1[cs:], b1[cs:], scale=scale[cs:], shift=shift[cs:])
+        if "sw_object" in k and ops.conv1x1_split_ok(p1, self.conv2.out_channels):
+            # the shared half once, then the per-object half with it added in the epilogue (no broadcast-add pass)
+            zero = k.setdefault("b2_zero", torch.zeros_like(k["b2"]))
+            return ops.conv1x1_split(p1, k["sw_object"], k["b2"], relu_out=not defer_relu,
+                                     add=ops.conv1x1_split(s1, k["sw_shared"], zero))
         y = self._pointwise(p1, k, "object", True, False)
         y += self._pointwise(s1, k, "shared", False, False)  # broadcast over the objects
         return y if defer_relu else y.relu_()

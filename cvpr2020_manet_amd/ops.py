@@ -629,6 +629,70 @@ def conv1x1_mfma(x, w2t, b2, relu_out=False, head_weight=None, head_bias=None):
     return out
 
 
+class SplitWeight:
+    """A 1x1 layer's folded weight packed for conv1x1_split (manet_conv1x1_x3_pack): the MFMA A-operand image of its hi
+    and lo bf16 pieces.  `cin` input channels, PW_COUT output channels."""
+
+    def __init__(self, w2t):
+        lib = _lib.load()
+        _need_gpu(w2t, "w2t")
+        w2t = w2t.detach().float().contiguous()
+        if w2t.dim() != 2 or w2t.shape[1] != PW_COUT:
+            raise ValueError("w2t must be [Cin, %d] (ops.fold_pointwise)" % PW_COUT)
+        self.cin = int(w2t.shape[0])
+        self.packed = torch.empty(int(lib.manet_conv1x1_x3_weight_bytes(self.cin)), dtype=torch.uint8, device=w2t.device)
+        with torch.cuda.device(w2t.device):
+            rc = lib.manet_conv1x1_x3_pack(w2t.data_ptr(), self.cin, PW_COUT, self.packed.data_ptr(), _stream_ptr(w2t.device))
+        _lib.check(rc, "manet_conv1x1_x3_pack")
+
+
+def conv1x1_split_ok(x, cout):
+    """shapes the split-bf16 1x1 kernel takes: 256 output channels, any Cin, h*w a multiple of 4"""
+    return cout == PW_COUT and x.dim() == 4 and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[2] * x.shape[3] >= 4
+
+
+def conv1x1_split(x, weight, b2, relu_out=False, add=None, head_weight=None, head_bias=None):
+    """conv2 -> bn2 [-> relu2] of a _split_separable_conv2d block (IntVOS.py:494,503-505) in split-bf16 arithmetic
+    (manet_conv1x1_x3_f32: fp32 factors as hi + lo bf16 pieces, fp32 accumulation; <= 2^-16 relative per product).
+    x [B, Cin, h, w] fp32; weight a SplitWeight; b2 [256] -> [B, 256, h, w].
+    add [1, 256, h, w] (or [256, h, w]): added to every batch entry before relu_out -- layer1's shared-embedding half.
+    head_weight / head_bias: DynamicSegHead's output layer fused (see conv1x1_mfma) -> [B, 1, h, w]."""
+    _refuse_autograd("conv1x1_split", x, b2, add, head_weight, head_bias)
+    lib = _lib.load()
+    _need_gpu(x, "x")
+    if not isinstance(weight, SplitWeight):
+        raise TypeError("weight must be an ops.SplitWeight")
+    x = x.float().contiguous()
+    B, cin, h, w = x.shape
+    if cin != weight.cin or b2.numel() != PW_COUT:
+        raise ValueError("x has %d channels, the packed weight %d; b2 must be [%d]" % (cin, weight.cin, PW_COUT))
+    if not conv1x1_split_ok(x, PW_COUT):
+        raise ValueError("conv1x1_split needs h*w to be a multiple of 4")
+    b2 = b2.detach().float().contiguous()
+    if add is not None:
+        if add.numel() != PW_COUT * h * w:
+            raise ValueError("add must be [1, %d, h, w]" % PW_COUT)
+        add = add.detach().float().contiguous()
+    hw = hb = hout = out = None
+    if head_weight is not None:
+        if head_weight.numel() != PW_COUT:
+            raise ValueError("head_weight must be [1, %d, 1, 1]" % PW_COUT)
+        if add is not None:
+            raise ValueError("add and the fused output layer are exclusive")
+        hw = head_weight.detach().float().contiguous()
+        hb = None if head_bias is None else head_bias.detach().float().contiguous()
+        hout = torch.empty((B, 1, h, w), dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty((B, PW_COUT, h, w), dtype=torch.float32, device=x.device)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    with torch.cuda.device(x.device):
+        rc = lib.manet_conv1x1_x3_f32(x.data_ptr(), cin * h * w, B, cin, h * w, weight.packed.data_ptr(), b2.data_ptr(),
+                                      ptr(add), PW_COUT, int(bool(relu_out)), ptr(out), ptr(hw), ptr(hb), ptr(hout),
+                                      _stream_ptr(x.device))
+    _lib.check(rc, "manet_conv1x1_x3_f32")
+    return hout if head_weight is not None else out
+
+
 def relu_conv1x1_c1(x, weight, bias=None, relu_in=True):
     """DynamicSegHead's output layer in one pass over the activation (IntVOS.py:519,525): Conv2d(C, 1, 1) applied to
     max(x, 0) (relu_in) or to x.  x [B, C, h, w] fp32, weight [1, C, 1, 1], bias [1] or None -> [B, 1, h, w]."""

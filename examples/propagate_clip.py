@@ -53,7 +53,10 @@ def main():
                     help="use ops.upsample_argmax instead of F.interpolate + argmax (test.py:253-255)")
     ap.add_argument("--graph", action="store_true", help="capture a propagated frame in a HIP graph and replay it")
     ap.add_argument("--framework-gemm", action="store_true",
-                    help="A/B: the heads' 1x1 convolutions on the framework's GEMM (r2) instead of the fp32-MFMA kernel")
+                    help="A/B: the heads' 1x1 convolutions on the framework's GEMM (r2)")
+    ap.add_argument("--pointwise", type=str, default=None, choices=["split", "f32", "framework"],
+                    help="A/B: the heads' 1x1 convolutions on the split-bf16 MFMA kernel (default), the exact fp32-MFMA kernel, "
+                         "or the framework's GEMM")
     ap.add_argument("--compute", type=str, default=None, help="arithmetic of the global match (f32 | bf16 | bf16x3 | bf16r)")
     ap.add_argument("--emb-dtype", type=str, default=None, help="storage of the embeddings (f32 | bf16)")
     ap.add_argument("--prepare-clip", action="store_true",
@@ -63,9 +66,9 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     cfg = make_cfg(["--TEST_MODE", "True"])
-    if args.framework_gemm:
+    if args.framework_gemm or args.pointwise:
         from cvpr2020_manet_amd.networks import IntVOS as _M
-        _M.MFMA_POINTWISE = False
+        _M.MFMA_POINTWISE = False if (args.framework_gemm or args.pointwise == "framework") else args.pointwise
     model = IntVOS(cfg, StandInEncoder(cfg.MODEL_ASPP_OUTDIM), compute=args.compute, emb_dtype=args.emb_dtype).to(dev).eval()
     F_, H, W, nobj = args.frames, args.height, args.width, args.objects
     seq = "synthetic"

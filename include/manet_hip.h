@@ -310,6 +310,21 @@ int manet_conv1x1_head_f32(const float *in, int64_t in_batch_stride, int B, int 
                            const float *b2, int Cout, int relu_out, float *out, const float *head_w,
                            const float *head_b, float *head_out, manet_stream_t stream);
 
+/* The same layer in SPLIT-bf16 arithmetic: each fp32 factor = hi + lo (two bf16 pieces, 16 significand bits), a product =
+ * hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (<= 2^-16 relative per product; the reference's
+ * cuDNN path is TF32 -- 10 bits -- under torch's default allow_tf32).  3/16 of the fp32 matrix pipe's time: the layer
+ * becomes a stream over its activation.
+ *   manet_conv1x1_x3_weight_bytes(Cin) / manet_conv1x1_x3_pack: w2t [Cin][256] fp32 (as for manet_conv1x1_f32) -> the packed
+ *     MFMA A-operand image `wpk` (hi and lo), once per fold of the layer's constants; wpk 16-byte aligned.
+ *   manet_conv1x1_x3_f32: in as above but ANY Cin >= 1 (HW a multiple of 4); add = NULL or [256][HW] fp32 added to every batch
+ *     entry's output before relu_out (layer1 of the shared-embedding form: the embedding half of the contraction, computed
+ *     once per frame); head_w / head_b / head_out as manet_conv1x1_head_f32 (exclusive with add). */
+int64_t manet_conv1x1_x3_weight_bytes(int Cin);
+int manet_conv1x1_x3_pack(const float *w2t, int Cin, int Cout, void *wpk, manet_stream_t stream);
+int manet_conv1x1_x3_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const void *wpk, const float *b2,
+                         const float *add, int Cout, int relu_out, float *out, const float *head_w, const float *head_b,
+                         float *head_out, manet_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Training path: what torch.autograd does for the reference's pure-PyTorch path
  * (train_stage1.py:126-156 back-propagates through IntVOS.forward) and what

@@ -148,7 +148,55 @@ def test_folded_constants_follow_parameter_updates():
 
 
 @pytest.mark.gpu
-def test_mfma_pointwise_vs_framework_conv_and_literal_module():
+def test_split_bf16_pointwise_error_bound_and_forms():
+    """ops.conv1x1_split (each fp32 factor = hi + lo bf16 pieces; hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulation)
+    against an fp64 convolution.  Stated bound, per output:  |err| <= 2^-15 * sum_k |x_k| |w_k|  +  fp32 accumulation
+    (2^-16 relative per product is the arithmetic's own bound: the dropped lo*lo term and the rounding of the lo pieces;
+    measured on these cases: <= 0.2 of the bound, 2.5e-5 absolute on outputs of magnitude 7 at K = 256).  Any Cin (the
+    per-object half of layer 1 has 3), partial pixel tiles, relu_out, the broadcast `add` term, the fused output layer."""
+    import torch
+    from cvpr2020_manet_amd import ops
+    torch.manual_seed(5)
+    with torch.no_grad():
+        for (B, cin, h, w) in ((3, 256, 30, 54), (2, 100, 9, 12), (3, 3, 21, 36), (1, 1, 2, 2), (2, 17, 6, 10), (2, 33, 5, 52),
+                               (3, 256, 120, 214)):
+            x = torch.randn(B, cin, h, w, device="cuda") * 1.5
+            w2t = torch.randn(cin, 256, device="cuda") * 0.08
+            b2 = torch.randn(256, device="cuda")
+            sw = ops.SplitWeight(w2t)
+            w64 = w2t.t().reshape(256, cin, 1, 1).double()
+            ref = torch.nn.functional.conv2d(x.double(), w64, b2.double())
+            mag = torch.nn.functional.conv2d(x.double().abs(), w64.abs())
+            got = ops.conv1x1_split(x, sw, b2)
+            err = (got.double() - ref).abs()
+            bound = 2.0 ** -15 * mag + 2.0 ** -22 * (mag + b2.abs().double().view(1, -1, 1, 1))
+            assert bool((err <= bound).all()), (cin, float((err / bound).max()))
+            assert torch.equal(ops.conv1x1_split(x, sw, b2, relu_out=True), torch.relu(got))
+            add = torch.randn(1, 256, h, w, device="cuda")
+            torch.testing.assert_close(ops.conv1x1_split(x, sw, b2, add=add), got + add, rtol=1e-6, atol=1e-6)
+            torch.testing.assert_close(ops.conv1x1_split(x, sw, b2, add=add, relu_out=True), torch.relu(got + add), rtol=1e-6, atol=1e-6)
+            fin = torch.nn.Conv2d(256, 1, 1).cuda()
+            torch.testing.assert_close(ops.conv1x1_split(x, sw, b2, head_weight=fin.weight, head_bias=fin.bias),
+                                       fin(torch.relu(got)), rtol=1e-4, atol=1e-4)
+            if cin % 4 == 0:  # and against the exact fp32-MFMA kernel
+                torch.testing.assert_close(got, ops.conv1x1_mfma(x, w2t, b2), rtol=1e-4, atol=1e-4)
+        # non-finite inputs propagate as in fp32 (inf stays inf, NaN stays NaN), nothing else is touched
+        x = torch.randn(1, 8, 4, 8, device="cuda")
+        x[0, 3, 1, 2] = float("inf")
+        x[0, 5, 2, 7] = float("nan")
+        sw = ops.SplitWeight(torch.ones(8, 256, device="cuda"))
+        y = ops.conv1x1_split(x, sw, torch.zeros(256, device="cuda"))
+        bad = ~torch.isfinite(y[0, 0])
+        assert bad.sum().item() == 2 and bool(bad[1, 2]) and bool(bad[2, 7])
+        with pytest.raises(ValueError):
+            ops.conv1x1_split(torch.randn(1, 8, 3, 3, device="cuda"), sw, torch.zeros(256, device="cuda"))  # h*w % 4
+        with pytest.raises(TypeError):
+            ops.conv1x1_split(x, torch.ones(8, 256, device="cuda"), torch.zeros(256, device="cuda"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["split", "f32"])
+def test_mfma_pointwise_vs_framework_conv_and_literal_module(mode):
     """ops.conv1x1_mfma (fp32-MFMA contraction fed by LDS-DMA) against the framework's 1x1 convolution with the same folded
     weights, and the blocks that use it against their literal form relu2(bn2(conv2(relu1(bn1(conv1(x)))))): full chunks,
     partial last chunks (Cin % 16 = 4, 8, 12), a partial last pixel tile, the full [3,256,120,214] size, the shared-embedding
@@ -157,6 +205,15 @@ def test_mfma_pointwise_vs_framework_conv_and_literal_module():
     from cvpr2020_manet_amd import ops
     from cvpr2020_manet_amd.networks import IntVOS as M
     torch.manual_seed(3)
+    keep = M.MFMA_POINTWISE
+    M.MFMA_POINTWISE = mode  # the blocks below run their 1x1 stage on this kernel
+    try:
+        _pointwise_module_cases(M, ops, torch)
+    finally:
+        M.MFMA_POINTWISE = keep
+
+
+def _pointwise_module_cases(M, ops, torch):
     with torch.no_grad():
         for (B, cin, h, w) in ((3, 256, 30, 54), (2, 100, 9, 12), (1, 16, 4, 16), (2, 4, 21, 36), (2, 44, 6, 10),
                                (3, 256, 120, 214)):
