@@ -380,7 +380,7 @@ __global__ __launch_bounds__(PW_NT, 3) void conv1x1_mfma_kernel(const float *__r
 //     registers (v_cvt_pk_bf16_f32: 5 VALU per pair) -- the depthwise kernel keeps writing plain fp32.
 //   any Cin >= 1 (rows past Cin are clamped reads against zero weight rows); h*w a multiple of 4 (16-byte DMA rows).
 //   `add` (layer1's shared-embedding half, [256][HW], the same for every batch entry) and the bias join in the epilogue.
-constexpr int X3_P = 128, X3_KC = 16, X3_NT = 256, X3_WCHUNK = 2 * 8 * 1024, X3_NB = 3;
+constexpr int X3_P = 128, X3_KC = 16, X3_NT = 256, X3_WCHUNK = 2 * 8 * 1024, X3_NB = 2;
 typedef __bf16 x3_bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -388,7 +388,10 @@ __device__ __forceinline__ void x3_split(float x0, float x1, unsigned &hi, unsig
 {
     hi = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0, x1}, x3_bf16x2));
     const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0 - h0, x1 - h1}, x3_bf16x2));
+    float l0, l1;  // two scalar subtractions on purpose: hipcc packs them into v_pk_add_f32 + two v_mov otherwise
+    asm("v_sub_f32 %0, %1, %2" : "=v"(l0) : "v"(x0), "v"(h0));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(l1) : "v"(x1), "v"(h1));
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){l0, l1}, x3_bf16x2));
 }
 
 // w2t [Cin][256] fp32 -> A-operand image [chunk][hi | lo][co block 8][lane 64] x 16 bytes; lane l of block b holds
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256) void conv1x1_x3_pack_kernel(const float *__res
 }
 
 template <int ABL>
-__global__ __launch_bounds__(X3_NT, 2) void conv1x1_x3_kernel(const float *__restrict__ in, long in_bs, int Cin, long HW,
+__global__ __launch_bounds__(X3_NT, 3) void conv1x1_x3_kernel(const float *__restrict__ in, long in_bs, int Cin, long HW,
                                                               const char *__restrict__ wpk, const float *__restrict__ b2,
                                                               const float *__restrict__ add, int relu_out,
                                                               float *__restrict__ out, const float *__restrict__ head_w,
@@ -459,8 +462,9 @@ __global__ __launch_bounds__(X3_NT, 2) void conv1x1_x3_kernel(const float *__res
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     bsh[tid] = b2[tid];
+    // chunks are fetched X3_NB - 1 steps ahead; a step waits for everything but the chunks issued behind its successor
     dma(0);
-    if (n > 1) {
+    if (X3_NB == 3 && n > 1) {
         dma(1);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else
@@ -468,8 +472,8 @@ __global__ __launch_bounds__(X3_NT, 2) void conv1x1_x3_kernel(const float *__res
     __syncthreads();
 #define X3_MFMA(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3_bf16x8, a_), __builtin_bit_cast(x3_bf16x8, b_), c_, 0, 0, 0)
     for (int c = 0; c < n; ++c) {
-        const bool more = c + 2 < n;
-        if (more && !(ABL & 4)) dma(c + 2);  // (its slot was last read in iteration c - 1: everyone is past that barrier)
+        const bool more = c + X3_NB - 1 < n;
+        if (more && !(ABL & 4)) dma(c + X3_NB - 1);  // (its slot was last read in iteration c - 1: everyone is past that barrier)
         if (ABL & 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -477,6 +481,10 @@ __global__ __launch_bounds__(X3_NT, 2) void conv1x1_x3_kernel(const float *__res
         }
         const float *X = &xbuf[c % X3_NB][8 * (lane >> 5) * X3_P + wq * 64 + (lane & 31)];
         uint4 bh[2], bl[2];
+        if (ABL & 16) {
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) bh[pb] = bl[pb] = make_uint4(lane + c, lane, c, pb);
+        } else {
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
             float v[8];
@@ -487,10 +495,16 @@ __global__ __launch_bounds__(X3_NT, 2) void conv1x1_x3_kernel(const float *__res
             x3_split(v[4], v[5], bh[pb].z, bl[pb].z);
             x3_split(v[6], v[7], bh[pb].w, bl[pb].w);
         }
+        }
         const uint4 *W = (const uint4 *)&wbuf[c % X3_NB][0] + (wc * 4) * 64 + lane;
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
             const uint4 ah = W[blk * 64], al = W[(8 + blk) * 64];
+            if (ABL & 8) {
+                acc[blk][0][0] += __uint_as_float((ah.x ^ bl[0].x ^ bh[0].y ^ bl[0].z ^ bh[0].w) & 0xff);
+                acc[blk][1][0] += __uint_as_float((al.x ^ bl[1].x ^ bh[1].y ^ bl[1].z ^ bh[1].w ^ bh[1].x ^ bl[1].y ^ bh[0].x ^ bl[0].y ^ bh[0].z ^ bl[0].w ^ bh[1].z ^ bl[1].w) & 0xff);
+                continue;
+            }
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) {
                 X3_MFMA(ah, bl[pb], acc[blk][pb]);
@@ -498,7 +512,7 @@ __global__ __launch_bounds__(X3_NT, 2) void conv1x1_x3_kernel(const float *__res
                 X3_MFMA(ah, bh[pb], acc[blk][pb]);
             }
         }
-        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (more && X3_NB == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -646,6 +660,9 @@ extern "C" int manet_conv1x1_x3_f32(const float *in, int64_t in_batch_stride, in
     case 4: X3_LAUNCH(4); break;
     case 6: X3_LAUNCH(6); break;
     case 7: X3_LAUNCH(7); break;
+    case 9: X3_LAUNCH(9); break;
+    case 17: X3_LAUNCH(17); break;
+    case 25: X3_LAUNCH(25); break;
     default: X3_LAUNCH(0);
     }
 #undef X3_LAUNCH
