@@ -45,7 +45,14 @@ constexpr int META_KMAX = 200;     // [200]      max |k|^2 over the bank's rows,
 // MANET_COMPUTE_BF16_REFINE: a pre-pass over every REFINE_SUB-th bank tile gives an upper bound of the minimum; the full
 // bf16 pass then keeps, per (query, object), the bank rows that could beat it; up to REFINE_CAP of them are re-evaluated in
 // the reference's fp32 arithmetic
-constexpr int REFINE_SUB = 4;
+#ifndef MANET_REFINE_SUB
+#define MANET_REFINE_SUB 8
+#endif
+constexpr int REFINE_SUB = MANET_REFINE_SUB;
+#ifndef MANET_REFINE_XCHG_MASK
+#define MANET_REFINE_XCHG_MASK 3
+#endif
+constexpr int REFINE_XCHG_MASK = MANET_REFINE_XCHG_MASK;  // threshold exchange every (mask + 1) steps
 constexpr int REFINE_CAP = 16;  // capacity of the flat candidate list, in rows per (query, object) pair ON AVERAGE
 constexpr int REFINE_LDS_LIST = 2048;  // candidate entries a filter workgroup collects in LDS before it appends them in bulk
 
@@ -169,8 +176,8 @@ struct MatchLayout {
     size_t qblk_bytes, off_q, off_keys, off_topk, total;
     // MANET_COMPUTE_BF16_REFINE: per (object, query) threshold and exact-distance key, the flat candidate list
     // {pair, bank slot} with its capacity, and two counters (candidates appended, list overflowed)
-    size_t off_thr, off_slack, off_keys2, off_list, off_stats;
-    long list_cap;
+    size_t off_thr, off_slack, off_keys2, off_list, off_stats, off_bcnt;
+    long list_cap, bucket_cap;  // the candidate list = N_pad / 32 buckets (one per 32-query block) of bucket_cap entries
 };
 
 constexpr int TOPK_SPLITS = 16;  // the top-k path trades a little tail balance for a bounded workspace
@@ -190,8 +197,8 @@ MatchLayout match_layout(int64_t N, int C, int n_ids, int compute, int k_nn = 1,
         L.total = manet_align_up(L.off_topk + (size_t)TOPK_SPLITS * n_ids * L.N_pad * MANET_MAX_KNN * sizeof(float), 1024);
     if (arg)  // 64-bit (distance key, bank slot) pairs of the arg-min form live where the top-k lists would
         L.total = manet_align_up(L.off_topk + (size_t)n_ids * L.N_pad * sizeof(unsigned long long), 1024);
-    L.off_thr = L.off_slack = L.off_keys2 = L.off_list = L.off_stats = 0;
-    L.list_cap = 0;
+    L.off_thr = L.off_slack = L.off_keys2 = L.off_list = L.off_stats = L.off_bcnt = 0;
+    L.list_cap = L.bucket_cap = 0;
     if (compute == MANET_COMPUTE_BF16_REFINE) {
         const size_t pairs = (size_t)n_ids * L.N_pad;
         L.list_cap = (long)pairs * REFINE_CAP;
@@ -199,8 +206,10 @@ MatchLayout match_layout(int64_t N, int C, int n_ids, int compute, int k_nn = 1,
         L.off_slack = manet_align_up(L.off_thr + pairs * sizeof(float), 256);
         L.off_keys2 = manet_align_up(L.off_slack + pairs * sizeof(float), 256);
         L.off_list = manet_align_up(L.off_keys2 + pairs * sizeof(unsigned), 256);
+        L.bucket_cap = (long)n_ids * QB * REFINE_CAP;
         L.off_stats = manet_align_up(L.off_list + (size_t)L.list_cap * sizeof(uint2), 256);
-        L.total = manet_align_up(L.off_stats + 256, 1024);
+        L.off_bcnt = L.off_stats + 256;
+        L.total = manet_align_up(L.off_bcnt + (size_t)(L.N_pad / QB) * sizeof(unsigned), 1024);
     }
     return L;
 }
@@ -1531,7 +1540,8 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
                                                                         int young_prio, unsigned *__restrict__ thr,
                                                                         const float *__restrict__ slack,
                                                                         unsigned long long *__restrict__ stats,
-                                                                        uint2 *__restrict__ list, long list_cap)
+                                                                        uint2 *__restrict__ list, long bucket_cap,
+                                                                        unsigned *__restrict__ bcnt)
 {
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     constexpr int NW = 4, TPS = 2, NQB = 4;  // waves, tiles per step, query blocks per wave
@@ -1558,8 +1568,17 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     auto stage_dma = [&](int t, int slot, bool prologue = false) __attribute__((always_inline)) {
         if ((ABL & 1) && !prologue) return;
         const int np = ((t1 - t) < TPS ? (t1 - t) : TPS) * UNITS;  // the split's last step may be short
-        const char *g = bpack + (size_t)t * TILE_BYTES + (size_t)lane * 16;
         const unsigned l = smem_base + (unsigned)slot * (unsigned)STEP_BYTES;
+        if (FILTER) {  // (at the register limit: a uniform base + this lane's 32-bit offset, no 64-bit address pair)
+            const char *g = bpack + (size_t)t * TILE_BYTES;
+#pragma unroll
+            for (int i = 0; i < (PIECES + NW - 1) / NW; ++i) {
+                const int pc = wave + i * NW;  // wave-uniform
+                if (pc < np) lds_dma16_s(g + (size_t)pc * 1024, (unsigned)lane * 16u, l + (unsigned)pc * 1024u);
+            }
+            return;
+        }
+        const char *g = bpack + (size_t)t * TILE_BYTES + (size_t)lane * 16;
 #pragma unroll
         for (int i = 0; i < (PIECES + NW - 1) / NW; ++i) {
             const int pc = wave + i * NW;  // wave-uniform
@@ -1597,11 +1616,17 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     float tq[NQB], sq[NQB];
 #pragma unroll
     for (int j = 0; j < NQB; ++j) ma[j] = mb[j] = MANET_WRONG_LABEL_PADDING_DISTANCE;
+    // FILTER: the lowest key this lane KNOWS to be published for its four (query, object) pairs -- what it read or wrote
+    // last -- lives in LDS (touched at exchanges only).  A lane publishes only below it: every lane every time was 13 M
+    // atomics per launch, most of them no-ops at the L2 -- the filter pass's main overhead over the plain kernel.
+    unsigned *pks = (unsigned *)(smem + 2 * STEP_BYTES + (size_t)REFINE_LDS_LIST * 8) + wave * 256 + lane;
     auto load_thr = [&](int obj) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NQB; ++j) {
-            tq[j] = FILTER ? float_of(thr[(size_t)obj * N_pad + qbase + 32 * j]) : 0.0f;
+            const unsigned kpub = FILTER ? thr[(size_t)obj * N_pad + qbase + 32 * j] : 0u;
+            tq[j] = FILTER ? float_of(kpub) : 0.0f;
             sq[j] = FILTER ? slack[(size_t)obj * N_pad + qbase + 32 * j] : 0.0f;
+            if (FILTER) pks[64 * j] = kpub;
         }
     };
     if (FILTER) load_thr(o);
@@ -1610,7 +1635,11 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
 #pragma unroll
             for (int j = 0; j < NQB; ++j) {
                 const float a = fminf(tq[j], __shfl_xor(tq[j], 32));
-                if (h == 0 && a == a) atomicMin(thr + (size_t)obj * N_pad + qbase + 32 * j, key_of(a));
+                const unsigned ka = key_of(a);
+                if (h == 0 && a == a && ka < pks[64 * j]) {
+                    atomicMin(thr + (size_t)obj * N_pad + qbase + 32 * j, ka);
+                    pks[64 * j] = ka;
+                }
             }
             return;
         }
@@ -1619,15 +1648,6 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
             const float v = min3p(ma[j], mb[j], mb[j]);
             const float a = min3p(v, v, __shfl_xor(v, 32));
             if (h == 0) atomicMin(keys + (size_t)obj * N_pad + qbase + 32 * j, key_of(a));
-        }
-    };
-    auto next_object = [&](int t) __attribute__((always_inline)) {
-        if (t >= seg_end) {  // wave-uniform: tile t starts another object's rows
-            flush(o);
-#pragma unroll
-            for (int j = 0; j < NQB; ++j) ma[j] = mb[j] = MANET_WRONG_LABEL_PADDING_DISTANCE;
-            do { ++o; seg_end = meta[META_SEG + o + 1]; } while (t >= seg_end);
-            if (FILTER) load_thr(o);
         }
     };
     (void)young_prio;
@@ -1642,15 +1662,12 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     // A qualifying row goes to the WAVE's own LDS list first -- its fill count lives in a scalar register, a hit costs a
     // ballot, a population count and a ds_write, no atomic (a returning global atomic per row stalled the wave for a memory
     // round trip: 2x the kernel's time; a returning LDS atomic: +45 %) -- and reaches the global list in bulk when the wave
-    // is done; rows beyond the wave's capacity are appended directly.
-    constexpr int WL = REFINE_LDS_LIST / NW;  // entries per wave
-    uint2 *fl = (uint2 *)(smem + 2 * STEP_BYTES) + wave * WL;
-    int wl_n = 0;  // (wave-uniform)
-    auto append_global = [&](int obj, long n, int slot) __attribute__((always_inline)) {
-        const unsigned long long idx = atomicAdd(&stats[0], 1ull);
-        if (idx < (unsigned long long)list_cap) list[idx] = make_uint2((unsigned)((size_t)obj * N_pad + n), (unsigned)slot);
-        else stats[1] = 1ull;
-    };
+    // is done; rows beyond a sub-list's capacity raise the overflow flag (refine_rescue_kernel).
+    // The wave's list is four sub-lists, one per query block: the re-rank kernel's waves then read 32 neighbouring queries
+    // (for a fixed channel one 128-byte line of the C-major embedding) instead of the wave's 128.
+    constexpr int WL = REFINE_LDS_LIST / NW / NQB;  // entries per wave and query block
+    uint2 *fl = (uint2 *)(smem + 2 * STEP_BYTES) + wave * (WL * NQB);
+    int wl_n[NQB] = {0, 0, 0, 0};  // (wave-uniform)
     auto emit = [&](const f32x16 &c, float t, int j, int row0) __attribute__((always_inline)) {
         const unsigned lq = (unsigned)(wave * (NQB * QB) + l31 + 32 * j);  // query inside the workgroup's 512
 #pragma unroll
@@ -1659,12 +1676,9 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
             const unsigned long long m = __ballot(hit);
             if (m) {  // wave-uniform: most registers hold no qualifying row for any lane
                 const int slot = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int idx = wl_n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (hit) {
-                    if (idx < WL) fl[idx] = make_uint2(((unsigned)o << 16) | lq, (unsigned)slot);
-                    else append_global(o, (long)qt * QTB + lq, slot);
-                }
-                wl_n += __popcll(m);
+                const int idx = wl_n[j] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (hit && idx < WL) fl[j * WL + idx] = make_uint2(((unsigned)o << 16) | lq, (unsigned)slot);
+                wl_n[j] += __popcll(m);
             }
         }
     };
@@ -1718,6 +1732,74 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         }                                                                                          \
     }
 
+    // FILTER form of a pass: the threshold test of two query blocks runs UNDER the MFMAs of the other two -- the pass is two
+    // half-passes (blocks 0,1 then blocks 2,3, KSB k-steps each), and the test of a half's accumulators sits in the basic
+    // block of the NEXT half's MFMAs, in front of its (rarely taken) branch to the slow path.  (First form: the test of all
+    // four blocks behind the pass's last MFMA, then the branch -- hipcc does not move MFMAs across a branch, so the ~50 VALU
+    // instructions of the test ran exposed in every pass: the filter cost +13 % over the plain kernel.)  Accumulators: two
+    // accumulate while two are tested, 64 registers as before.  pc2 / pc3 = the pending second half (blocks 2,3 of the
+    // previous pass, rows pend_row0..), tested under the next pass's first half; an object change or the end of the split
+    // tests it on the spot.
+#define MANET_TEST2(ca_, cb_, ja_, jb_, row0_)                                                     \
+    {                                                                                              \
+        const float pa = min16(ca_), pb = min16(cb_);                                              \
+        tq[ja_] = fminf(tq[ja_], pa + sq[ja_]);                                                    \
+        tq[jb_] = fminf(tq[jb_], pb + sq[jb_]);                                                    \
+        const bool ha = pa <= tq[ja_], hb = pb <= tq[jb_];                                         \
+        if (__ballot(ha | hb)) { /* wave-uniform */                                                \
+            if (__ballot(ha)) emit(ca_, tq[ja_], ja_, (row0_));                                    \
+            if (__ballot(hb)) emit(cb_, tq[jb_], jb_, (row0_));                                    \
+        }                                                                                          \
+    }
+#define MANET_PASS_F(next_base_, row0_)                                                            \
+    {                                                                                              \
+        f32x16 c0 = {0}, c1 = {0};                                                                 \
+        _Pragma("unroll") for (int k = 0; k < KSB; ++k)                                            \
+        {                                                                                          \
+            MANET_MFMA(F[k], q[0][k], c0);                                                         \
+            MANET_MFMA(F[k], q[1][k], c1);                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); /* 2 MFMA */                        \
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); /* a slice of the pending test */   \
+        }                                                                                          \
+        MANET_TEST2(pc2, pc3, 2, 3, pend_row0);                                                    \
+        pc2 = (f32x16){0};                                                                         \
+        pc3 = (f32x16){0};                                                                         \
+        _Pragma("unroll") for (int k = 0; k < KSB; ++k)                                            \
+        {                                                                                          \
+            MANET_MFMA(F[k], q[2][k], pc2);                                                        \
+            MANET_MFMA(F[k], q[3][k], pc3);                                                        \
+            MANET_LOADF(k, next_base_);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                     \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* the refill right behind them */  \
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                     \
+        }                                                                                          \
+        MANET_TEST2(c0, c1, 0, 1, (row0_));                                                        \
+        pend_row0 = (row0_);                                                                       \
+    }
+    unsigned xk[NQB] = {0u, 0u, 0u, 0u};  // FILTER: threshold keys asked for in the previous exchange step, of object xo
+    int xo = -1;
+    f32x16 pc2, pc3;  // FILTER: the pending half (nothing pending: distances no threshold admits)
+    int pend_row0 = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pc2[r] = pc3[r] = MANET_WRONG_LABEL_PADDING_DISTANCE;
+    auto test_pending = [&]() __attribute__((always_inline)) {
+        if (FILTER) {
+            MANET_TEST2(pc2, pc3, 2, 3, pend_row0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pc2[r] = pc3[r] = MANET_WRONG_LABEL_PADDING_DISTANCE;
+        }
+    };
+    auto next_object = [&](int t) __attribute__((always_inline)) {
+        if (t >= seg_end) {  // wave-uniform: tile t starts another object's rows
+            test_pending();  // (FILTER: the previous pass's second half still belongs to the old object)
+            flush(o);
+#pragma unroll
+            for (int j = 0; j < NQB; ++j) ma[j] = mb[j] = MANET_WRONG_LABEL_PADDING_DISTANCE;
+            do { ++o; seg_end = meta[META_SEG + o + 1]; } while (t >= seg_end);
+            if (FILTER) load_thr(o);
+        }
+    };
+
     // prologue: steps 0 and 1 in flight; publish step 0, fetch the first pass's fragments
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1732,13 +1814,22 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         const bool has_b = (t + 1 < t1);
         // ---- tile A: rows 0-31 (refill: A rows 32-63), rows 32-63 (refill: B rows 0-31)
         next_object(t);
-        MANET_PASS(cur + 32 * 16, t * BT);
-        MANET_PASS(cur + TILE_BYTES, t * BT + 32);
+        if (FILTER) {
+            MANET_PASS_F(cur + 32 * 16, t * BT);
+            MANET_PASS_F(cur + TILE_BYTES, t * BT + 32);
+        } else {
+            MANET_PASS(cur + 32 * 16, t * BT);
+            MANET_PASS(cur + TILE_BYTES, t * BT + 32);
+        }
         // ---- tile B rows 0-31 (refill: B rows 32-63).  After this pass every fragment of `cur` is in
         // registers.
         if (has_b) {
             next_object(t + 1);
-            MANET_PASS(cur + TILE_BYTES + 32 * 16, (t + 1) * BT);
+            if (FILTER) {
+                MANET_PASS_F(cur + TILE_BYTES + 32 * 16, (t + 1) * BT);
+            } else {
+                MANET_PASS(cur + TILE_BYTES + 32 * 16, (t + 1) * BT);
+            }
         }
         // ---- this wave's pieces of the next step have landed (issued one step ago) and its reads of `cur`
         // have returned; the barrier publishes the next buffer and frees `cur` for step + 2
@@ -1746,34 +1837,72 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (FILTER) {
+            // threshold exchange with the workgroups running beside this one on the same queries and object: every fourth
+            // step the wave publishes its thresholds (non-returning atomics) and ASKS for the published ones; the answer is
+            // taken one step later, right here behind the step's vmcnt(0) -- the loads never stall the wave (first form:
+            // load and use in one place, a memory round trip exposed per exchange).
+            if (xo == o) {
+#pragma unroll
+                for (int j = 0; j < NQB; ++j) {
+                    tq[j] = fminf(tq[j], float_of(xk[j]));
+                    if (h == 0 && xk[j] < pks[64 * j]) pks[64 * j] = xk[j];
+                }
+            }
+            xo = -1;
+            if ((((t - t0) / TPS) & REFINE_XCHG_MASK) == REFINE_XCHG_MASK) {
+                flush(o);
+                xo = o;
+#pragma unroll
+                for (int j = 0; j < NQB; ++j) xk[j] = thr[(size_t)o * N_pad + qbase + 32 * j];
+            }
+        }
         if (t + 2 * TPS < t1) stage_dma(t + 2 * TPS, buf);
         // ---- tile B rows 32-63 (refill: first pass of the next step; a stale read if there is none)
-        if (has_b) MANET_PASS(nxt, (t + 1) * BT + 32);
-        if (FILTER && (((t - t0) / TPS) & 3) == 3) {
-            // every fourth step: publish this wave's thresholds and pick up what the workgroups running beside it on the
-            // same queries and object have found (non-returning atomics + four loads per lane)
-            flush(o);
-#pragma unroll
-            for (int j = 0; j < NQB; ++j) tq[j] = fminf(tq[j], float_of(thr[(size_t)o * N_pad + qbase + 32 * j]));
+        if (has_b) {
+            if (FILTER) {
+                MANET_PASS_F(nxt, (t + 1) * BT + 32);
+            } else {
+                MANET_PASS(nxt, (t + 1) * BT + 32);
+            }
         }
     }
+    test_pending();
 #undef MANET_PASS
+#undef MANET_PASS_F
+#undef MANET_TEST2
 #undef MANET_LOADF
 #undef MANET_MFMA
 #undef MANET_BF
     flush(o);
-    if (FILTER) {  // the wave's candidates -> the global list: ONE returning atomic reserves their places
-        const int total = wl_n < WL ? wl_n : WL;
-        unsigned long long base = 0ull;
-        if (lane == 0 && total) base = atomicAdd(&stats[0], (unsigned long long)total);
-        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
-               (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)base);
-        for (int i = lane; i < total; i += 64) {
-            const uint2 e = fl[i];  // (this wave's own ds_writes: ordered behind them in the LDS queue)
-            if (base + i < (unsigned long long)list_cap)
-                list[base + i] = make_uint2((unsigned)((size_t)(e.x >> 16) * N_pad + (size_t)qt * QTB + (e.x & 0xffffu)), e.y);
-            else stats[1] = 1ull;
+    if (FILTER) {
+        // the wave's candidates -> the global list, which is one BUCKET per 32-query block (the wave's sub-list j belongs to
+        // block 16 qt + 4 wave + j): one returning atomic per sub-list reserves its places.  The re-rank kernel runs one
+        // workgroup per bucket with the block's 32 query vectors in LDS.
+        int cnt[NQB], total = 0;
+#pragma unroll
+        for (int j = 0; j < NQB; ++j) {
+            cnt[j] = wl_n[j] < WL ? wl_n[j] : WL;
+            total += wl_n[j];  // (statistics: the qualifying rows SEEN)
+            if (wl_n[j] > WL) stats[1] = 1ull;  // more rows than a sub-list holds (20x the average): the rescue scan takes over
         }
+        // lane j reserves sub-list j's places: the four atomics are one instruction, one round trip
+        const int mine = lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : cnt[3];
+        const long b0 = (long)qt * (QTB / QB) + wave * NQB;
+        unsigned got = 0u;
+        if (lane < NQB && mine) got = atomicAdd(&bcnt[b0 + lane], (unsigned)mine);
+#pragma unroll
+        for (int j = 0; j < NQB; ++j) {
+            const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)got, j);
+            for (int i = lane; i < cnt[j]; i += 64) {
+                const uint2 e = fl[j * WL + i];  // (this wave's own ds_writes: ordered behind them in the LDS queue)
+                if ((long)base + i < bucket_cap)
+                    list[(b0 + j) * bucket_cap + base + i] =
+                        make_uint2((unsigned)((size_t)(e.x >> 16) * N_pad + (size_t)qt * QTB + (e.x & 0xffffu)), e.y);
+                else stats[1] = 1ull;
+            }
+        }
+        if (lane == 0 && total) atomicAdd(&stats[0], (unsigned long long)total);  // (statistics only)
     }
 }
 
@@ -1868,10 +1997,11 @@ __device__ __forceinline__ float query_norm_from_image(const char *qimg, long qb
 __global__ void refine_threshold_kernel(const unsigned *__restrict__ keys, const char *__restrict__ qimg, long qblk_bytes,
                                         int C, const int *__restrict__ meta, long N, long N_pad, int n_ids,
                                         unsigned *__restrict__ thr, float *__restrict__ slack, unsigned *__restrict__ keys2,
-                                        unsigned long long *__restrict__ stats)
+                                        unsigned long long *__restrict__ stats, unsigned *__restrict__ bcnt)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) stats[0] = stats[1] = 0ull;
+    if (i < N_pad / QB) bcnt[i] = 0u;
     if (i >= (long)n_ids * N_pad) return;
     const long n = i % N_pad;
     keys2[i] = 0xffffffffu;  // "no row": the exact distances meet here by atomicMin
@@ -1893,42 +2023,58 @@ __global__ void refine_threshold_kernel(const unsigned *__restrict__ keys, const
     slack[i] = sl;       // ... to (smallest bf16 distance they met) + slack: E only shrinks with U
 }
 
-// exact re-rank: one thread per candidate {pair, bank slot}: the reference's fp32 distance (the oracle's fmaf chains,
-// IntVOS.py:32-39) of that (query, bank row), reduced per pair by atomicMin on the order-preserving key; the usual finish
-// kernel decodes the keys.  (The candidates of a filter workgroup sit together and belong to its 512 queries: for a fixed
-// channel a wave's query reads fall into a 2 KiB window of the C-major embedding.)
+// exact re-rank: one workgroup per bucket of the candidate list (= 32 neighbouring queries, every object), one thread per
+// candidate {pair, bank slot}: the reference's fp32 distance (the oracle's fmaf chains, IntVOS.py:32-39) of that (query,
+// bank row), reduced per pair by atomicMin on the order-preserving key; the usual finish kernel decodes the keys.
+// The block's 32 query vectors are read ONCE, coalesced, into LDS as [channel][query] (same query: broadcast, different
+// queries: different banks) -- with a flat list in emission order a wave's candidates spread over a filter workgroup's 512
+// queries, so each of the 100 query loads touched ~14 cache lines: measured, the query gather cost as much as the bank-row
+// gather (48 us each of the kernel's 87 at cfg3 shape; tools/ history in DESIGN.md 3.2b).  A lane's bank row is read 32
+// channels per round, all eight 16-byte loads issued together: one 128-byte line's worth, crossing L2 -> L1 once.
 template <typename SRC>
 __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restrict__ q, long q_sn, long q_sc,
                                                             const float *__restrict__ rows, const float *__restrict__ norms,
-                                                            const uint2 *__restrict__ list, long list_cap, long N_pad, int C,
-                                                            unsigned *__restrict__ keys2,
-                                                            const unsigned long long *__restrict__ stats)
+                                                            const uint2 *__restrict__ list, const unsigned *__restrict__ bcnt,
+                                                            long bucket_cap, long N, long N_pad, int C,
+                                                            unsigned *__restrict__ keys2)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)(stats[0] < (unsigned long long)list_cap ? stats[0] : (unsigned long long)list_cap);
-    if (i >= total) return;
-    const uint2 e = list[i];
-    const long n = (long)(e.x % (unsigned long)N_pad);
-    const SRC *qr = q + n * q_sn;
-    const float *kr = rows + (long)e.y * C;
-    float xs = 0.0f, mm = 0.0f;
-    int k = 0;
-    for (; (C & 3) == 0 && k + 4 <= C; k += 4) {  // (four loads in flight; the chains stay in ascending k)
-        const float x0 = emb_load(qr, (long)k * q_sc), x1 = emb_load(qr, (long)(k + 1) * q_sc);
-        const float x2 = emb_load(qr, (long)(k + 2) * q_sc), x3 = emb_load(qr, (long)(k + 3) * q_sc);
-        const f32x4 y4 = *(const f32x4 *)(kr + k);  // (rows are 16-byte aligned: C % 4 == 0 here, else the scalar tail)
-        const float y0 = y4[0], y1 = y4[1], y2 = y4[2], y3 = y4[3];
-        xs = fmaf(x0, x0, xs); mm = fmaf(x0, y0, mm);
-        xs = fmaf(x1, x1, xs); mm = fmaf(x1, y1, mm);
-        xs = fmaf(x2, x2, xs); mm = fmaf(x2, y2, mm);
-        xs = fmaf(x3, x3, xs); mm = fmaf(x3, y3, mm);
+    extern __shared__ __attribute__((aligned(16))) char rr_smem[];
+    float *qs = (float *)rr_smem;  // [C][QB]
+    const long b = blockIdx.x;
+    const unsigned have = bcnt[b];
+    const int cnt = (long)have < bucket_cap ? (int)have : (int)bucket_cap;
+    if (cnt == 0) return;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < QB * C; idx += 256) {
+        long n = b * QB + (idx & (QB - 1));
+        n = n < N ? n : N - 1;  // (padding queries have no candidates)
+        qs[idx] = emb_load(q + n * q_sn, (long)(idx / QB) * q_sc);
     }
-    for (; k < C; ++k) {
-        const float x = emb_load(qr, (long)k * q_sc);
-        xs = fmaf(x, x, xs);
-        mm = fmaf(x, kr[k], mm);
+    __syncthreads();
+    for (int i = tid; i < cnt; i += 256) {
+        const uint2 e = list[b * bucket_cap + i];
+        const float *x = qs + (int)((e.x % (unsigned long)N_pad) & (QB - 1));
+        const float *kr = rows + (long)e.y * C;
+        float xs = 0.0f, mm = 0.0f;
+        int k = 0;
+        for (; (C & 3) == 0 && k + 32 <= C; k += 32) {
+            f32x4 y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = *(const f32x4 *)(kr + k + 4 * j);  // (rows are 16-byte aligned: C % 4 == 0)
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const float xv = x[(k + j) * QB];
+                xs = fmaf(xv, xv, xs);
+                mm = fmaf(xv, y[j >> 2][j & 3], mm);
+            }
+        }
+        for (; k < C; ++k) {
+            const float xv = x[k * QB];
+            xs = fmaf(xv, xv, xs);
+            mm = fmaf(xv, kr[k], mm);
+        }
+        atomicMin(keys2 + e.x, key_of(fmaf(-2.0f, mm, xs + norms[e.y])));  // IntVOS.py:39
     }
-    atomicMin(keys2 + e.x, key_of(fmaf(-2.0f, mm, xs + norms[e.y])));  // IntVOS.py:39
 }
 
 // The candidate list overflowed (duplicated bank rows, a pathological threshold ...): every pair scans its object's rows in
@@ -2251,11 +2397,12 @@ void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int
         const float *no_slack = nullptr;
         unsigned long long *no_stats = nullptr;
         uint2 *no_list = nullptr;
+        unsigned *no_bcnt = nullptr;
         long no_cap = 0;
         // (the narrow kernel takes the first ten arguments; the wide one also the FILTER form's five, unused here)
         void *args[] = {(void *)&qpack, (void *)&bpack, (void *)&meta, (void *)&n_ids, (void *)&nQT, (void *)&S,
                         (void *)&N_pad, (void *)&keys, (void *)&bm, (void *)&prio, (void *)&no_thr, (void *)&no_slack,
-                        (void *)&no_stats, (void *)&no_list, (void *)&no_cap};
+                        (void *)&no_stats, (void *)&no_list, (void *)&no_cap, (void *)&no_bcnt};
         manet_profile_record(st, true, prof_channel);
         (void)hipLaunchKernel(fn, dim3((unsigned)(nQT * S)), dim3(threads), args, lds, st);
         manet_profile_record(st, false, prof_channel);
@@ -2281,6 +2428,7 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
     float *slack = (float *)(mws + ML.off_slack);
     uint2 *list = (uint2 *)(mws + ML.off_list);
     unsigned long long *stats = (unsigned long long *)(mws + ML.off_stats);
+    unsigned *bcnt = (unsigned *)(mws + ML.off_bcnt);
     // 1. pre-pass over the sub-sampled bank -> keys = U
     const int S1 = pick_splits(ML.nQT, BL.T_sub_max, 512);
     if (ML.G.steps == 2) launch_main_bf16<2, false>(qimg, bws + BL.off_sub_pack, sub_meta, n_ids, ML.nQT, S1, ML.N_pad, keys, st, 3);
@@ -2288,38 +2436,39 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
     // 2. thresholds; exact keys and counters reset
     const long pairs = (long)n_ids * ML.N_pad;
     hipLaunchKernelGGL(refine_threshold_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, (const unsigned *)keys,
-                       qimg, (long)ML.qblk_bytes, C, meta, N, ML.N_pad, n_ids, thr, slack, keys2, stats);
+                       qimg, (long)ML.qblk_bytes, C, meta, N, ML.N_pad, n_ids, thr, slack, keys2, stats, bcnt);
     // 3. filter pass over the whole bank -> candidate list
     {
         const int S = pick_splits(ML.nQT, BL.T_max, 512);
-        const size_t lds = (size_t)2 * 2 * bank_tile_bytes_u(2 * ML.G.steps, false) + (size_t)REFINE_LDS_LIST * 8;
+        const size_t lds = (size_t)2 * 2 * bank_tile_bytes_u(2 * ML.G.steps, false) + (size_t)REFINE_LDS_LIST * 8 + 4 * 256 * 4;  // + the published keys
         const void *fn = ML.G.steps == 2 ? (const void *)global_match_bf16_wide_kernel<2, 0, true>
                                          : (const void *)global_match_bf16_wide_kernel<7, 0, true>;
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const char *bpack = bws + BL.off_pack;
         int nQT = ML.nQT, Sv = S, bm = block_map_arg(ML.nQT, 512), prio = 0;
         if ((bm & 0xff) == 0) bm |= 3;  // (see split_of_block)
-        long N_pad = ML.N_pad, cap = ML.list_cap;
+        long N_pad = ML.N_pad, cap = ML.bucket_cap;
         unsigned *thr_c = thr;
         const float *slack_c = slack;
         void *args[] = {(void *)&qimg, (void *)&bpack, (void *)&meta, (void *)&n_ids, (void *)&nQT, (void *)&Sv,
                         (void *)&N_pad, (void *)&keys, (void *)&bm, (void *)&prio, (void *)&thr_c, (void *)&slack_c, (void *)&stats,
-                        (void *)&list, (void *)&cap};
+                        (void *)&list, (void *)&cap, (void *)&bcnt};
         manet_profile_record(st, true, 0);
         (void)hipLaunchKernel(fn, dim3((unsigned)(nQT * S)), dim3(256), args, lds, st);
         manet_profile_record(st, false, 0);
     }
     // 4. exact re-rank of the candidates (+ the rescue scan, a no-op unless the list overflowed), then the usual finish
     const float *rows = (const float *)(bws + BL.off_rows), *norms = (const float *)(bws + BL.off_norms);
-    const dim3 rgrid((unsigned)((ML.list_cap + 255) / 256)), sgrid((unsigned)((N + 255) / 256), (unsigned)n_ids);
+    const dim3 rgrid((unsigned)(ML.N_pad / QB)), sgrid((unsigned)((N + 255) / 256), (unsigned)n_ids);
+    const size_t rlds = (size_t)QB * C * sizeof(float);
     if (q_dtype == MANET_EMB_F32) {
-        hipLaunchKernelGGL(refine_rerank_kernel<float>, rgrid, dim3(256), 0, st, (const float *)qraw, q_sn, q_sc, rows, norms,
-                           (const uint2 *)list, ML.list_cap, ML.N_pad, C, keys2, (const unsigned long long *)stats);
+        hipLaunchKernelGGL(refine_rerank_kernel<float>, rgrid, dim3(256), rlds, st, (const float *)qraw, q_sn, q_sc, rows, norms,
+                           (const uint2 *)list, (const unsigned *)bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2);
         hipLaunchKernelGGL(refine_rescue_kernel<float>, sgrid, dim3(256), 0, st, (const float *)qraw, q_sn, q_sc, rows, norms, meta,
                            N, ML.N_pad, C, keys2, (const unsigned long long *)stats);
     } else {
-        hipLaunchKernelGGL(refine_rerank_kernel<unsigned short>, rgrid, dim3(256), 0, st, (const unsigned short *)qraw, q_sn, q_sc,
-                           rows, norms, (const uint2 *)list, ML.list_cap, ML.N_pad, C, keys2, (const unsigned long long *)stats);
+        hipLaunchKernelGGL(refine_rerank_kernel<unsigned short>, rgrid, dim3(256), rlds, st, (const unsigned short *)qraw, q_sn, q_sc,
+                           rows, norms, (const uint2 *)list, (const unsigned *)bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2);
         hipLaunchKernelGGL(refine_rescue_kernel<unsigned short>, sgrid, dim3(256), 0, st, (const unsigned short *)qraw, q_sn, q_sc,
                            rows, norms, meta, N, ML.N_pad, C, keys2, (const unsigned long long *)stats);
     }

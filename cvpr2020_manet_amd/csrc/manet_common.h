@@ -73,6 +73,17 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_dst)
                  : "memory");
 }
 
+// The same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (saddr form): one VGPR of address
+// state instead of a pair -- for kernels at the register limit.
+__device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
 // The local-window kernels' form: hardware exp2 / reciprocal (1 ulp each) instead of libm expf and an IEEE divide --
 // 6 instructions instead of ~25 per window entry (the fused kernel normalises (2d+1)^2 entries per pooled pixel:
 // 4.3 us of its 56 at d=12).  Exact where it matters: x = 0 -> 0, x = inf -> 1.  |error| <= 3e-7 absolute; the
