@@ -41,6 +41,11 @@ def test_two_rank_flow_on_one_gpu():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 10 and line["scaling"] == "weak"
     assert line["value"] > 0 and line["cpu_baseline"] is None
+    # the line says what the exchange of the timed region really was (a driver-run N-rank line shows backend nccl, world N)
+    col = line["collective"]
+    assert col["world"] == 2 and col["backend"] == "gloo" and col["ownership"] == "round_robin"
+    assert col["slab_bytes"] > 0 and col["gathered_bytes"] == 2 * col["slab_bytes"] and col["allgather_ms"] > 0
+    assert col["bank_slots_per_rank"] == 3  # cfg3: a 5-frame bank, shipped once, dealt round robin to the 2 ranks
 
 
 def test_mismatched_world_size_is_an_error():
