@@ -466,14 +466,27 @@ def also_leg(cfg, compute, device, lib, args):
     # kernel's result bit for bit
     del wl, r
     torch.cuda.empty_cache()
+    leg["exact_mode"] = exact_leg(cfg, device, lib, args)
+    return leg
+
+
+def exact_leg(cfg, device, lib, args):
+    """The same step with compute="bf16r" on fp32-stored embeddings (bf16 filter pass + exact fp32 re-rank of the rows inside
+    the rounding bound), and a live check that it IS the fp32 kernel's result: both modes on the probe frame, compared bit for
+    bit."""
+    from cvpr2020_manet_amd import ops
+    K, Wm = args.also_steps, 2
     wx = Workload(cfg, "bf16r", "f32", device, n_local=CONFIGS[cfg]["T"] + 2)
     rx = run_leg(wx, K, Wm, args, lib)
     cands, over = rx["bank"].refine_stats()
-    leg["exact_mode"] = {"dtype": "bf16r", "embeddings": "f32-stored", "value": K / rx["elapsed"], "unit": "frames/s",
-                         "ms_per_step": rx["elapsed"] / K * 1e3, "filter_kernel_ms": rx["kern_ms"],
-                         "result": "bit-equal to compute='f32' (tests/test_bf16_refine.py)",
-                         "candidate_rows_per_pair": cands / float(wx.H * wx.W * wx.n_ids), "candidate_list_overflowed": int(over)}
-    return leg
+    q = wx.frame_emb(wx.probe_frame()).permute(1, 2, 0)
+    same = bool(torch.equal(ops.global_match(rx["bank_rows"], q, rx["bank_lab"], wx.n_ids, compute="bf16r"),
+                            ops.global_match(rx["bank_rows"], q, rx["bank_lab"], wx.n_ids, compute="f32")))
+    return {"dtype": "bf16r", "embeddings": "f32-stored", "value": K / rx["elapsed"], "unit": "frames/s", "steps": K,
+            "ms_per_step": rx["elapsed"] / K * 1e3, "filter_kernel_ms": rx["kern_ms"],
+            "result": "the fp32 kernel's distances, bit for bit (tests/test_bf16_refine.py)",
+            "bit_equal_to_f32_on_probe_frame": same,
+            "candidate_rows_per_pair": cands / float(wx.H * wx.W * wx.n_ids), "candidate_list_overflowed": int(over)}
 
 
 def spawn_ranks(n, argv):
@@ -630,6 +643,9 @@ def main():
             line["cpu_baseline"] = None  # measured on rank 0 at N=1 only (see the N=1 line)
         if world == 1 and not use_dist and not args.no_also and args.cfg == 2 and args.compute == "f32":
             del wl, r, bank_rows, bank_lab
+            torch.cuda.empty_cache()
+            # the headline's own workload through the exact bf16 filter + fp32 re-rank: same bits as the fp32 line above
+            line["headline_exact_mode"] = exact_leg(2, device, lib, args)
             torch.cuda.empty_cache()
             line["also"] = []
             for cfg_, compute_ in ((3, "bf16"), (5, "bf16")):
