@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box: the round's tracked evidence.  usage: tools/capture_profiles.sh RTAG   (e.g. r03)
 #   gpurun_out/RTAG/RTAG_bench_line.json                 the default `python bench.py` line (headline + `also` legs + cpu baseline)
-#   for each of: cfg2 f32 (headline), cfg3 bf16, cfg5 bf16, cfg3 bf16r (fp32-stored embeddings)
+#   for each of: cfg2 f32 (headline), cfg3 bf16, cfg5 bf16, cfg3 bf16r and cfg2 bf16r (fp32-stored embeddings)
 #     gpurun_out/RTAG/RTAG_cfgN_<compute>_{bench_line_under_rocprof.json,kernel_stats.csv,pmc_summary.csv}
 #                                                        rocprofv3 kernel stats + separate --pmc passes (tools/profile_gpu.sh)
 #   gpurun_out/RTAG/RTAG_local_pmc_summary.csv           the local-window stage alone (tools/local_pmc.sh)
@@ -10,7 +10,7 @@
 R=$1
 mkdir -p gpurun_out/$R
 python bench.py > gpurun_out/$R/${R}_bench_line.json 2> gpurun_out/$R/${R}_bench.err
-for c in "2 f32 auto" "3 bf16 auto" "5 bf16 auto" "3 bf16r f32"; do
+for c in "2 f32 auto" "3 bf16 auto" "5 bf16 auto" "3 bf16r f32" "2 bf16r f32"; do
   set -- $c
   tag=${R}_cfg$1_$2
   tools/profile_gpu.sh ${R}/$tag --cfg $1 --compute $2 --emb $3 --steps 20 --no-also > gpurun_out/$R/${tag}_profile.log 2>&1
@@ -25,3 +25,5 @@ cp gpurun_out/$R/local/pmc_summary.csv gpurun_out/$R/${R}_local_pmc_summary.csv
 tools/e2e_launch_count.sh $R/e2e > gpurun_out/$R/${R}_e2e.log 2>&1
 cp gpurun_out/$R/e2e/per_frame_kernels.csv gpurun_out/$R/${R}_e2e_per_frame_kernels.csv
 tail -3 gpurun_out/$R/${R}_e2e.log
+python tools/pw_bench.py > gpurun_out/$R/${R}_head_pointwise.log 2>&1
+tail -8 gpurun_out/$R/${R}_head_pointwise.log

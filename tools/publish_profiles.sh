@@ -5,7 +5,8 @@ SRC=$1; R=$2
 cp gpurun_out/$SRC/${SRC}_bench_line.json profiles/${R}_bench_line.json
 cp gpurun_out/$SRC/${SRC}_local_pmc_summary.csv profiles/${R}_local_pmc_summary.csv
 cp gpurun_out/$SRC/${SRC}_e2e_per_frame_kernels.csv profiles/${R}_e2e_per_frame_kernels.csv
-for c in "2 f32 global_match_f32_pipe_kernel" "3 bf16 global_match_bf16_wide_kernel<7, 0, false>" "5 bf16 global_match_bf16_wide_kernel<7, 0, false>" "3 bf16r global_match_bf16_wide_kernel<7, 0, true>"; do
+cp gpurun_out/$SRC/${SRC}_head_pointwise.log profiles/${R}_head_pointwise.log
+for c in "2 f32 global_match_f32_pipe_kernel" "3 bf16 global_match_bf16_wide_kernel<7, 0, false>" "5 bf16 global_match_bf16_wide_kernel<7, 0, false>" "3 bf16r global_match_bf16_wide_kernel<7, 0, true>" "2 bf16r global_match_bf16_wide_kernel<7, 0, true>"; do
   IFS=' ' read -r cfg comp kern <<< "$c"
   t=${SRC}_cfg${cfg}_${comp}
   for f in bench_line_under_rocprof.json kernel_stats.csv pmc_summary.csv; do
