@@ -75,7 +75,55 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float *__res
     small[i] = argmax_at(logits, n_ids, h, w, Y, X, H, W);
 }
 
+// F.interpolate(mask.float(), size=(h, w), mode='nearest').int() (IntVOS.py:598-599) on an int64 mask, in one launch
+__global__ __launch_bounds__(256) void label_resize_kernel(const long long *__restrict__ mask, int H, int W, int h, int w,
+                                                           int *__restrict__ small)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)h * w) return;
+    const int y = (int)(i / w), x = (int)(i - (long)y * w);
+    const float sy = (float)H / (float)h, sx = (float)W / (float)w;  // aten nearest_neighbor_compute_source_index
+    int Y = (int)floorf((float)y * sy), X = (int)floorf((float)x * sx);
+    if (Y > H - 1) Y = H - 1;
+    if (X > W - 1) X = W - 1;
+    small[i] = (int)mask[(long)Y * W + X];
+}
+
+// the per-object channels of the head's input (IntVOS.py:663-669): out[o] = (global map of o, local map of o, label == o)
+__global__ __launch_bounds__(256) void head_inputs_kernel(const float *__restrict__ gmap, const float *__restrict__ lmap,
+                                                          const int *__restrict__ labels, long HW, int n_ids,
+                                                          float *__restrict__ out)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const int lab = labels[p];
+    for (int o = 0; o < n_ids; ++o) {
+        float *dst = out + (long)o * 3 * HW + p;
+        dst[0] = gmap[p * n_ids + o];
+        dst[HW] = lmap[p * n_ids + o];
+        dst[2 * HW] = lab == o ? 1.0f : 0.0f;
+    }
+}
+
 }  // namespace
+
+extern "C" int manet_label_resize_nearest(const int64_t *mask_hw, int H, int W, int h, int w, int32_t *label_small_hw,
+                                          manet_stream_t stream)
+{
+    if (!mask_hw || !label_small_hw || h <= 0 || w <= 0 || H <= 0 || W <= 0) return manet_set_error(MANET_E_INVALID, "bad arguments");
+    hipLaunchKernelGGL(label_resize_kernel, dim3((unsigned)(((long)h * w + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long *)mask_hw, H, W, h, w, (int *)label_small_hw);
+    return manet_check_launch("manet_label_resize_nearest");
+}
+
+extern "C" int manet_head_inputs_f32(const float *global_map, const float *local_map, const int32_t *labels, int64_t HW,
+                                     int n_ids, float *out, manet_stream_t stream)
+{
+    if (!global_map || !local_map || !labels || !out || HW <= 0 || n_ids <= 0) return manet_set_error(MANET_E_INVALID, "bad arguments");
+    hipLaunchKernelGGL(head_inputs_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream, global_map,
+                       local_map, (const int *)labels, (long)HW, n_ids, out);
+    return manet_check_launch("manet_head_inputs_f32");
+}
 
 extern "C" int manet_upsample_argmax(const float *logits, int n_ids, int h, int w, int H, int W, int64_t *mask_hw,
                                      int32_t *label_small_hw, manet_stream_t stream)

@@ -360,6 +360,18 @@ def _run_head(head, embedding_chw, per_object):
 
 
 # --------------------------------------------------------------------------------------------------
+_ids_cache = {}
+
+
+def _obj_ids(n_ids, device):
+    """torch.arange(0, n_ids, int32) on `device` (IntVOS.py:573 builds it per frame: one launch), made once"""
+    key = (int(n_ids), str(device))
+    t = _ids_cache.get(key)
+    if t is None:
+        t = _ids_cache[key] = torch.arange(0, n_ids, dtype=torch.int32, device=device)
+    return t
+
+
 MAX_CLIP_FRAMES = 104       # hard-coded clip length of the reference's memories (IntVOS.py:617,645)
 MAX_INTERACTIONS = 9        # IntVOS.py:641,645
 MAX_CACHED_FRAMES = 2 * MAX_CLIP_FRAMES + 8  # prepared per-frame operands kept per model (17 MB each at 480p)
@@ -561,7 +573,11 @@ class IntVOS(nn.Module):
         else:
             scale_ref_scribble_label = F.interpolate(ref_scribble_label.float(), size=(h, w), mode="nearest")
         scale_ref_scribble_label = scale_ref_scribble_label.int()
-        scale_previous_frame_label = F.interpolate(previous_frame_mask.float(), size=(h, w), mode="nearest").int()
+        if (bs == 1 and previous_frame_mask.is_cuda and not previous_frame_mask.is_floating_point()
+                and previous_frame_mask.numel() == previous_frame_mask.shape[-1] * previous_frame_mask.shape[-2]):
+            scale_previous_frame_label = ops.label_resize_nearest(previous_frame_mask, (h, w))  # the same, one launch
+        else:
+            scale_previous_frame_label = F.interpolate(previous_frame_mask.float(), size=(h, w), mode="nearest").int()
         for n in range(bs):
             # HWC views of the C-major embeddings: exactly what the kernels read coalesced
             seq_current_frame_embedding = current_frame_embedding[n].permute(1, 2, 0)
@@ -569,7 +585,7 @@ class IntVOS(nn.Module):
             seq_prev_frame_embedding = previous_frame_embedding[n].permute(1, 2, 0)
             seq_ref_scribble_label = scale_ref_scribble_label[n].permute(1, 2, 0)
             n_ids = _n_ids_from(gt_ids[n], None)
-            ref_obj_ids = torch.arange(0, n_ids, dtype=torch.int32, device=current_frame_embedding.device)
+            ref_obj_ids = _obj_ids(n_ids, current_frame_embedding.device)
 
             # ---- global map: match + normalise (:611-612) + min-merge with the memory (:615-622), fused
             mem = None
@@ -648,11 +664,17 @@ class IntVOS(nn.Module):
                 local_map_dics = (local_map_tmp_dic, local_map_dist_dic)
 
             # ---- head input [n_ids, C+3, h, w] (:663-673)
-            to_cat_previous_frame = (seq_previous_frame_label.float() == ref_obj_ids.float())
-            to_cat_nn_feature_n = nn_features_n.squeeze(0).permute(2, 3, 0, 1)
-            to_cat_previous_frame = to_cat_previous_frame.unsqueeze(-1).permute(2, 3, 0, 1).float()
-            to_cat_prev_frame_nn_feature_n = prev_frame_nn_features_n.squeeze(0).permute(2, 3, 0, 1)
-            per_object = torch.cat((to_cat_nn_feature_n, to_cat_prev_frame_nn_feature_n, to_cat_previous_frame), 1)
+            if (inference and nn_features_n.is_cuda and nn_features_n.dtype == torch.float32
+                    and prev_frame_nn_features_n.dtype == torch.float32
+                    and nn_features_n.numel() == h * w * n_ids and prev_frame_nn_features_n.numel() == h * w * n_ids):
+                # the three per-object channels written by one launch (no arange / compare / permute / cat kernels)
+                per_object = ops.head_inputs(nn_features_n, prev_frame_nn_features_n, seq_previous_frame_label, n_ids, (h, w))
+            else:
+                to_cat_previous_frame = (seq_previous_frame_label.float() == ref_obj_ids.float())
+                to_cat_nn_feature_n = nn_features_n.squeeze(0).permute(2, 3, 0, 1)
+                to_cat_previous_frame = to_cat_previous_frame.unsqueeze(-1).permute(2, 3, 0, 1).float()
+                to_cat_prev_frame_nn_feature_n = prev_frame_nn_features_n.squeeze(0).permute(2, 3, 0, 1)
+                per_object = torch.cat((to_cat_nn_feature_n, to_cat_prev_frame_nn_feature_n, to_cat_previous_frame), 1)
             pred_ = _run_head(dynamic_seghead, current_frame_embedding[n], per_object)
             dic_tmp[seq_names[n]] = pred_.permute(1, 0, 2, 3)
 

@@ -537,6 +537,43 @@ def upsample_argmax(logits, size, want_small=True):
     return mask, small
 
 
+def label_resize_nearest(mask, size):
+    """F.interpolate(mask.float(), size=(h, w), mode='nearest').int() (IntVOS.py:598-599) in one launch.
+    mask: integer [1, 1, H, W] (or [1, H, W] / [H, W]) -> int32 [1, 1, h, w]."""
+    lib = _lib.load()
+    _need_gpu(mask, "mask")
+    if mask.is_floating_point() or mask.numel() != mask.shape[-1] * mask.shape[-2]:
+        raise ValueError("mask must be ONE integer image [.., H, W]")
+    m = mask.to(torch.int64).contiguous()
+    H, W = int(m.shape[-2]), int(m.shape[-1])
+    h, w = int(size[0]), int(size[1])
+    out = torch.empty((1, 1, h, w), dtype=torch.int32, device=m.device)
+    with torch.cuda.device(m.device):
+        rc = lib.manet_label_resize_nearest(m.data_ptr(), H, W, h, w, out.data_ptr(), _stream_ptr(m.device))
+    _lib.check(rc, "manet_label_resize_nearest")
+    return out
+
+
+def head_inputs(global_map, local_map, labels, n_ids, size):
+    """The per-object channels of the head's input (IntVOS.py:663-669) in one launch:
+    [n_ids, 3, h, w] = (global map of o, local map of o, labels == o), size = (h, w); global_map / local_map hold
+    h*w*n_ids elements laid out [h, w, n_ids] (any view shape), labels h*w integers."""
+    _refuse_autograd("head_inputs", global_map, local_map)
+    lib = _lib.load()
+    _need_gpu(global_map, "global_map")
+    lab = labels.to(torch.int32).contiguous()
+    h, w = int(size[0]), int(size[1])
+    if lab.numel() != h * w or global_map.numel() != h * w * n_ids or local_map.numel() != h * w * n_ids:
+        raise ValueError("global_map / local_map must hold h*w*n_ids elements as [h, w, n_ids], labels h*w")
+    g, l = global_map.float().contiguous(), local_map.float().contiguous()
+    out = torch.empty((n_ids, 3, h, w), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = lib.manet_head_inputs_f32(g.data_ptr(), l.data_ptr(), lab.data_ptr(), h * w, n_ids, out.data_ptr(),
+                                       _stream_ptr(g.device))
+    _lib.check(rc, "manet_head_inputs_f32")
+    return out
+
+
 def fold_bn(bn):
     """eval-mode BatchNorm as per-channel (scale, shift): y = x * scale + shift"""
     inv = torch.rsqrt(bn.running_var.detach().float() + bn.eps)

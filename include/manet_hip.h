@@ -270,6 +270,18 @@ int manet_correlation_forward(const void *in1, const void *in2, int dtype, int B
 int manet_upsample_argmax(const float *logits, int n_ids, int h, int w, int H, int W, int64_t *mask_hw,
                           int32_t *label_small_hw, manet_stream_t stream);
 
+/* The two glue steps on either side of the matches in a propagated frame, one launch each:
+ *   manet_label_resize_nearest: F.interpolate(previous_frame_mask.float(), size=(h, w), mode='nearest').int()
+ *     (networks/IntVOS.py:598-599) on the int64 [H][W] mask -> int32 [h][w] (aten's nearest source index:
+ *     min(floor(dst * (in / out)), in - 1), the ratio in float);
+ *   manet_head_inputs_f32: the per-object channels of the head's input (networks/IntVOS.py:663-669, the three tensors
+ *     torch.cat joins behind the repeated embedding): out [n_ids][3][HW] = (global_map[p][o], local_map[p][o], labels[p] == o)
+ *     from global_map / local_map [HW][n_ids] fp32 and labels [HW] int32. */
+int manet_label_resize_nearest(const int64_t *mask_hw, int H, int W, int h, int w, int32_t *label_small_hw,
+                               manet_stream_t stream);
+int manet_head_inputs_f32(const float *global_map, const float *local_map, const int32_t *labels, int64_t HW, int n_ids,
+                          float *out, manet_stream_t stream);
+
 /* Depthwise 7x7 convolution (padding 3, one filter per channel) + bias + BatchNorm(eval) + ReLU, fused:
  * the first half of the reference's _split_separable_conv2d (IntVOS.py:491-493,500-502), the building block
  * of DynamicSegHead.  in/out [B][C][h][w] fp32 contiguous, weight [C][7][7],

@@ -55,3 +55,30 @@ def test_gpu_full_size_vs_torch_ops_and_oracle(oracle):
     om, osm = oracle.upsample_argmax(logits.cpu().numpy(), (480, 854))
     np.testing.assert_array_equal(mask.cpu().numpy(), om)  # same arithmetic as the oracle: exact
     np.testing.assert_array_equal(small.cpu().numpy(), osm)
+
+
+@pytest.mark.gpu
+def test_label_resize_and_head_inputs_match_the_framework_ops():
+    """ops.label_resize_nearest == F.interpolate(mask.float(), size, mode='nearest').int() (IntVOS.py:598-599) and
+    ops.head_inputs == the eq / permute / cat assembly of the head's per-object channels (IntVOS.py:663-669), exactly."""
+    import torch
+    import torch.nn.functional as F
+    from cvpr2020_manet_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for (H, W, h, w, n_ids) in ((480, 854, 120, 214, 3), (33, 47, 9, 12, 5), (720, 1280, 180, 320, 6), (7, 5, 7, 5, 1),
+                                (10, 10, 23, 31, 2)):
+        mask = torch.randint(0, n_ids + 1, (1, 1, H, W), generator=g, device="cuda", dtype=torch.int64)
+        want = F.interpolate(mask.float(), size=(h, w), mode="nearest").int()
+        got = ops.label_resize_nearest(mask, (h, w))
+        assert got.dtype == torch.int32 and torch.equal(got, want)
+        gm = torch.rand(1, h, w, n_ids, 1, generator=g, device="cuda")
+        lm = torch.rand(1, h, w, n_ids, 1, generator=g, device="cuda")
+        lab = want[0].permute(1, 2, 0)  # [h, w, 1] as the module holds it
+        ids = torch.arange(0, n_ids, dtype=torch.int32, device="cuda")
+        prev = (lab.float() == ids.float()).unsqueeze(-1).permute(2, 3, 0, 1).float()
+        ref = torch.cat((gm.squeeze(0).permute(2, 3, 0, 1), lm.squeeze(0).permute(2, 3, 0, 1), prev), 1)
+        assert torch.equal(ops.head_inputs(gm, lm, lab, n_ids, (h, w)), ref)
+    with pytest.raises(ValueError):
+        ops.label_resize_nearest(torch.zeros(1, 1, 4, 4, device="cuda"), (2, 2))  # floating-point mask
+    with pytest.raises(ValueError):
+        ops.head_inputs(torch.zeros(5, device="cuda"), torch.zeros(5, device="cuda"), torch.zeros(2, 2, device="cuda"), 2, (2, 2))
