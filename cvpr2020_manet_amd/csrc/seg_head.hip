@@ -36,8 +36,12 @@ constexpr int DW_NP = (DW_TY + 2 * DW_R) / 2;  // 35 row pairs per image (rows y
 constexpr int DW_IMG = DW_NP * DW_LW * 2;    // floats per interleaved image
 
 // FAST: w even (every aligned column pair is inside or outside the image as a whole, rows are 8-byte aligned)
-template <bool FAST>
-__global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *__restrict__ in, int C, int h, int w,
+// r3b: a workgroup owns one (tile, channel) and walks the BATCH items (the objects of a frame): the next item's global loads
+// are issued before the current item's arithmetic and land under it, the weights are read once.  (One workgroup per
+// (tile, plane), as before: every workgroup of a launch read, then computed, then wrote, in step with its neighbours -- the
+// memory system saw alternating read and write bursts: 53 us for 158 MB at [3,256,120,214].)
+template <bool FAST, int ABL = 0>
+__global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *__restrict__ in, int B, int C, int h, int w,
                                                                    const float *__restrict__ weight,
                                                                    const float *__restrict__ bias,
                                                                    const float *__restrict__ scale,
@@ -46,10 +50,9 @@ __global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *
 {
     // E: element (r, col) at ((r >> 1) * LW + col) * 2 + (r & 1), r = row - (y0 - 3); O: the same for r - 1
     __shared__ __attribute__((aligned(16))) float tile[2 * DW_IMG];
-    const int plane_id = blockIdx.z;  // b * C + c
-    const int c = plane_id % C;
+    const int c = blockIdx.z;
     const int x0 = blockIdx.x * DW_TX, y0 = blockIdx.y * DW_TY;
-    const float *src = in + (long)plane_id * h * w;
+    const long plane = (long)h * w;
     const int tid = threadIdx.x;
     // staging item = (row pair p, column pair q): rows 2p, 2p+1, 2p+2 of the tile, two columns -- one b128 store into E
     // (rows 2p, 2p+1) and one into O (rows 2p+1, 2p+2).  Branch-free: clamped addresses, values selected afterwards.
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *
     // rectifies and stores.  Written as one loop, hipcc sinks each load into the branch of its select and waits
     // vmcnt(0) there: 15 serial L2 round trips per thread (r2 trace: this, not the 392 FMAs, was the kernel's time).
     f32x2 ld[KI][3];
+    unsigned off[KI][3];  // element offsets inside a plane (the same for every batch item)
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
         const int i = tid + 256 * k;
@@ -66,89 +70,115 @@ __global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
             const int yc = min(max(y0 - DW_R + 2 * p + e, 0), h - 1);
-            // (unsigned element offsets: the loads take the scalar-base + 32-bit-offset form, no 64-bit address VALU)
-            if (FAST) {
-                ld[k][e] = *(const f32x2 *)(src + (unsigned)(yc * w + min(max(xx, 0), w - 2)));
-            } else {
-                ld[k][e][0] = src[(unsigned)(yc * w + min(max(xx, 0), w - 1))];
-                ld[k][e][1] = src[(unsigned)(yc * w + min(max(xx + 1, 0), w - 1))];
+            off[k][e] = (unsigned)(yc * w + min(max(xx, 0), FAST ? w - 2 : w - 1));
+        }
+    }
+    auto issue_loads = [&](int b) __attribute__((always_inline)) {
+        // (unsigned element offsets: the loads take the scalar-base + 32-bit-offset form, no 64-bit address VALU)
+        const float *src = in + ((long)b * C + c) * plane;
+#pragma unroll
+        for (int k = 0; k < KI; ++k) {
+            const int i = tid + 256 * k;
+            const int xx = x0 - 4 + 2 * (i - (i / NQ) * NQ);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                if (ABL & 2) {
+                    ld[k][e] = f32x2{(float)off[k][e], (float)xx};
+                } else if (FAST) {
+                    ld[k][e] = *(const f32x2 *)(src + off[k][e]);
+                } else {
+                    ld[k][e][0] = src[off[k][e]];
+                    ld[k][e][1] = src[(unsigned)(off[k][e] - (unsigned)min(max(xx, 0), w - 1) + (unsigned)min(max(xx + 1, 0), w - 1))];
+                }
             }
         }
-    }
-#pragma unroll
-    for (int k = 0; k < KI; ++k) asm volatile("" : "+v"(ld[k][0]), "+v"(ld[k][1]), "+v"(ld[k][2]));
-#pragma unroll
-    for (int k = 0; k < KI; ++k) {
-        const int i = tid + 256 * k;
-        const int p = i / NQ, q = i - p * NQ;
-        const int xx = x0 - 4 + 2 * q;
-        const bool iok = i < NITEM;
-        f32x2 rv[3];
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            const int yy = y0 - DW_R + 2 * p + e;
-            const bool yok = yy >= 0 && yy < h && iok;
-            rv[e][0] = (yok && xx >= 0 && xx < w) ? ld[k][e][0] : 0.0f;
-            rv[e][1] = (yok && xx + 1 >= 0 && xx + 1 < w) ? ld[k][e][1] : 0.0f;
-            if (relu_in) rv[e] = __builtin_elementwise_max(rv[e], f32x2{0.0f, 0.0f});
-        }
-        if (iok) {
-            float *d = tile + (p * DW_LW + 2 * q) * 2;
-            *(f32x4 *)d = f32x4{rv[0][0], rv[1][0], rv[0][1], rv[1][1]};
-            *(f32x4 *)(d + DW_IMG) = f32x4{rv[1][0], rv[2][0], rv[1][1], rv[2][1]};
-        }
-    }
-    __syncthreads();
-    const int t = tid >> 3, tg = tid & 7;  // output row pair (2t, 2t+1), group of 8 columns
-    if (t >= DW_TY / 2) return;            // (no barrier below)
+    };
     const float *wk = weight + (long)c * DW_K * DW_K;
-    f32x2 acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = f32x2{0.0f, 0.0f};
-#pragma unroll
-    for (int ky = 0; ky < DW_K; ++ky) {
-        // input rows (2t + ky, 2t + ky + 1): pair t + ky/2 of E (ky even) or pair t + (ky-1)/2 of O (ky odd); output
-        // column 8 tg + j, tap kx reads LDS column 8 tg + j + kx + 1 (LDS column 0 is image column x0 - 4)
-        const float *row = tile + ((ky & 1) ? DW_IMG : 0) + ((t + (ky >> 1)) * DW_LW + 8 * tg) * 2;
-        // (ties the reads of this kernel row behind the previous row's arithmetic: the fully unrolled loop otherwise
-        // holds all the reads in flight and the register count halves the occupancy)
-        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])::"memory");
-        f32x2 win[16];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const f32x4 u = *(const f32x4 *)(row + 4 * i);
-            win[2 * i] = f32x2{u[0], u[1]};
-            win[2 * i + 1] = f32x2{u[2], u[3]};
-        }
-#pragma unroll
-        for (int kx = 0; kx < DW_K; ++kx) {
-            const float wv = wk[ky * DW_K + kx];
-            const f32x2 w2 = {wv, wv};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = __builtin_elementwise_fma(win[kx + j + 1], w2, acc[j]);
-        }
-    }
     const float bc = bias ? bias[c] : 0.0f, sc = scale ? scale[c] : 1.0f, sh = shift ? shift[c] : 0.0f;
-    const int x = x0 + 8 * tg;
+    const int t = tid >> 3, tg = tid & 7;  // output row pair (2t, 2t+1), group of 8 columns
+    issue_loads(0);
+    for (int b = 0; b < B; ++b) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int y = y0 + 2 * t + e;
-        if (y >= h) continue;
-        float *dst = out + (long)plane_id * h * w + (unsigned)(y * w + x);
-        float r[8];
+        for (int k = 0; k < KI; ++k) asm volatile("" : "+v"(ld[k][0]), "+v"(ld[k][1]), "+v"(ld[k][2]));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float o = fmaf(acc[j][e] + bc, sc, sh);
-            r[j] = relu ? fmaxf(o, 0.0f) : o;
+        for (int k = 0; k < KI; ++k) {
+            const int i = tid + 256 * k;
+            const int p = i / NQ, q = i - p * NQ;
+            const int xx = x0 - 4 + 2 * q;
+            const bool iok = i < NITEM;
+            f32x2 rv[3];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const int yy = y0 - DW_R + 2 * p + e;
+                const bool yok = yy >= 0 && yy < h && iok;
+                rv[e][0] = (yok && xx >= 0 && xx < w) ? ld[k][e][0] : 0.0f;
+                rv[e][1] = (yok && xx + 1 >= 0 && xx + 1 < w) ? ld[k][e][1] : 0.0f;
+                if (relu_in) rv[e] = __builtin_elementwise_max(rv[e], f32x2{0.0f, 0.0f});
+            }
+            if (iok) {
+                float *d = tile + (p * DW_LW + 2 * q) * 2;
+                *(f32x4 *)d = f32x4{rv[0][0], rv[1][0], rv[0][1], rv[1][1]};
+                *(f32x4 *)(d + DW_IMG) = f32x4{rv[1][0], rv[2][0], rv[1][1], rv[2][1]};
+            }
         }
-        if (FAST && x + 7 < w) {  // w even, plane 8-byte aligned: float2 stores are always aligned
+        // LDS-only barriers: __syncthreads() is also a release fence for GLOBAL memory -- it would wait out the previous
+        // item's output stores (s_waitcnt vmcnt(0)) in front of every barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (b + 1 < B) issue_loads(b + 1);  // in flight under this item's arithmetic
+        if (t < DW_TY / 2) {
+            f32x2 acc[8];
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) *(f32x2 *)(dst + j) = f32x2{r[j], r[j + 1]};
-        } else {
+            for (int j = 0; j < 8; ++j) acc[j] = f32x2{0.0f, 0.0f};
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (x + j < w) dst[j] = r[j];
+            for (int ky = 0; ky < ((ABL & 1) ? 1 : DW_K); ++ky) {
+                // input rows (2t + ky, 2t + ky + 1): pair t + ky/2 of E (ky even) or pair t + (ky-1)/2 of O (ky odd); output
+                // column 8 tg + j, tap kx reads LDS column 8 tg + j + kx + 1 (LDS column 0 is image column x0 - 4)
+                const float *row = tile + ((ky & 1) ? DW_IMG : 0) + ((t + (ky >> 1)) * DW_LW + 8 * tg) * 2;
+                // (ties the reads of this kernel row behind the previous row's arithmetic: the fully unrolled loop otherwise
+                // holds all the reads in flight and the register count halves the occupancy)
+                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])::"memory");
+                f32x2 win[16];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 u = *(const f32x4 *)(row + 4 * i);
+                    win[2 * i] = f32x2{u[0], u[1]};
+                    win[2 * i + 1] = f32x2{u[2], u[3]};
+                }
+#pragma unroll
+                for (int kx = 0; kx < DW_K; ++kx) {
+                    const float wv = wk[ky * DW_K + kx];
+                    const f32x2 w2 = {wv, wv};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = __builtin_elementwise_fma(win[kx + j + 1], w2, acc[j]);
+                }
+            }
+            const int x = x0 + 8 * tg;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int y = y0 + 2 * t + e;
+                if (y >= h) continue;
+                float *dst = out + ((long)b * C + c) * plane + (unsigned)(y * w + x);
+                float r[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float o = fmaf(acc[j][e] + bc, sc, sh);
+                    r[j] = relu ? fmaxf(o, 0.0f) : o;
+                }
+                if (FAST && x + 7 < w) {  // w even, plane 8-byte aligned: float2 stores are always aligned
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) *(f32x2 *)(dst + j) = f32x2{r[j], r[j + 1]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (x + j < w) dst[j] = r[j];
+                }
+            }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next item's staging overwrites the tile)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
 }
 
@@ -588,13 +618,21 @@ extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, 
 {
     if (!in || !weight || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || (long)B * C > 65535)
         return manet_set_error(MANET_E_INVALID, "bad arguments (B*C must be <= 65535)");
-    dim3 grid((unsigned)((w + DW_TX - 1) / DW_TX), (unsigned)((h + DW_TY - 1) / DW_TY), (unsigned)(B * C));
-    if (w % 2 == 0 && w >= 2 && ((size_t)in & 7) == 0 && ((size_t)out & 7) == 0)
-        hipLaunchKernelGGL(dwconv7x7_bn_relu_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, C, h, w, weight,
-                           bias, bn_scale, bn_shift, relu, relu_in, out);
-    else
-        hipLaunchKernelGGL(dwconv7x7_bn_relu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, C, h, w, weight,
-                           bias, bn_scale, bn_shift, relu, relu_in, out);
+    if (C > 65535) return manet_set_error(MANET_E_INVALID, "C must be <= 65535");
+    dim3 grid((unsigned)((w + DW_TX - 1) / DW_TX), (unsigned)((h + DW_TY - 1) / DW_TY), (unsigned)C);
+#define DW_LAUNCH(F_, A_)                                                                                              \
+    hipLaunchKernelGGL((dwconv7x7_bn_relu_kernel<F_, A_>), grid, dim3(256), 0, (hipStream_t)stream, in, B, C, h, w, weight, bias, \
+                       bn_scale, bn_shift, relu, relu_in, out)
+    if (w % 2 == 0 && w >= 2 && ((size_t)in & 7) == 0 && ((size_t)out & 7) == 0) {
+        switch (manet_tune_get(MANET_TUNE_ABLATION, 0)) {  // timing experiments only (tools/pw_bench.py --dw)
+        case 1: DW_LAUNCH(true, 1); break;
+        case 2: DW_LAUNCH(true, 2); break;
+        case 3: DW_LAUNCH(true, 3); break;
+        default: DW_LAUNCH(true, 0);
+        }
+    } else
+        DW_LAUNCH(false, 0);
+#undef DW_LAUNCH
     return manet_check_launch("manet_dwconv7x7_bn_relu_f32");
 }
 

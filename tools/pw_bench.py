@@ -37,6 +37,21 @@ if "--ablate" in sys.argv:  # needs MANET_TUNING=1: 1 no stores, 2 no LDS reads 
             print("ablation %d: %.1f us" % (abl, timeit(lambda: ops.conv1x1_split(x, sw, b2))))
         lib.manet_tune_set(3, 0)
     sys.exit(0)
+if "--dw" in sys.argv:  # the depthwise kernel; with MANET_TUNING=1 also its ablations: 1 one kernel row only, 2 no global loads
+    from cvpr2020_manet_amd import _lib
+    lib = _lib.load()
+    with torch.no_grad():
+        x = torch.randn(3, 256, 120, 214, device="cuda")
+        wt = torch.randn(256, 1, 7, 7, device="cuda")
+        sc, sh = torch.rand(256, device="cuda") + 0.5, torch.randn(256, device="cuda")
+        for abl in ((0, 1, 2, 3) if os.environ.get("MANET_TUNING") == "1" else (0,)):
+            if abl:
+                assert lib.manet_tune_set(3, abl) == 0
+            t = timeit(lambda: ops.dwconv7x7_bn_relu(x, wt, None, scale=sc, shift=sh, relu_in=True))
+            print("depthwise [3,256,120,214] ablation %d: %.1f us (%.2f TB/s over in + out)" % (abl, t, 2 * x.numel() * 4 / t / 1e6))
+        if os.environ.get("MANET_TUNING") == "1":
+            lib.manet_tune_set(3, 0)
+    sys.exit(0)
 with torch.no_grad():
     for (B, cin) in ((3, 256), (2, 256), (1, 100), (3, 3)):
         x = torch.randn(B, cin, 120, 214, device="cuda")
