@@ -79,6 +79,24 @@ def test_gpu_full_size_vs_framework_conv():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 3, 61, 65), (3, 5, 9, 13), (2, 4, 130, 71), (4, 2, 7, 7), (2, 3, 60, 64), (3, 2, 121, 130)])
+def test_depthwise_batch_walk_odd_widths_and_tile_edges(shape):
+    """the depthwise kernel walks the batch items of a (tile, channel) with the next item's loads in flight: every item,
+    odd and even widths (the 4-byte and the 8-byte load path), one / several tiles per axis, against torch's conv + BN (+ReLU)"""
+    from cvpr2020_manet_amd import ops
+    B, C, h, w = shape
+    torch.manual_seed(B * 1000 + w)
+    conv = torch.nn.Conv2d(C, C, 7, padding=3, groups=C).cuda()
+    bn = torch.nn.BatchNorm2d(C).cuda().eval()
+    bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(B, C, h, w, device="cuda")
+    with torch.no_grad():
+        torch.testing.assert_close(ops.dwconv7x7_bn_relu(x, conv.weight, conv.bias, bn), torch.relu(bn(conv(x))), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(ops.dwconv7x7_bn_relu(x, conv.weight, conv.bias, bn, relu=False, relu_in=True),
+                                   bn(conv(torch.relu(x))), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
 def test_output_layer_and_deferred_relu_on_gpu():
     """ops.relu_conv1x1_c1 == Conv2d(C, 1, 1)(relu(x)); dwconv's relu_in == dwconv(relu(x)) bit for bit; and the whole
     DynamicSegHead fast path (ReLUs deferred into the next block, fused output layer) == the module's literal form."""
