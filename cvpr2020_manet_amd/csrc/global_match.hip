@@ -718,7 +718,8 @@ __device__ __forceinline__ float min3p(float m, float a, float b)
 // workgroup load its 256-query operand for a single tile.  The kernel re-decides: S' = clamp(small_S, 1, T) splits with
 // small_S = resident workgroup slots / query tiles -- one full round of workgroups, whole tiles each -- and a flat
 // block -> (tile, split) map (such a bank fits every XCD's L2 anyway).  The minimum is order-independent: same bits.
-// `block_map`: bits 0-7 = tuning (0: XCD-aware, 1: tile fastest, 2: split fastest), bits 8.. = small_S.
+// `block_map`: bits 0-7 = tuning (0: XCD-aware, 1: tile fastest, 2: split fastest, 4..7: XCD-aware with 2..5 splits
+// fastest), bits 8.. = small_S.
 __device__ __forceinline__ bool split_of_block(int b, int nQT, int S, int T, int block_map, int &qt, int &s, int &t0,
                                                int &t1)
 {
@@ -742,6 +743,18 @@ __device__ __forceinline__ bool split_of_block(int b, int nQT, int S, int T, int
         // spread over the whole bank, i.e. over all objects, so most of an object's splits start after earlier ones of the
         // same object have published their tightened thresholds
         if (bm == 3 && (S & 7) == 0) s = xcd * (S >> 3) + idx / nQT;
+    } else if (bm >= 4 && bm <= 7 && (S & 7) == 0) {
+        // XCD-aware with PB splits fastest: the workgroups of an XCD that are resident together cover 64 / PB query tiles x
+        // PB of the XCD's splits -- a query operand is loaded by PB workgroups at about the same time (one L2 miss, PB - 1
+        // hits) at the price of PB splits streaming through the L2 side by side
+        const int PB = bm - 2, S8 = S >> 3;
+        const int xcd = b & 7, idx = b >> 3;
+        const int g = idx / (nQT * PB), r = idx - g * (nQT * PB);
+        const int pbg = (S8 - g * PB) < PB ? (S8 - g * PB) : PB;
+        if (pbg <= 0) return false;
+        qt = r / pbg;
+        s = xcd + 8 * (g * PB + (r - qt * pbg));
+        if (qt >= nQT) return false;
     } else if (bm == 1) {
         qt = b % nQT;
         s = b / nQT;
@@ -2303,13 +2316,30 @@ int check_common(int64_t N, int64_t M0, int C, int n_ids, int k_nn, int compute)
     return MANET_OK;
 }
 
-// the kernels' `block_map` argument: tuning bits + small_S (see split_of_block)
-int block_map_arg(int nQT, int slots)
+// the kernels' `block_map` argument: mapping bits + small_S (see split_of_block).
+// Mapping (r3b): XCD-aware with PB splits fastest, PB = how many of this bank's splits fit an XCD's L2 side by side
+// (<= 3; 2.4 MB of the 4 MB: the query operands in flight want the rest).  The workgroups of an XCD that are resident
+// together then cover 64 / PB query tiles x PB splits instead of 64 x 1, a query operand is fetched over the fabric once
+// per PB workgroups, and the splits still stream through the L2 once.  Measured (FETCH_SIZE x 2, kernel time unchanged
+// within 0.3 %): cfg2 fp32 692 -> 420 MB per launch (PB = 2; PB = 3: 538), cfg3 bf16 277 -> 142 MB (PB = 3; 4: 168),
+// cfg5 bf16 1.26 GB at PB = 1, which its 1.6 MB splits keep (PB = 3: 1.64 GB).
+thread_local double tl_bank_bytes_hint = 0.0;  // packed bytes of the bank about to be matched (set by the entry points)
+int block_map_arg(int nQT, int slots, int S = 0)
 {
     int small_S = slots / (nQT > 0 ? nQT : 1);
     if (small_S < 1) small_S = 1;
     if (small_S > 4096) small_S = 4096;
-    return (manet_tune_get(MANET_TUNE_BLOCK_MAP, 0) & 0xff) | (small_S << 8);
+    int bm = manet_tune_get(MANET_TUNE_BLOCK_MAP, -1);
+    if (bm < 0) {
+        bm = 0;
+        if (S >= 16 && (S & 7) == 0 && tl_bank_bytes_hint > 0.0) {
+            int pb = (int)(2.4e6 / (tl_bank_bytes_hint / S));
+            pb = pb > 3 ? 3 : pb;
+            if (pb > S / 8) pb = S / 8;
+            if (pb >= 2) bm = pb + 2;
+        }
+    }
+    return (bm & 0xff) | (small_S << 8);
 }
 
 template <int KS, int KNN, bool ARG = false>
@@ -2322,7 +2352,7 @@ void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int 
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     manet_profile_record(st, true);
     hipLaunchKernelGGL((global_match_f32_kernel<KS, KNN, ARG>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack,
-                       bpack, meta, n_ids, nQT, S, N_pad, keys, topk, block_map_arg(nQT, 512));
+                       bpack, meta, n_ids, nQT, S, N_pad, keys, topk, block_map_arg(nQT, 512, S));
     manet_profile_record(st, false);
 }
 
@@ -2335,7 +2365,7 @@ void launch_main_f32_pipe(const char *qpack, const char *bpack, const int *meta,
                               (int)lds);
     manet_profile_record(st, true);
     hipLaunchKernelGGL((global_match_f32_pipe_kernel<KS>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack, bpack, meta,
-                       n_ids, nQT, S, N_pad, keys, block_map_arg(nQT, 512));
+                       n_ids, nQT, S, N_pad, keys, block_map_arg(nQT, 512, S));
     manet_profile_record(st, false);
 }
 
@@ -2348,7 +2378,7 @@ void launch_main_bf16_v(const char *qpack, const char *bpack, const int *meta, i
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     manet_profile_record(st, true);
     hipLaunchKernelGGL((global_match_bf16_kernel<KSB, X3, TPS, DMA>), dim3((unsigned)(nQT * S)), dim3(512), lds, st,
-                       qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, block_map_arg(nQT, 256),
+                       qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, block_map_arg(nQT, 256, S),
                        young_prio);
     manet_profile_record(st, false);
 }
@@ -2392,7 +2422,7 @@ void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int
             if (!fn) fn = (const void *)global_match_bf16_wide_kernel<KSB, 0>;
         }
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        int bm = block_map_arg(nQT, narrow ? 256 : 512);
+        int bm = block_map_arg(nQT, narrow ? 256 : 512, S);
         unsigned *no_thr = nullptr;
         const float *no_slack = nullptr;
         unsigned long long *no_stats = nullptr;
@@ -2431,6 +2461,7 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
     unsigned *bcnt = (unsigned *)(mws + ML.off_bcnt);
     // 1. pre-pass over the sub-sampled bank -> keys = U
     const int S1 = pick_splits(ML.nQT, BL.T_sub_max, 512);
+    tl_bank_bytes_hint = (double)BL.T_sub_max * (double)BL.tile_bytes;  // (block_map_arg: the pre-pass's bank)
     if (ML.G.steps == 2) launch_main_bf16<2, false>(qimg, bws + BL.off_sub_pack, sub_meta, n_ids, ML.nQT, S1, ML.N_pad, keys, st, 3);
     else launch_main_bf16<7, false>(qimg, bws + BL.off_sub_pack, sub_meta, n_ids, ML.nQT, S1, ML.N_pad, keys, st, 3);
     // 2. thresholds; exact keys and counters reset
@@ -2738,6 +2769,7 @@ int manet_global_match_prepared_ex(const void *query, int emb_dtype, int64_t q_s
     const bool two_per_cu = compute == MANET_COMPUTE_F32 ||
                             (compute == MANET_COMPUTE_BF16 && !(bv & (16 | 64)) && ML.G.steps != 9);
     int S = pick_splits(ML.nQT, BL.T_max, two_per_cu ? 512 : 256);
+    tl_bank_bytes_hint = (double)BL.T_max * (double)BL.tile_bytes;  // (block_map_arg)
     {
         int forced = manet_tune_get(MANET_TUNE_SPLITS, 0);  // tuning only
         if (forced > 0) S = (forced + 7) / 8 * 8;
@@ -2855,6 +2887,7 @@ int manet_global_match_arg_f32(const float *query, int64_t q_stride_n, int64_t q
                            mws + ML.off_q, nullptr, 0, st);
     if (rc) return rc;
     int S = pick_splits(ML.nQT, BL.T_max, 512);
+    tl_bank_bytes_hint = (double)BL.T_max * (double)BL.tile_bytes;  // (block_map_arg)
     const char *qpack = mws + ML.off_q, *bpack = bws + BL.off_pack;
     unsigned *keys = (unsigned *)(mws + ML.off_keys);
     switch (pick_ks(C)) {
