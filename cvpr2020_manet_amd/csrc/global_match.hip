@@ -2477,7 +2477,10 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const char *bpack = bws + BL.off_pack;
         int nQT = ML.nQT, Sv = S, bm = block_map_arg(ML.nQT, 512), prio = 0;
-        if ((bm & 0xff) == 0) bm |= 3;  // (see split_of_block)
+        // (see split_of_block) the spread map.  (PB splits fastest on top of it, as the plain kernels have it: fabric fetch
+        // of this pass 301 -> 176 MB at cfg3 shape, but concurrent splits of one object share thresholds later --
+        // 4.3 -> 5.05 candidate rows per pair -- and the step got 1 % slower: not taken.)
+        if ((bm & 0xff) == 0) bm |= 3;
         long N_pad = ML.N_pad, cap = ML.bucket_cap;
         unsigned *thr_c = thr;
         const float *slack_c = slack;
