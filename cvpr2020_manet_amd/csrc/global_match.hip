@@ -53,7 +53,7 @@ constexpr int REFINE_SUB = MANET_REFINE_SUB;
 #define MANET_REFINE_XCHG_MASK 3
 #endif
 constexpr int REFINE_XCHG_MASK = MANET_REFINE_XCHG_MASK;  // threshold exchange every (mask + 1) steps
-constexpr int REFINE_CAP = 16;  // capacity of the flat candidate list, in rows per (query, object) pair ON AVERAGE
+constexpr int REFINE_CAP = 32;  // capacity of a candidate bucket (one per 32-query block), in rows per (query, object) pair ON AVERAGE
 constexpr int REFINE_LDS_LIST = 2048;  // candidate entries a filter workgroup collects in LDS before it appends them in bulk
 
 // Packed operand image of one row block: `units` 16-byte units per row, stored [unit][row][16 B].
@@ -1675,13 +1675,34 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     // A qualifying row goes to the WAVE's own LDS list first -- its fill count lives in a scalar register, a hit costs a
     // ballot, a population count and a ds_write, no atomic (a returning global atomic per row stalled the wave for a memory
     // round trip: 2x the kernel's time; a returning LDS atomic: +45 %) -- and reaches the global list in bulk when the wave
-    // is done; rows beyond a sub-list's capacity raise the overflow flag (refine_rescue_kernel).
+    // is done, or earlier when a sub-list fills up (flush_sub).
     // The wave's list is four sub-lists, one per query block: the re-rank kernel's waves then read 32 neighbouring queries
     // (for a fixed channel one 128-byte line of the C-major embedding) instead of the wave's 128.
     constexpr int WL = REFINE_LDS_LIST / NW / NQB;  // entries per wave and query block
     uint2 *fl = (uint2 *)(smem + 2 * STEP_BYTES) + wave * (WL * NQB);
     int wl_n[NQB] = {0, 0, 0, 0};  // (wave-uniform)
-    auto emit = [&](const f32x16 &c, float t, int j, int row0) __attribute__((always_inline)) {
+    int wl_total = 0;              // (statistics)
+    // sub-list j of this wave -> its bucket of the global list (block 16 qt + 4 wave + j): one returning atomic reserves the
+    // places.  Called when the sub-list cannot take a block's hits (so nothing is dropped here: on spatially smooth
+    // embeddings whole regions qualify while the thresholds are still loose) and at the wave's end.
+    auto flush_sub = [&](int j) {
+        const int cnt = wl_n[j];
+        if (cnt == 0) return;  // (wave-uniform)
+        const long b = (long)qt * (QTB / QB) + wave * NQB + j;
+        unsigned base = 0u;
+        if (lane == 0) base = atomicAdd(&bcnt[b], (unsigned)cnt) & 0x7fffffffu;  // (bit 31 = the bucket's "incomplete" mark)
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        for (int i = lane; i < cnt; i += 64) {
+            const uint2 e = fl[j * WL + i];  // (this wave's own ds_writes: ordered behind them in the LDS queue)
+            if ((long)base + i < bucket_cap)
+                list[b * bucket_cap + base + i] =
+                    make_uint2((unsigned)((size_t)(e.x >> 16) * N_pad + (size_t)qt * QTB + (e.x & 0xffffu)), e.y);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the sub-list was read before it is refilled
+        wl_n[j] = 0;
+        wl_total += cnt;
+    };
+    auto emit_regs = [&](const f32x16 &c, float t, int j, int row0) __attribute__((always_inline)) {
         const unsigned lq = (unsigned)(wave * (NQB * QB) + l31 + 32 * j);  // query inside the workgroup's 512
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1693,6 +1714,25 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
                 if (hit && idx < WL) fl[j * WL + idx] = make_uint2(((unsigned)o << 16) | lq, (unsigned)slot);
                 wl_n[j] += __popcll(m);
             }
+        }
+    };
+    // The hits of one 32 x 32 block go to sub-list j optimistically (the fast path is the loop above and one scalar compare).
+    // If they did not fit behind what the sub-list held, nothing is lost: the sub-list is rolled back to its old fill,
+    // flushed to its bucket, and the block is listed again into the empty sub-list.  A block with more hits than a whole
+    // sub-list (> 128 of its 1 024 distances inside the threshold: embeddings the bf16 pass cannot tell apart) is not
+    // listed at all -- its bucket is marked incomplete and refine_rescue_kernel scans that 32-query block exactly.
+    auto emit = [&](const f32x16 &c, float t, int j, int row0) __attribute__((always_inline)) {
+        const int before = wl_n[j];
+        emit_regs(c, t, j, row0);
+        if (wl_n[j] > WL) {  // (wave-uniform, rare)
+            const int total = wl_n[j] - before;
+            wl_n[j] = before;
+            flush_sub(j);
+            if (total > WL) {
+                if (lane == 0) atomicOr(&bcnt[(long)qt * (QTB / QB) + wave * NQB + j], 0x80000000u);  // (bit 31: incomplete)
+                wl_total += total;  // (statistics: qualifying rows SEEN)
+            } else
+                emit_regs(c, t, j, row0);
         }
     };
 
@@ -1889,37 +1929,15 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
 #undef MANET_BF
     flush(o);
     if (FILTER) {
-        // the wave's candidates -> the global list, which is one BUCKET per 32-query block (the wave's sub-list j belongs to
-        // block 16 qt + 4 wave + j): one returning atomic per sub-list reserves its places.  The re-rank kernel runs one
-        // workgroup per bucket with the block's 32 query vectors in LDS.
-        int cnt[NQB], total = 0;
+        // the wave's remaining candidates -> the global list, which is one BUCKET per 32-query block (flush_sub).  The
+        // re-rank kernel runs one workgroup per bucket with the block's 32 query vectors in LDS.  A bucket that outgrows its
+        // capacity keeps counting (bcnt > bucket_cap marks it) and refine_rescue_kernel re-scans that block's pairs.
 #pragma unroll
-        for (int j = 0; j < NQB; ++j) {
-            cnt[j] = wl_n[j] < WL ? wl_n[j] : WL;
-            total += wl_n[j];  // (statistics: the qualifying rows SEEN)
-            if (wl_n[j] > WL) stats[1] = 1ull;  // more rows than a sub-list holds (20x the average): the rescue scan takes over
-        }
-        // lane j reserves sub-list j's places: the four atomics are one instruction, one round trip
-        const int mine = lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : cnt[3];
-        const long b0 = (long)qt * (QTB / QB) + wave * NQB;
-        unsigned got = 0u;
-        if (lane < NQB && mine) got = atomicAdd(&bcnt[b0 + lane], (unsigned)mine);
-#pragma unroll
-        for (int j = 0; j < NQB; ++j) {
-            const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)got, j);
-            for (int i = lane; i < cnt[j]; i += 64) {
-                const uint2 e = fl[j * WL + i];  // (this wave's own ds_writes: ordered behind them in the LDS queue)
-                if ((long)base + i < bucket_cap)
-                    list[(b0 + j) * bucket_cap + base + i] =
-                        make_uint2((unsigned)((size_t)(e.x >> 16) * N_pad + (size_t)qt * QTB + (e.x & 0xffffu)), e.y);
-                else stats[1] = 1ull;
-            }
-        }
-        if (lane == 0 && total) atomicAdd(&stats[0], (unsigned long long)total);  // (statistics only)
+        for (int j = 0; j < NQB; ++j) flush_sub(j);
+        if (lane == 0 && wl_total) atomicAdd(&stats[0], (unsigned long long)wl_total);  // (statistics only)
     }
 }
 
-// ---------------------------------------------------------------------------------------------
 // MANET_COMPUTE_BF16_REFINE: fp32-exact minima at bf16 cost (VERDICT r2 "next" #4).
 //   IntVOS.py:81-85 is a MINIMUM over the bank, so any filter that keeps the true arg-min row may discard the rest:
 //   1. pre-pass  : the plain bf16 kernel over every REFINE_SUB-th bank tile -> U(n,o), a bf16 distance of SOME row, i.e. an
@@ -2049,15 +2067,16 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restric
                                                             const float *__restrict__ rows, const float *__restrict__ norms,
                                                             const uint2 *__restrict__ list, const unsigned *__restrict__ bcnt,
                                                             long bucket_cap, long N, long N_pad, int C,
-                                                            unsigned *__restrict__ keys2)
+                                                            unsigned *__restrict__ keys2, unsigned long long *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) char rr_smem[];
     float *qs = (float *)rr_smem;  // [C][QB]
     const long b = blockIdx.x;
-    const unsigned have = bcnt[b];
+    const unsigned raw = bcnt[b], have = raw & 0x7fffffffu;  // (bit 31: a block's hits were not listed, see emit)
     const int cnt = (long)have < bucket_cap ? (int)have : (int)bucket_cap;
-    if (cnt == 0) return;
     const int tid = threadIdx.x;
+    if (((long)have > bucket_cap || (raw >> 31)) && tid == 0) stats[1] = 1ull;  // (statistics; refine_rescue_kernel looks at bcnt itself)
+    if (cnt == 0) return;
     for (int idx = tid; idx < QB * C; idx += 256) {
         long n = b * QB + (idx & (QB - 1));
         n = n < N ? n : N - 1;  // (padding queries have no candidates)
@@ -2090,36 +2109,72 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restric
     }
 }
 
-// The candidate list overflowed (duplicated bank rows, a pathological threshold ...): every pair scans its object's rows in
-// the same arithmetic instead -- exact, slow, and never on the path of a sane input.  Launched always, returns at once
-// unless stats[1] is set.  Lanes along the queries: every lane of a wave walks the same bank rows (uniform reads).
+// A bucket overflowed (more candidates for a 32-query block than its capacity: duplicated bank rows, embeddings the bf16
+// pass cannot tell apart): that block's pairs are evaluated against EVERY row of their object, exactly.  One workgroup per
+// bucket, launched always, returns at once for complete buckets.  The block's 32 query vectors sit in LDS as
+// [channel][query]; a thread takes a bank row (read once, 16-byte loads) and carries the 32 ascending-k fmaf chains of that
+// row against the 32 queries (the queries' values are LDS broadcasts); minima meet per (query, object) by LDS atomics,
+// then by atomicMin on the global keys.  (First form: one thread per (query, object) walking the object's rows on its
+// own -- 0.8 s at cfg3 shape when every pair overflowed; this one: the cost of an fp32 VALU pass over the bank.)
 template <typename SRC>
 __global__ __launch_bounds__(256) void refine_rescue_kernel(const SRC *__restrict__ q, long q_sn, long q_sc,
                                                             const float *__restrict__ rows, const float *__restrict__ norms,
-                                                            const int *__restrict__ meta, long N, long N_pad, int C,
+                                                            const int *__restrict__ meta, long N, long N_pad, int C, int n_ids,
                                                             unsigned *__restrict__ keys2,
-                                                            const unsigned long long *__restrict__ stats)
+                                                            const unsigned *__restrict__ bcnt, long bucket_cap)
 {
-    if (stats[1] == 0ull) return;
-    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int o = blockIdx.y;
-    if (n >= N) return;
-    const SRC *qr = q + n * q_sn;
-    float xs = 0.0f;
-    for (int k = 0; k < C; ++k) {
-        const float x = emb_load(qr, (long)k * q_sc);
-        xs = fmaf(x, x, xs);
+    extern __shared__ __attribute__((aligned(16))) char rs_smem[];
+    const long b = blockIdx.x;
+    {
+        const unsigned raw = bcnt[b];
+        if (!(raw >> 31) && (long)raw <= bucket_cap) return;  // this block's bucket holds every candidate: the re-rank was complete
     }
-    const long r0 = (long)meta[META_SEG + o] * BT, r1 = r0 + meta[META_CNT + o];
-    unsigned best = 0xffffffffu;
-    for (long r = r0; r < r1; ++r) {
-        const float *kr = rows + r * C;
-        float mm = 0.0f;
-        for (int k = 0; k < C; ++k) mm = fmaf(emb_load(qr, (long)k * q_sc), kr[k], mm);
-        const unsigned key = key_of(fmaf(-2.0f, mm, xs + norms[r]));
-        best = key < best ? key : best;
+    float *qs = (float *)rs_smem;                    // [C][QB]
+    float *xs = qs + (size_t)C * QB;                  // [QB]
+    unsigned *best = (unsigned *)(xs + QB);           // [n_ids][QB]
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < QB * C; idx += 256) {
+        long n = b * QB + (idx & (QB - 1));
+        n = n < N ? n : N - 1;
+        qs[idx] = emb_load(q + n * q_sn, (long)(idx / QB) * q_sc);
     }
-    atomicMin(keys2 + (size_t)o * N_pad + n, best);
+    for (int i = tid; i < n_ids * QB; i += 256) best[i] = 0xffffffffu;
+    __syncthreads();
+    if (tid < QB) {
+        float a = 0.0f;
+        for (int k = 0; k < C; ++k) a = fmaf(qs[k * QB + tid], qs[k * QB + tid], a);
+        xs[tid] = a;
+    }
+    __syncthreads();
+    for (int o = 0; o < n_ids; ++o) {
+        const long r0 = (long)meta[META_SEG + o] * BT, r1 = r0 + meta[META_CNT + o];
+        for (long r = r0 + tid; r < r1; r += 256) {
+            const float *kr = rows + r * C;
+            float mm[QB];
+#pragma unroll
+            for (int j = 0; j < QB; ++j) mm[j] = 0.0f;
+            for (int k = 0; k < C; ++k) {
+                const float y = kr[k];
+                const f32x4 *x4 = (const f32x4 *)(qs + k * QB);
+#pragma unroll
+                for (int j4 = 0; j4 < QB / 4; ++j4) {
+                    const f32x4 x = x4[j4];  // (the same address in every lane: a broadcast)
+                    mm[4 * j4] = fmaf(x[0], y, mm[4 * j4]);
+                    mm[4 * j4 + 1] = fmaf(x[1], y, mm[4 * j4 + 1]);
+                    mm[4 * j4 + 2] = fmaf(x[2], y, mm[4 * j4 + 2]);
+                    mm[4 * j4 + 3] = fmaf(x[3], y, mm[4 * j4 + 3]);
+                }
+            }
+            const float ys = norms[r];
+#pragma unroll
+            for (int j = 0; j < QB; ++j) atomicMin(&best[o * QB + j], key_of(fmaf(-2.0f, mm[j], xs[j] + ys)));  // IntVOS.py:39
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n_ids * QB; i += 256) {
+        const long n = b * QB + (i & (QB - 1));
+        if (n < N && best[i] != 0xffffffffu) atomicMin(keys2 + (long)(i / QB) * N_pad + n, best[i]);
+    }
 }
 
 // decode + (sigmoid-0.5)*2 (IntVOS.py:611-612) + min-merge with the stored map (IntVOS.py:620-622)
@@ -2493,18 +2548,19 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
     }
     // 4. exact re-rank of the candidates (+ the rescue scan, a no-op unless the list overflowed), then the usual finish
     const float *rows = (const float *)(bws + BL.off_rows), *norms = (const float *)(bws + BL.off_norms);
-    const dim3 rgrid((unsigned)(ML.N_pad / QB)), sgrid((unsigned)((N + 255) / 256), (unsigned)n_ids);
+    const dim3 rgrid((unsigned)(ML.N_pad / QB)), sgrid((unsigned)(ML.N_pad / QB));
+    const size_t slds = ((size_t)C * QB + QB + (size_t)n_ids * QB) * sizeof(float);
     const size_t rlds = (size_t)QB * C * sizeof(float);
     if (q_dtype == MANET_EMB_F32) {
         hipLaunchKernelGGL(refine_rerank_kernel<float>, rgrid, dim3(256), rlds, st, (const float *)qraw, q_sn, q_sc, rows, norms,
-                           (const uint2 *)list, (const unsigned *)bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2);
-        hipLaunchKernelGGL(refine_rescue_kernel<float>, sgrid, dim3(256), 0, st, (const float *)qraw, q_sn, q_sc, rows, norms, meta,
-                           N, ML.N_pad, C, keys2, (const unsigned long long *)stats);
+                           (const uint2 *)list, (const unsigned *)bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2, stats);
+        hipLaunchKernelGGL(refine_rescue_kernel<float>, sgrid, dim3(256), slds, st, (const float *)qraw, q_sn, q_sc, rows, norms, meta,
+                           N, ML.N_pad, C, n_ids, keys2, (const unsigned *)bcnt, ML.bucket_cap);
     } else {
         hipLaunchKernelGGL(refine_rerank_kernel<unsigned short>, rgrid, dim3(256), rlds, st, (const unsigned short *)qraw, q_sn, q_sc,
-                           rows, norms, (const uint2 *)list, (const unsigned *)bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2);
-        hipLaunchKernelGGL(refine_rescue_kernel<unsigned short>, sgrid, dim3(256), 0, st, (const unsigned short *)qraw, q_sn, q_sc,
-                           rows, norms, meta, N, ML.N_pad, C, keys2, (const unsigned long long *)stats);
+                           rows, norms, (const uint2 *)list, (const unsigned *)bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2, stats);
+        hipLaunchKernelGGL(refine_rescue_kernel<unsigned short>, sgrid, dim3(256), slds, st, (const unsigned short *)qraw, q_sn, q_sc,
+                           rows, norms, meta, N, ML.N_pad, C, n_ids, keys2, (const unsigned *)bcnt, ML.bucket_cap);
     }
     const long total = N * n_ids;
     hipLaunchKernelGGL(global_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, keys2, N, ML.N_pad, n_ids,

@@ -91,7 +91,7 @@ def test_adversarial_duplicate_rows_overflow_every_list(ops):
     got = bank.match(q)
     assert torch.equal(got, want)
     cands, over = bank.refine_stats()
-    assert over == 1 and cands >= 16 * N * n_ids  # the list overflowed, the rescue scan ran, the result is still exact
+    assert over == 1 and cands >= 16 * N * n_ids  # every bucket overflowed, the rescue scan ran, the result is still exact
 
 
 @pytest.mark.parametrize("cfg", [3, 5])
@@ -118,3 +118,48 @@ def test_errors_are_loud(ops):
     q, k, lab = _case(1, 100, 500, 100, 2)
     with pytest.raises(RuntimeError, match="k_nn"):
         ops.global_match(k, q, lab, 2, compute="bf16r", k_nearest_neighbors=2)
+
+
+def test_spatially_smooth_embeddings_do_not_overflow(ops):
+    """embeddings that vary slowly over the image (what a trained encoder produces; the random fields of the other tests are
+    the easy case): whole 32-query blocks qualify together while the thresholds are still loose.  The filter pass must list
+    them all (sub-lists are flushed to their buckets when full, nothing is dropped) -- r3's first form raised the overflow flag
+    here and every pair fell back to a 0.8 s scan."""
+    import torch.nn.functional as F
+    H, W, T, n_ids = 60, 107, 4, 3
+    g = torch.Generator(device="cuda").manual_seed(8)
+    for coarse, noise in ((8, 0.1), (16, 0.0)):
+        base = torch.randn(1, 100, H // coarse + 2, W // coarse + 2, generator=g, device="cuda")
+        frames = []
+        for i in range(T + 1):
+            f = F.interpolate(base + 0.05 * i * torch.randn(base.shape, generator=g, device="cuda"), size=(H, W),
+                              mode="bilinear", align_corners=True)[0]
+            frames.append(torch.relu(f + noise * torch.randn(100, H, W, generator=g, device="cuda")) * 0.1)
+        bank_rows = torch.stack(frames[:T]).permute(0, 2, 3, 1).reshape(-1, 100)
+        lab = torch.randint(0, n_ids, (T * H * W,), generator=g, device="cuda", dtype=torch.int32)
+        q = frames[T].permute(1, 2, 0)
+        want = ops.global_match(bank_rows, q, lab, n_ids, compute="f32")
+        bank = ops.PreparedBank(bank_rows, lab, n_ids, compute="bf16r")
+        assert torch.equal(bank.match(q), want)
+        cands, over = bank.refine_stats()
+        assert over == 0 and cands / (H * W * n_ids) < 16.0
+
+
+def test_partly_degenerate_embeddings_rescue_only_their_blocks(ops):
+    """a band of the image where every embedding is the SAME vector (nothing for the bf16 pass to tell apart: hundreds of
+    bank rows tie for every query of the band): those 32-query blocks are marked incomplete and re-scanned exactly by
+    refine_rescue_kernel, the rest of the frame goes through the candidate lists; the result is the fp32 kernel's, bit for bit"""
+    H, W, n_ids = 40, 64, 2
+    g = torch.Generator(device="cuda").manual_seed(9)
+    q = torch.relu(torch.randn(100, H, W, generator=g, device="cuda")) * 0.2
+    ref = torch.relu(torch.randn(100, H, W, generator=g, device="cuda")) * 0.2
+    const = torch.relu(torch.randn(100, generator=g, device="cuda")) * 0.2
+    q[:, 10:20, :] = const[:, None, None]
+    ref[:, 5:30, :] = (const * 1.001)[:, None, None]
+    lab = torch.randint(0, n_ids, (H * W,), generator=g, device="cuda", dtype=torch.int32)
+    bank_rows = ref.permute(1, 2, 0).reshape(-1, 100)
+    want = ops.global_match(bank_rows, q.permute(1, 2, 0), lab, n_ids, compute="f32")
+    bank = ops.PreparedBank(bank_rows, lab, n_ids, compute="bf16r")
+    assert torch.equal(bank.match(q.permute(1, 2, 0)), want)
+    _, over = bank.refine_stats()
+    assert over == 1  # (the band's blocks were rescued)
