@@ -252,6 +252,21 @@ def test_end_to_end_on_gpu_with_2_byte_embeddings_and_bf16_arithmetic():
 
 
 @pytest.mark.gpu
+def test_end_to_end_bf16r_equals_f32_through_the_module():
+    """IntVOS(cfg, fe, compute="bf16r"): the bf16 filter + exact fp32 re-rank behind the reference API -- every map and every
+    logit of the scripted session (two interaction rounds, propagation both ways) EQUALS the compute="f32" model's, bit for
+    bit, and both sit on the reference class's fixture."""
+    g = load_golden("e2e_tiny")
+    outs = {}
+    for compute in ("f32", "bf16r"):
+        outs[compute] = run_script(build_model(g, "cuda", compute=compute), g, "cuda")
+    for k in ("gmap_round1", "gmap_round2", "lmap_tmp", "int_logits", "prop1_logits_2", "prop1_logits_3", "int2_logits",
+              "prop2_logits_3"):
+        assert torch.equal(outs["bf16r"][k], outs["f32"][k]), k
+        np.testing.assert_allclose(outs["bf16r"][k].cpu().numpy(), g[k], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
 def test_module_functions_on_gpu_match_reference():
     from cvpr2020_manet_amd.networks import IntVOS as M
     M.set_cfg(tiny_cfg())
