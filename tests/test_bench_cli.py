@@ -48,6 +48,23 @@ def test_two_rank_flow_on_one_gpu():
     assert col["bank_slots_per_rank"] == 3  # cfg3: a 5-frame bank, shipped once, dealt round robin to the 2 ranks
 
 
+@pytest.mark.gpu
+def test_two_rank_strong_scaling_flow_on_one_gpu():
+    """`--scaling strong`: a fixed 64-frame clip sharded over the ranks (32 frames each at N = 2), same exchange"""
+    env = dict(os.environ, MANET_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "1",
+                        "--cfg", "3", "--compute", "bf16", "--scaling", "strong"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["clip_frames"] == 64 and line["config"]["frames_per_gpu"] == 32
+    assert line["collective"]["world"] == 2
+
+
 def test_mismatched_world_size_is_an_error():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env,
