@@ -53,7 +53,7 @@ constexpr int REFINE_SUB = MANET_REFINE_SUB;
 #define MANET_REFINE_XCHG_MASK 3
 #endif
 constexpr int REFINE_XCHG_MASK = MANET_REFINE_XCHG_MASK;  // threshold exchange every (mask + 1) steps
-constexpr int REFINE_CAP = 32;  // capacity of a candidate bucket (one per 32-query block), in rows per (query, object) pair ON AVERAGE
+constexpr int REFINE_CAP = 64;  // capacity of a candidate bucket (one per 32-query block), in rows per (query, object) pair ON AVERAGE
 constexpr int REFINE_LDS_LIST = 2048;  // candidate entries a filter workgroup collects in LDS before it appends them in bulk
 
 // Packed operand image of one row block: `units` 16-byte units per row, stored [unit][row][16 B].
@@ -142,6 +142,8 @@ struct BankLayout {
     // exact re-rank reads), and the sub-sampled bank of the pre-pass (its own meta block + every REFINE_SUB-th tile)
     long T_sub_max;
     size_t off_rows, off_norms, off_sub_meta, off_sub_pack;
+    Geom G32;  // ... and its fp32 operand image (the rescue pass of incomplete candidate buckets: the exact fp32 kernel)
+    size_t off_pack32;
 };
 
 BankLayout bank_layout(int64_t M0, int C, int n_ids, int compute)
@@ -157,14 +159,17 @@ BankLayout bank_layout(int64_t M0, int C, int n_ids, int compute)
     L.off_pack = manet_align_up(L.off_src + (size_t)L.T_max * BT * sizeof(int), 1024);
     L.total = manet_align_up(L.off_pack + (size_t)L.T_max * L.tile_bytes, 1024);
     L.T_sub_max = 0;
-    L.off_rows = L.off_norms = L.off_sub_meta = L.off_sub_pack = 0;
+    L.off_rows = L.off_norms = L.off_sub_meta = L.off_sub_pack = L.off_pack32 = 0;
+    L.G32 = L.G;
     if (compute == MANET_COMPUTE_BF16_REFINE) {
         L.T_sub_max = L.T_max / REFINE_SUB + n_ids + 1;
         L.off_rows = L.total;
         L.off_norms = manet_align_up(L.off_rows + (size_t)L.T_max * BT * C * sizeof(float), 256);
         L.off_sub_meta = manet_align_up(L.off_norms + (size_t)L.T_max * BT * sizeof(float), 256);
         L.off_sub_pack = manet_align_up(L.off_sub_meta + META_INTS * sizeof(int), 1024);
-        L.total = manet_align_up(L.off_sub_pack + (size_t)L.T_sub_max * L.tile_bytes, 1024);
+        L.G32 = geom_of(C, MANET_COMPUTE_F32);
+        L.off_pack32 = manet_align_up(L.off_sub_pack + (size_t)L.T_sub_max * L.tile_bytes, 1024);
+        L.total = manet_align_up(L.off_pack32 + (size_t)L.T_max * L.G32.tile_bytes, 1024);
     }
     return L;
 }
@@ -176,7 +181,7 @@ struct MatchLayout {
     size_t qblk_bytes, off_q, off_keys, off_topk, total;
     // MANET_COMPUTE_BF16_REFINE: per (object, query) threshold and exact-distance key, the flat candidate list
     // {pair, bank slot} with its capacity, and two counters (candidates appended, list overflowed)
-    size_t off_thr, off_slack, off_keys2, off_list, off_stats, off_bcnt;
+    size_t off_thr, off_slack, off_keys2, off_list, off_stats, off_bcnt, off_q32;
     long list_cap, bucket_cap;  // the candidate list = N_pad / 32 buckets (one per 32-query block) of bucket_cap entries
 };
 
@@ -197,7 +202,7 @@ MatchLayout match_layout(int64_t N, int C, int n_ids, int compute, int k_nn = 1,
         L.total = manet_align_up(L.off_topk + (size_t)TOPK_SPLITS * n_ids * L.N_pad * MANET_MAX_KNN * sizeof(float), 1024);
     if (arg)  // 64-bit (distance key, bank slot) pairs of the arg-min form live where the top-k lists would
         L.total = manet_align_up(L.off_topk + (size_t)n_ids * L.N_pad * sizeof(unsigned long long), 1024);
-    L.off_thr = L.off_slack = L.off_keys2 = L.off_list = L.off_stats = L.off_bcnt = 0;
+    L.off_thr = L.off_slack = L.off_keys2 = L.off_list = L.off_stats = L.off_bcnt = L.off_q32 = 0;
     L.list_cap = L.bucket_cap = 0;
     if (compute == MANET_COMPUTE_BF16_REFINE) {
         const size_t pairs = (size_t)n_ids * L.N_pad;
@@ -209,7 +214,8 @@ MatchLayout match_layout(int64_t N, int C, int n_ids, int compute, int k_nn = 1,
         L.bucket_cap = (long)n_ids * QB * REFINE_CAP;
         L.off_stats = manet_align_up(L.off_list + (size_t)L.list_cap * sizeof(uint2), 256);
         L.off_bcnt = L.off_stats + 256;
-        L.total = manet_align_up(L.off_bcnt + (size_t)(L.N_pad / QB) * sizeof(unsigned), 1024);
+        L.off_q32 = manet_align_up(L.off_bcnt + (size_t)(L.N_pad / QB) * sizeof(unsigned), 1024);  // fp32 query image (rescue)
+        L.total = manet_align_up(L.off_q32 + (size_t)(L.N_pad / QB) * geom_of(C, MANET_COMPUTE_F32).qblk_bytes, 1024);
     }
     return L;
 }
@@ -419,11 +425,23 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const SRC *__restrict__ 
                                                         int C, int compute, int units, int kpad,
                                                         char *__restrict__ dst, long tile_bytes,
                                                         float pad_norm, unsigned *__restrict__ keys, long N_pad,
-                                                        int n_ids)
+                                                        int n_ids, const unsigned *__restrict__ only_marked = nullptr,
+                                                        long mark_cap = 0)
 {
     constexpr bool IS_QUERY = (IMG == QB);
     const long tile = blockIdx.x;
     if (meta && tile >= meta[META_T]) return;
+    if (only_marked) {
+        // MANET_COMPUTE_BF16_REFINE's rescue: only the query tiles (QT / QB = 8 blocks: the fp32 kernel's workgroup) that
+        // hold a 32-query block whose candidate bucket is incomplete
+        const long t0 = tile / (QT / QB) * (QT / QB);
+        bool need = false;
+        for (int i = 0; i < QT / QB; ++i) {
+            const unsigned raw = only_marked[t0 + i];
+            need = need || (raw >> 31) || (long)raw > mark_cap;
+        }
+        if (!need) return;
+    }
     if (keys)
         for (int i = threadIdx.x; i < ROWS * n_ids; i += 256) keys[(size_t)(i / ROWS) * N_pad + tile * ROWS + (i % ROWS)] = 0xffffffffu;
     extern __shared__ __attribute__((aligned(16))) char pack_smem[];
@@ -989,12 +1007,17 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__
 // that share of a 12.8 k-cycle tile.  Here a wave's MFMA stream never stops for an epilogue.
 // Staging by asm LDS-DMA (see lds_dma16): it frees the 28 staging VGPRs the 16 carried |k|^2 need, and removes
 // the ds_write pass; one raw s_barrier per tile.
-template <int KS>
+// RESCUE (MANET_COMPUTE_BF16_REFINE): the same kernel as the exact fall-back of the bf16 filter -- a workgroup returns at
+// once unless one of its query tile's eight 32-query blocks has an incomplete candidate bucket (bit 31 or a count past
+// the capacity); the minima meet the re-rank's by atomicMin on the same keys (the same fp32 chains: the same bits).
+template <int KS, bool RESCUE = false>
 __global__ __launch_bounds__(256, 2) void global_match_f32_pipe_kernel(const char *__restrict__ qpack,
                                                                        const char *__restrict__ bpack,
                                                                        const int *__restrict__ meta, int n_ids,
                                                                        int nQT, int S, long N_pad,
-                                                                       unsigned *__restrict__ keys, int block_map)
+                                                                       unsigned *__restrict__ keys, int block_map,
+                                                                       const unsigned *__restrict__ bcnt = nullptr,
+                                                                       long bucket_cap = 0)
 {
     constexpr int NG = (KS + 3) / 4;
     constexpr size_t TILE_BYTES = bank_tile_bytes(NG);  // whole KiB
@@ -1012,6 +1035,14 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_pipe_kernel(const cha
     int qt, s, t0, t1;
     const int T = meta[META_T];
     if (!split_of_block(blockIdx.x, nQT, S, T, block_map, qt, s, t0, t1)) return;
+    if (RESCUE) {
+        bool need = false;
+        for (int i = 0; i < QT / QB; ++i) {
+            const unsigned raw = bcnt[(long)qt * (QT / QB) + i];
+            need = need || (raw >> 31) || (long)raw > bucket_cap;
+        }
+        if (!need) return;  // (wave-uniform: every lane read the same eight counters)
+    }
 
     const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
     auto stage_dma = [&](int t, int slot) __attribute__((always_inline)) {
@@ -1720,7 +1751,7 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     // If they did not fit behind what the sub-list held, nothing is lost: the sub-list is rolled back to its old fill,
     // flushed to its bucket, and the block is listed again into the empty sub-list.  A block with more hits than a whole
     // sub-list (> 128 of its 1 024 distances inside the threshold: embeddings the bf16 pass cannot tell apart) is not
-    // listed at all -- its bucket is marked incomplete and refine_rescue_kernel scans that 32-query block exactly.
+    // listed at all -- its bucket is marked incomplete and the rescue pass (the exact fp32 kernel) takes that query tile.
     auto emit = [&](const f32x16 &c, float t, int j, int row0) __attribute__((always_inline)) {
         const int before = wl_n[j];
         emit_regs(c, t, j, row0);
@@ -1931,7 +1962,7 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     if (FILTER) {
         // the wave's remaining candidates -> the global list, which is one BUCKET per 32-query block (flush_sub).  The
         // re-rank kernel runs one workgroup per bucket with the block's 32 query vectors in LDS.  A bucket that outgrows its
-        // capacity keeps counting (bcnt > bucket_cap marks it) and refine_rescue_kernel re-scans that block's pairs.
+        // capacity keeps counting (bcnt > bucket_cap marks it) and the rescue pass takes that query tile.
 #pragma unroll
         for (int j = 0; j < NQB; ++j) flush_sub(j);
         if (lane == 0 && wl_total) atomicAdd(&stats[0], (unsigned long long)wl_total);  // (statistics only)
@@ -2075,7 +2106,7 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restric
     const unsigned raw = bcnt[b], have = raw & 0x7fffffffu;  // (bit 31: a block's hits were not listed, see emit)
     const int cnt = (long)have < bucket_cap ? (int)have : (int)bucket_cap;
     const int tid = threadIdx.x;
-    if (((long)have > bucket_cap || (raw >> 31)) && tid == 0) stats[1] = 1ull;  // (statistics; refine_rescue_kernel looks at bcnt itself)
+    if (((long)have > bucket_cap || (raw >> 31)) && tid == 0) stats[1] = 1ull;  // (statistics; the rescue pass looks at bcnt itself)
     if (cnt == 0) return;
     for (int idx = tid; idx < QB * C; idx += 256) {
         long n = b * QB + (idx & (QB - 1));
@@ -2109,73 +2140,6 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restric
     }
 }
 
-// A bucket overflowed (more candidates for a 32-query block than its capacity: duplicated bank rows, embeddings the bf16
-// pass cannot tell apart): that block's pairs are evaluated against EVERY row of their object, exactly.  One workgroup per
-// bucket, launched always, returns at once for complete buckets.  The block's 32 query vectors sit in LDS as
-// [channel][query]; a thread takes a bank row (read once, 16-byte loads) and carries the 32 ascending-k fmaf chains of that
-// row against the 32 queries (the queries' values are LDS broadcasts); minima meet per (query, object) by LDS atomics,
-// then by atomicMin on the global keys.  (First form: one thread per (query, object) walking the object's rows on its
-// own -- 0.8 s at cfg3 shape when every pair overflowed; this one: the cost of an fp32 VALU pass over the bank.)
-template <typename SRC>
-__global__ __launch_bounds__(256) void refine_rescue_kernel(const SRC *__restrict__ q, long q_sn, long q_sc,
-                                                            const float *__restrict__ rows, const float *__restrict__ norms,
-                                                            const int *__restrict__ meta, long N, long N_pad, int C, int n_ids,
-                                                            unsigned *__restrict__ keys2,
-                                                            const unsigned *__restrict__ bcnt, long bucket_cap)
-{
-    extern __shared__ __attribute__((aligned(16))) char rs_smem[];
-    const long b = blockIdx.x;
-    {
-        const unsigned raw = bcnt[b];
-        if (!(raw >> 31) && (long)raw <= bucket_cap) return;  // this block's bucket holds every candidate: the re-rank was complete
-    }
-    float *qs = (float *)rs_smem;                    // [C][QB]
-    float *xs = qs + (size_t)C * QB;                  // [QB]
-    unsigned *best = (unsigned *)(xs + QB);           // [n_ids][QB]
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < QB * C; idx += 256) {
-        long n = b * QB + (idx & (QB - 1));
-        n = n < N ? n : N - 1;
-        qs[idx] = emb_load(q + n * q_sn, (long)(idx / QB) * q_sc);
-    }
-    for (int i = tid; i < n_ids * QB; i += 256) best[i] = 0xffffffffu;
-    __syncthreads();
-    if (tid < QB) {
-        float a = 0.0f;
-        for (int k = 0; k < C; ++k) a = fmaf(qs[k * QB + tid], qs[k * QB + tid], a);
-        xs[tid] = a;
-    }
-    __syncthreads();
-    for (int o = 0; o < n_ids; ++o) {
-        const long r0 = (long)meta[META_SEG + o] * BT, r1 = r0 + meta[META_CNT + o];
-        for (long r = r0 + tid; r < r1; r += 256) {
-            const float *kr = rows + r * C;
-            float mm[QB];
-#pragma unroll
-            for (int j = 0; j < QB; ++j) mm[j] = 0.0f;
-            for (int k = 0; k < C; ++k) {
-                const float y = kr[k];
-                const f32x4 *x4 = (const f32x4 *)(qs + k * QB);
-#pragma unroll
-                for (int j4 = 0; j4 < QB / 4; ++j4) {
-                    const f32x4 x = x4[j4];  // (the same address in every lane: a broadcast)
-                    mm[4 * j4] = fmaf(x[0], y, mm[4 * j4]);
-                    mm[4 * j4 + 1] = fmaf(x[1], y, mm[4 * j4 + 1]);
-                    mm[4 * j4 + 2] = fmaf(x[2], y, mm[4 * j4 + 2]);
-                    mm[4 * j4 + 3] = fmaf(x[3], y, mm[4 * j4 + 3]);
-                }
-            }
-            const float ys = norms[r];
-#pragma unroll
-            for (int j = 0; j < QB; ++j) atomicMin(&best[o * QB + j], key_of(fmaf(-2.0f, mm[j], xs[j] + ys)));  // IntVOS.py:39
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < n_ids * QB; i += 256) {
-        const long n = b * QB + (i & (QB - 1));
-        if (n < N && best[i] != 0xffffffffu) atomicMin(keys2 + (long)(i / QB) * N_pad + n, best[i]);
-    }
-}
 
 // decode + (sigmoid-0.5)*2 (IntVOS.py:611-612) + min-merge with the stored map (IntVOS.py:620-622)
 // MANET_EPI_KEYS_ARMED: the keys are put back to "no candidate" as they are read (every key, padding rows included), so
@@ -2411,6 +2375,18 @@ void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int 
     manet_profile_record(st, false);
 }
 
+// the exact fp32 kernel as MANET_COMPUTE_BF16_REFINE's rescue pass (workgroups of complete query tiles return at once)
+template <int KS>
+void launch_rescue_f32_pipe(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S, long N_pad,
+                            unsigned *keys, const unsigned *bcnt, long bucket_cap, hipStream_t st)
+{
+    size_t lds = 2 * bank_tile_bytes((KS + 3) / 4);
+    (void)hipFuncSetAttribute((const void *)global_match_f32_pipe_kernel<KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL((global_match_f32_pipe_kernel<KS, true>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack, bpack, meta,
+                       n_ids, nQT, S, N_pad, keys, block_map_arg(nQT, 512, S), bcnt, bucket_cap);
+}
+
 template <int KS>
 void launch_main_f32_pipe(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S, long N_pad,
                           unsigned *keys, hipStream_t st)
@@ -2420,7 +2396,7 @@ void launch_main_f32_pipe(const char *qpack, const char *bpack, const int *meta,
                               (int)lds);
     manet_profile_record(st, true);
     hipLaunchKernelGGL((global_match_f32_pipe_kernel<KS>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack, bpack, meta,
-                       n_ids, nQT, S, N_pad, keys, block_map_arg(nQT, 512, S));
+                       n_ids, nQT, S, N_pad, keys, block_map_arg(nQT, 512, S), (const unsigned *)nullptr, 0L);
     manet_profile_record(st, false);
 }
 
@@ -2548,19 +2524,41 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
     }
     // 4. exact re-rank of the candidates (+ the rescue scan, a no-op unless the list overflowed), then the usual finish
     const float *rows = (const float *)(bws + BL.off_rows), *norms = (const float *)(bws + BL.off_norms);
-    const dim3 rgrid((unsigned)(ML.N_pad / QB)), sgrid((unsigned)(ML.N_pad / QB));
-    const size_t slds = ((size_t)C * QB + QB + (size_t)n_ids * QB) * sizeof(float);
+    const dim3 rgrid((unsigned)(ML.N_pad / QB));
     const size_t rlds = (size_t)QB * C * sizeof(float);
-    if (q_dtype == MANET_EMB_F32) {
+    if (q_dtype == MANET_EMB_F32)
         hipLaunchKernelGGL(refine_rerank_kernel<float>, rgrid, dim3(256), rlds, st, (const float *)qraw, q_sn, q_sc, rows, norms,
                            (const uint2 *)list, (const unsigned *)bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2, stats);
-        hipLaunchKernelGGL(refine_rescue_kernel<float>, sgrid, dim3(256), slds, st, (const float *)qraw, q_sn, q_sc, rows, norms, meta,
-                           N, ML.N_pad, C, n_ids, keys2, (const unsigned *)bcnt, ML.bucket_cap);
-    } else {
+    else
         hipLaunchKernelGGL(refine_rerank_kernel<unsigned short>, rgrid, dim3(256), rlds, st, (const unsigned short *)qraw, q_sn, q_sc,
                            rows, norms, (const uint2 *)list, (const unsigned *)bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2, stats);
-        hipLaunchKernelGGL(refine_rescue_kernel<unsigned short>, sgrid, dim3(256), slds, st, (const unsigned short *)qraw, q_sn, q_sc,
-                           rows, norms, meta, N, ML.N_pad, C, n_ids, keys2, (const unsigned *)bcnt, ML.bucket_cap);
+    // 5. rescue: the 32-query blocks whose bucket is incomplete (a block's hits were not listed, or the bucket overflowed)
+    //    go through the exact fp32 kernel against the whole bank -- their fp32 operand image is packed on the spot (blocks
+    //    of complete buckets return at once in both launches), the minima meet the re-rank's by atomicMin on keys2
+    {
+        const Geom G32 = BL.G32;
+        char *q32 = mws + ML.off_q32;
+        constexpr int SR = QB;
+        const size_t plds = (size_t)SR * (G32.kpad + 1) * sizeof(float) + 2 * SR * sizeof(int);
+        if (q_dtype == MANET_EMB_F32)
+            hipLaunchKernelGGL((pack_rows_kernel<SR, QB, float>), rgrid, dim3(256), plds, st, (const float *)qraw, q_sn, q_sc,
+                               (const int *)nullptr, (const int *)nullptr, N, C, G32.compute, G32.units, G32.kpad, q32,
+                               (long)G32.qblk_bytes, 0.0f, (unsigned *)nullptr, ML.N_pad, n_ids, (const unsigned *)bcnt, ML.bucket_cap);
+        else
+            hipLaunchKernelGGL((pack_rows_kernel<SR, QB, unsigned short>), rgrid, dim3(256), plds, st, (const unsigned short *)qraw,
+                               q_sn, q_sc, (const int *)nullptr, (const int *)nullptr, N, C, G32.compute, G32.units, G32.kpad, q32,
+                               (long)G32.qblk_bytes, 0.0f, (unsigned *)nullptr, ML.N_pad, n_ids, (const unsigned *)bcnt,
+                               ML.bucket_cap);
+        const int nQT32 = (int)(ML.N_pad / QT);
+        const int S32 = pick_splits(nQT32, BL.T_max, 512);
+        tl_bank_bytes_hint = (double)BL.T_max * (double)G32.tile_bytes;
+        const char *bpack32 = bws + BL.off_pack32;
+        switch (G32.steps) {
+        case 16: launch_rescue_f32_pipe<16>(q32, bpack32, meta, n_ids, nQT32, S32, ML.N_pad, keys2, bcnt, ML.bucket_cap, st); break;
+        case 50: launch_rescue_f32_pipe<50>(q32, bpack32, meta, n_ids, nQT32, S32, ML.N_pad, keys2, bcnt, ML.bucket_cap, st); break;
+        case 52: launch_rescue_f32_pipe<52>(q32, bpack32, meta, n_ids, nQT32, S32, ML.N_pad, keys2, bcnt, ML.bucket_cap, st); break;
+        default: launch_rescue_f32_pipe<64>(q32, bpack32, meta, n_ids, nQT32, S32, ML.N_pad, keys2, bcnt, ML.bucket_cap, st); break;
+        }
     }
     const long total = N * n_ids;
     hipLaunchKernelGGL(global_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, keys2, N, ML.N_pad, n_ids,
@@ -2731,6 +2729,11 @@ int manet_bank_prepare_ex(const void *bank, int emb_dtype, int64_t b_stride_m, i
                           C, L.G, ws + L.off_pack, L.T_max, st);
     if (rc) return rc;
     if (compute == MANET_COMPUTE_BF16_REFINE) {
+        // the fp32 operand image of the same sorted bank: what the rescue pass (the exact fp32 kernel on the query blocks
+        // whose candidate buckets are incomplete) multiplies against
+        rc = launch_bank_pack(bank, emb_dtype, (long)b_stride_m, (long)b_stride_c, (const int *)src_of, (const int *)meta,
+                              (long)M0, C, L.G32, ws + L.off_pack32, L.T_max, st);
+        if (rc) return rc;
         // the fp32 copy of the sorted rows the exact re-rank reads, and the sub-sampled bank of the pre-pass
         float *rows = (float *)(ws + L.off_rows), *norms = (float *)(ws + L.off_norms);
         int *sub_meta = (int *)(ws + L.off_sub_meta);
