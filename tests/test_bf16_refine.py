@@ -147,8 +147,8 @@ def test_spatially_smooth_embeddings_do_not_overflow(ops):
 
 def test_partly_degenerate_embeddings_rescue_only_their_blocks(ops):
     """a band of the image where every embedding is the SAME vector (nothing for the bf16 pass to tell apart: hundreds of
-    bank rows tie for every query of the band): those 32-query blocks are marked incomplete and re-scanned exactly by
-    refine_rescue_kernel, the rest of the frame goes through the candidate lists; the result is the fp32 kernel's, bit for bit"""
+    bank rows tie for every query of the band): those 32-query blocks are marked incomplete and re-evaluated exactly by
+    the rescue pass (the exact fp32 kernel on their query tiles), the rest of the frame goes through the candidate lists; the result is the fp32 kernel's, bit for bit"""
     H, W, n_ids = 40, 64, 2
     g = torch.Generator(device="cuda").manual_seed(9)
     q = torch.relu(torch.randn(100, H, W, generator=g, device="cuda")) * 0.2
