@@ -1735,15 +1735,23 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     };
     auto emit_regs = [&](const f32x16 &c, float t, int j, int row0) __attribute__((always_inline)) {
         const unsigned lq = (unsigned)(wave * (NQB * QB) + l31 + 32 * j);  // query inside the workgroup's 512
+        // (four registers at a time first: a block usually has its one or two hits in one group -- 8 tests instead of 16)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool hit = c[r] <= t;
-            const unsigned long long m = __ballot(hit);
-            if (m) {  // wave-uniform: most registers hold no qualifying row for any lane
-                const int slot = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int idx = wl_n[j] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (hit && idx < WL) fl[j * WL + idx] = make_uint2(((unsigned)o << 16) | lq, (unsigned)slot);
-                wl_n[j] += __popcll(m);
+        for (int g4 = 0; g4 < 4; ++g4) {
+            // (the group's minimum is computed here, behind the branch: carrying the four group minima out of the pass's
+            // own min16 -- 10 operations instead of 8 in front of the branch -- measured the same)
+            const float gm = fminf(min3p(c[4 * g4], c[4 * g4 + 1], c[4 * g4 + 2]), c[4 * g4 + 3]);
+            if (!__ballot(gm <= t)) continue;  // wave-uniform
+#pragma unroll
+            for (int r = 4 * g4; r < 4 * g4 + 4; ++r) {
+                const bool hit = c[r] <= t;
+                const unsigned long long m = __ballot(hit);
+                if (m) {  // wave-uniform: most registers hold no qualifying row for any lane
+                    const int slot = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int idx = wl_n[j] + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (hit && idx < WL) fl[j * WL + idx] = make_uint2(((unsigned)o << 16) | lq, (unsigned)slot);
+                    wl_n[j] += __popcll(m);
+                }
             }
         }
     };
@@ -1788,20 +1796,7 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); /* 4 MFMA */                        \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* the refill right behind them */  \
         }                                                                                          \
-        if (FILTER) {                                                                              \
-            const float p0 = min16(c0), p1 = min16(c1), p2 = min16(c2), p3 = min16(c3);            \
-            tq[0] = fminf(tq[0], p0 + sq[0]);                                                      \
-            tq[1] = fminf(tq[1], p1 + sq[1]);                                                      \
-            tq[2] = fminf(tq[2], p2 + sq[2]);                                                      \
-            tq[3] = fminf(tq[3], p3 + sq[3]);                                                      \
-            const bool h0 = p0 <= tq[0], h1 = p1 <= tq[1], h2 = p2 <= tq[2], h3 = p3 <= tq[3];     \
-            if (__ballot(h0 | h1 | h2 | h3)) { /* wave-uniform */                                  \
-                if (__ballot(h0)) emit(c0, tq[0], 0, (row0_));                                     \
-                if (__ballot(h1)) emit(c1, tq[1], 1, (row0_));                                     \
-                if (__ballot(h2)) emit(c2, tq[2], 2, (row0_));                                     \
-                if (__ballot(h3)) emit(c3, tq[3], 3, (row0_));                                     \
-            }                                                                                      \
-        } else {                                                                                   \
+        {                                                                                          \
         _Pragma("unroll") for (int r = 0; r < ((ABL & 4) ? 2 : 16); r += 4)                        \
         {                                                                                          \
             ma[0] = min3p(ma[0], c0[r], c0[r + 2]);                                                \
@@ -1830,7 +1825,7 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         tq[ja_] = fminf(tq[ja_], pa + sq[ja_]);                                                    \
         tq[jb_] = fminf(tq[jb_], pb + sq[jb_]);                                                    \
         const bool ha = pa <= tq[ja_], hb = pb <= tq[jb_];                                         \
-        if (__ballot(ha | hb)) { /* wave-uniform */                                                \
+        if (!(ABL & 16) && __ballot(ha | hb)) { /* wave-uniform */                                 \
             if (__ballot(ha)) emit(ca_, tq[ja_], ja_, (row0_));                                    \
             if (__ballot(hb)) emit(cb_, tq[jb_], jb_, (row0_));                                    \
         }                                                                                          \
@@ -1934,7 +1929,7 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
                 }
             }
             xo = -1;
-            if ((((t - t0) / TPS) & REFINE_XCHG_MASK) == REFINE_XCHG_MASK) {
+            if (!(ABL & 32) && (((t - t0) / TPS) & REFINE_XCHG_MASK) == REFINE_XCHG_MASK) {
                 flush(o);
                 xo = o;
 #pragma unroll
@@ -2505,6 +2500,12 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
         const size_t lds = (size_t)2 * 2 * bank_tile_bytes_u(2 * ML.G.steps, false) + (size_t)REFINE_LDS_LIST * 8 + 4 * 256 * 4;  // + the published keys
         const void *fn = ML.G.steps == 2 ? (const void *)global_match_bf16_wide_kernel<2, 0, true>
                                          : (const void *)global_match_bf16_wide_kernel<7, 0, true>;
+        if (ML.G.steps != 2) {  // timing experiments only (results are wrong): 16 no slow path, 32 no threshold exchange
+            const int fabl = manet_tune_get(MANET_TUNE_ABLATION, 0);
+            if (fabl == 16) fn = (const void *)global_match_bf16_wide_kernel<7, 16, true>;
+            if (fabl == 32) fn = (const void *)global_match_bf16_wide_kernel<7, 32, true>;
+            if (fabl == 48) fn = (const void *)global_match_bf16_wide_kernel<7, 48, true>;
+        }
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const char *bpack = bws + BL.off_pack;
         int nQT = ML.nQT, Sv = S, bm = block_map_arg(ML.nQT, 512), prio = 0;
@@ -2550,7 +2551,10 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
                                (long)G32.qblk_bytes, 0.0f, (unsigned *)nullptr, ML.N_pad, n_ids, (const unsigned *)bcnt,
                                ML.bucket_cap);
         const int nQT32 = (int)(ML.N_pad / QT);
-        const int S32 = pick_splits(nQT32, BL.T_max, 512);
+        // (at most 16 splits: a healthy frame pays for the dispatch of nQT32 x S32 workgroups that return at once -- 7.7 us
+        // at 48 splits -- and a full rescue loses ~10 % to the coarser last round)
+        int S32 = pick_splits(nQT32, BL.T_max, 512);
+        S32 = S32 > 16 ? 16 : S32;
         tl_bank_bytes_hint = (double)BL.T_max * (double)G32.tile_bytes;
         const char *bpack32 = bws + BL.off_pack32;
         switch (G32.steps) {
