@@ -425,23 +425,11 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const SRC *__restrict__ 
                                                         int C, int compute, int units, int kpad,
                                                         char *__restrict__ dst, long tile_bytes,
                                                         float pad_norm, unsigned *__restrict__ keys, long N_pad,
-                                                        int n_ids, const unsigned *__restrict__ only_marked = nullptr,
-                                                        long mark_cap = 0)
+                                                        int n_ids)
 {
     constexpr bool IS_QUERY = (IMG == QB);
     const long tile = blockIdx.x;
     if (meta && tile >= meta[META_T]) return;
-    if (only_marked) {
-        // MANET_COMPUTE_BF16_REFINE's rescue: only the query tiles (QT / QB = 8 blocks: the fp32 kernel's workgroup) that
-        // hold a 32-query block whose candidate bucket is incomplete
-        const long t0 = tile / (QT / QB) * (QT / QB);
-        bool need = false;
-        for (int i = 0; i < QT / QB; ++i) {
-            const unsigned raw = only_marked[t0 + i];
-            need = need || (raw >> 31) || (long)raw > mark_cap;
-        }
-        if (!need) return;
-    }
     if (keys)
         for (int i = threadIdx.x; i < ROWS * n_ids; i += 256) keys[(size_t)(i / ROWS) * N_pad + tile * ROWS + (i % ROWS)] = 0xffffffffu;
     extern __shared__ __attribute__((aligned(16))) char pack_smem[];
@@ -2093,7 +2081,8 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restric
                                                             const float *__restrict__ rows, const float *__restrict__ norms,
                                                             const uint2 *__restrict__ list, const unsigned *__restrict__ bcnt,
                                                             long bucket_cap, long N, long N_pad, int C,
-                                                            unsigned *__restrict__ keys2, unsigned long long *__restrict__ stats)
+                                                            unsigned *__restrict__ keys2, unsigned long long *__restrict__ stats,
+                                                            char *__restrict__ q32, int units32, long qblk_bytes32)
 {
     extern __shared__ __attribute__((aligned(16))) char rr_smem[];
     float *qs = (float *)rr_smem;  // [C][QB]
@@ -2102,13 +2091,40 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restric
     const int cnt = (long)have < bucket_cap ? (int)have : (int)bucket_cap;
     const int tid = threadIdx.x;
     if (((long)have > bucket_cap || (raw >> 31)) && tid == 0) stats[1] = 1ull;  // (statistics; the rescue pass looks at bcnt itself)
-    if (cnt == 0) return;
+    // the rescue pass (the exact fp32 kernel) takes every 256-query tile that holds an incomplete bucket: the blocks of such
+    // a tile also write their fp32 operand image here, where the block's queries are in LDS anyway (a separate pack launch
+    // cost 5 us per healthy frame)
+    bool rescue = false;
+    {
+        const long t0 = b / (QT / QB) * (QT / QB);
+        for (int i = 0; i < QT / QB; ++i) {
+            const unsigned r2 = bcnt[t0 + i];
+            rescue = rescue || (r2 >> 31) || (long)r2 > bucket_cap;
+        }
+    }
+    if (cnt == 0 && !rescue) return;
     for (int idx = tid; idx < QB * C; idx += 256) {
         long n = b * QB + (idx & (QB - 1));
         n = n < N ? n : N - 1;  // (padding queries have no candidates)
         qs[idx] = emb_load(q + n * q_sn, (long)(idx / QB) * q_sc);
     }
     __syncthreads();
+    if (rescue) {  // (block-uniform) the block's image as pack_rows_kernel<32,32> writes it for MANET_COMPUTE_F32
+        char *out0 = q32 + b * qblk_bytes32;
+        for (int item = tid; item < units32 * QB; item += 256) {
+            const int r = item & (QB - 1), u = item / QB;
+            const int k0 = 8 * (u >> 1) + (u & 1);  // image_unit_f32: k0, k0 + 2, k0 + 4, k0 + 6
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (k0 + 2 * e < C) ? qs[(k0 + 2 * e) * QB + r] : 0.0f;
+            *(f32x4 *)(out0 + ((long)u * QB + r) * 16) = v;
+        }
+        if (tid < QB) {
+            float nrm = 0.0f;
+            for (int k = 0; k < C; ++k) nrm = fmaf(qs[k * QB + tid], qs[k * QB + tid], nrm);
+            *(float *)(out0 + (long)units32 * QB * 16 + tid * 4) = nrm;
+        }
+    }
     for (int i = tid; i < cnt; i += 256) {
         const uint2 e = list[b * bucket_cap + i];
         const float *x = qs + (int)((e.x % (unsigned long)N_pad) & (QB - 1));
@@ -2523,33 +2539,25 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
         (void)hipLaunchKernel(fn, dim3((unsigned)(nQT * S)), dim3(256), args, lds, st);
         manet_profile_record(st, false, 0);
     }
-    // 4. exact re-rank of the candidates (+ the rescue scan, a no-op unless the list overflowed), then the usual finish
+    // 4. exact re-rank of the candidates
     const float *rows = (const float *)(bws + BL.off_rows), *norms = (const float *)(bws + BL.off_norms);
     const dim3 rgrid((unsigned)(ML.N_pad / QB));
     const size_t rlds = (size_t)QB * C * sizeof(float);
+    const Geom G32 = BL.G32;
+    char *q32 = mws + ML.off_q32;
     if (q_dtype == MANET_EMB_F32)
         hipLaunchKernelGGL(refine_rerank_kernel<float>, rgrid, dim3(256), rlds, st, (const float *)qraw, q_sn, q_sc, rows, norms,
-                           (const uint2 *)list, (const unsigned *)bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2, stats);
+                           (const uint2 *)list, (const unsigned *)bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2, stats, q32, G32.units,
+                           (long)G32.qblk_bytes);
     else
         hipLaunchKernelGGL(refine_rerank_kernel<unsigned short>, rgrid, dim3(256), rlds, st, (const unsigned short *)qraw, q_sn, q_sc,
-                           rows, norms, (const uint2 *)list, (const unsigned *)bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2, stats);
-    // 5. rescue: the 32-query blocks whose bucket is incomplete (a block's hits were not listed, or the bucket overflowed)
-    //    go through the exact fp32 kernel against the whole bank -- their fp32 operand image is packed on the spot (blocks
-    //    of complete buckets return at once in both launches), the minima meet the re-rank's by atomicMin on keys2
+                           rows, norms, (const uint2 *)list, (const unsigned *)bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2, stats, q32,
+                           G32.units, (long)G32.qblk_bytes);
+    // 5. rescue: the 256-query tiles that hold a 32-query block whose bucket is incomplete (a block's hits were not listed,
+    //    or the bucket overflowed) go through the exact fp32 kernel against the whole bank -- their fp32 operand image was
+    //    written by the re-rank launch above; the workgroups of complete tiles return at once; the minima meet the
+    //    re-rank's by atomicMin on keys2
     {
-        const Geom G32 = BL.G32;
-        char *q32 = mws + ML.off_q32;
-        constexpr int SR = QB;
-        const size_t plds = (size_t)SR * (G32.kpad + 1) * sizeof(float) + 2 * SR * sizeof(int);
-        if (q_dtype == MANET_EMB_F32)
-            hipLaunchKernelGGL((pack_rows_kernel<SR, QB, float>), rgrid, dim3(256), plds, st, (const float *)qraw, q_sn, q_sc,
-                               (const int *)nullptr, (const int *)nullptr, N, C, G32.compute, G32.units, G32.kpad, q32,
-                               (long)G32.qblk_bytes, 0.0f, (unsigned *)nullptr, ML.N_pad, n_ids, (const unsigned *)bcnt, ML.bucket_cap);
-        else
-            hipLaunchKernelGGL((pack_rows_kernel<SR, QB, unsigned short>), rgrid, dim3(256), plds, st, (const unsigned short *)qraw,
-                               q_sn, q_sc, (const int *)nullptr, (const int *)nullptr, N, C, G32.compute, G32.units, G32.kpad, q32,
-                               (long)G32.qblk_bytes, 0.0f, (unsigned *)nullptr, ML.N_pad, n_ids, (const unsigned *)bcnt,
-                               ML.bucket_cap);
         const int nQT32 = (int)(ML.N_pad / QT);
         // (at most 16 splits: a healthy frame pays for the dispatch of nQT32 x S32 workgroups that return at once -- 7.7 us
         // at 48 splits -- and a full rescue loses ~10 % to the coarser last round)
