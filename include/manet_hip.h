@@ -176,8 +176,10 @@ int manet_frame_prepare(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y
  * manet_query_pack with MANET_COMPUTE_BF16 or _BF16_REFINE): the fp32 re-rank also needs the query as stored, so this entry
  * point takes both.  query_image == NULL: same as manet_global_match_prepared_ex(..., MANET_COMPUTE_BF16_REFINE, ...).
  * manet_global_match_refine_stats reads back (blocking copy -- tests / benchmarks) what the last call on `match_ws` did:
- * candidate rows re-evaluated in fp32, and whether the candidate list (16 rows per pair on average) overflowed -- 1: every
- * pair scanned its object's rows instead (exact, slow; duplicated bank rows can do that), 0: never on a sane input. */
+ * qualifying bank rows seen by the filter pass, and whether some 32-query block's candidate bucket (64 rows per pair on
+ * average) was incomplete -- 1: the 256-query tiles of those blocks also went through the exact fp32 kernel (the bank
+ * workspace of this mode carries the fp32 operand image beside the bf16 one for that), which bounds the cost of any input at
+ * about the fp32 path's; 0: the usual case. */
 int manet_global_match_refine(const void *query, int emb_dtype, int64_t q_stride_n, int64_t q_stride_c,
                               const void *query_image, const void *bank_ws, int64_t N, int64_t M0, int C, int n_ids,
                               float *out, float *mem_inout, int epilogue_flags, void *match_ws, size_t match_ws_bytes,
