@@ -54,7 +54,7 @@ int manet_tune_set(int key, int value)
         return manet_set_error(MANET_E_INVALID, "manet_tune_set is for experiments: set MANET_TUNING=1 in the environment");
     if (key < 0 || key >= MANET_TUNE_COUNT) return manet_set_error(MANET_E_INVALID, "tune key %d", key);
     g_tune[key] = value;
-    g_tune_set[key] = true;
+    g_tune_set[key] = value != INT32_MIN;  // INT32_MIN: back to "not set" (the shipped default, e.g. the automatic block map)
     return MANET_OK;
 }
 

@@ -408,7 +408,10 @@ int manet_profile_begin(int max_launches);
 /* Tuning knobs for experiments (process-wide; the defaults are the shipped configuration).  Refused
  * (MANET_E_INVALID) unless the environment has MANET_TUNING=1: without that opt-in nothing can change them, and the
  * data path keeps no state between calls.
- * key 0 = block -> (query tile, bank split) mapping of the global-match kernel (0 XCD-aware),
+ * value INT32_MIN puts a key back to "not set".
+ * key 0 = block -> (query tile, bank split) mapping of the global-match kernels (not set: XCD-aware with as many splits
+ *         fastest as fit an L2 side by side; 0 XCD-aware tile-fastest, 1 tile fastest, 2 split fastest, 4..7 XCD-aware with
+ *         2..5 splits fastest),
  * key 1 = forced number of bank splits (0 = automatic),
  * key 2 = form of the bf16 kernels (bit field, see launch_main_bf16 in csrc/global_match.hip),
  * key 3 = timing ablations (results are garbage), key 4 = 1: the r1 three-launch local match.
