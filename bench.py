@@ -63,39 +63,75 @@ MAIN_KERNEL = {"f32": "global_match_f32_pipe_kernel<50>", "bf16": "global_match_
                "bf16x3": "global_match_bf16_kernel<7, true, 1, true>", "bf16r": "global_match_bf16_wide_kernel<7, 0> + refine"}
 
 
-class Workload:
-    """One BASELINE config: synthetic clip of this rank, memory bank, previous-frame labels."""
+_CLIP_CACHE = {}
 
-    def __init__(self, cfg, compute, emb, device, rank=0, world=1, n_local=8, keep_f32=False):
+
+def _synthetic_scene(kind, n_frames, H, W, n_ids, scale, device, seed):
+    """tools/synth_clip.make_clip, cached per (kind, shape, scale): the robustness legs run three arithmetic modes on one clip"""
+    from tools import synth_clip
+    key = (kind, n_frames, H, W, n_ids, float(scale), str(device), seed)
+    if key not in _CLIP_CACHE:
+        _CLIP_CACHE.clear()  # one clip at a time (130 MB at 480p)
+        _CLIP_CACHE[key] = synth_clip.make_clip(kind, n_frames, C, H, W, n_ids, scale=scale, device=device, seed=seed)
+    return _CLIP_CACHE[key]
+
+
+class Workload:
+    """One BASELINE config: synthetic clip of this rank, memory bank, previous-frame labels.
+
+    The resident QUERY frames (cycled over by the timed steps) and the T BANK frames are different frames: no timed
+    query is its own bank row (r3 cycled over 8 frames of which 5 were bank members -- exact zero-distance duplicates,
+    the cheapest case for the bf16 filter of compute="bf16r").
+    data = "iid" (SURVEY 8d's distribution, the headline) | "video" | "smooth" (tools/synth_clip.py: spatially smooth,
+    temporally redundant, label-coherent clips -- bank frames interleaved in time with the query frames)."""
+
+    def __init__(self, cfg, compute, emb, device, rank=0, world=1, n_local=8, keep_f32=False, data="iid", scale=0.1):
         c = CONFIGS[cfg]
-        self.cfg, self.compute, self.emb = cfg, compute, emb
+        self.cfg, self.compute, self.emb, self.data, self.scale = cfg, compute, emb, data, scale
         self.H, self.W, self.T, self.n_ids, self.d = c["H"], c["W"], c["T"], c["n_ids"], c["d"]
         self.device, self.rank, self.world = device, rank, world
         self.emb_dtype = torch.bfloat16 if emb == "bf16" else torch.float32
-        gen = torch.Generator(device=device).manual_seed(20200614 + 2 + 1000 * rank)
         self.n_local = n_local
-        # resident frames, cycled: 8 x 10.3 MB (fp32, 480p); at least T + 2 when the clip allows, so that the resident set
-        # holds a frame that is not in the bank (the parity probe)
-        n_res = min(n_local, max(8, c["T"] + 2))
-        f32 = [torch.relu(torch.randn(C, self.H, self.W, generator=gen, device=device)) * 0.1 for _ in range(n_res)]
-        # C-major embeddings as extract_feature produces them (post-ReLU), stored in the producer's type
-        self.local_emb = torch.stack([f.to(self.emb_dtype) for f in f32]).contiguous()
-        self.f32_frames = f32 if keep_f32 else None  # the values before storage rounding (parity of the bf16 legs)
         self.F_total = world * n_local
         T, F_total = self.T, self.F_total
+        # which clip frames are the annotated ones (who ships what in the N-rank exchange): spread over the clip
         bank_frames = sorted({int(round(i * (F_total - 1) / max(T - 1, 1))) for i in range(T)})
-        while len(bank_frames) < T:  # tiny clips: duplicate-free fill
-            for f in range(F_total):
-                if f not in bank_frames:
-                    bank_frames.append(f)
-                    break
-            else:
-                break
+        f = 0
+        while len(bank_frames) < T:  # tiny clips: the bank still holds T distinct (synthetic) frames
+            if f not in bank_frames:
+                bank_frames.append(f)
+            f += 1
         self.bank_frames = sorted(bank_frames)[:T]
-        lab_gen = torch.Generator(device=device).manual_seed(20200614 + 2)
-        self.bank_labels = {f: torch.randint(0, self.n_ids, (self.H, self.W), generator=lab_gen, device=device,
-                                             dtype=torch.int32) for f in self.bank_frames}
-        self.prev_labs = [self.blob_labels(s) for s in range(8)]
+        # resident query frames, cycled: 8 x 10.3 MB (fp32, 480p), at least T + 2
+        n_res = min(max(n_local, 1), max(8, T + 2))
+        if data == "iid":
+            gen = torch.Generator(device=device).manual_seed(20200614 + 2 + 1000 * rank)
+            f32 = [torch.relu(torch.randn(C, self.H, self.W, generator=gen, device=device)) * scale for _ in range(n_res)]
+            bank_f32 = {}
+            for fb in self.bank_frames:  # the same on every rank
+                g = torch.Generator(device=device).manual_seed(977 + fb)
+                bank_f32[fb] = torch.relu(torch.randn(C, self.H, self.W, generator=g, device=device)) * scale
+            lab_gen = torch.Generator(device=device).manual_seed(20200614 + 2)
+            self.bank_labels = {fb: torch.randint(0, self.n_ids, (self.H, self.W), generator=lab_gen, device=device,
+                                                  dtype=torch.int32) for fb in self.bank_frames}
+            self.prev_labs = [self.blob_labels(s) for s in range(8)]
+        else:
+            if world != 1:
+                raise SystemExit("bench.py --data %s: single-GPU legs only" % data)
+            n_clip = T + n_res
+            emb_c, lab_c = _synthetic_scene(data, n_clip, self.H, self.W, self.n_ids, scale, device, 20200614 + cfg)
+            pos = sorted({int(round(i * (n_clip - 1) / max(T - 1, 1))) for i in range(T)})
+            qpos = [i for i in range(n_clip) if i not in pos][:n_res]
+            f32 = [emb_c[i] for i in qpos]
+            bank_f32 = {fb: emb_c[pos[j]] for j, fb in enumerate(self.bank_frames)}
+            self.bank_labels = {fb: lab_c[pos[j]].contiguous() for j, fb in enumerate(self.bank_frames)}
+            # the previous frame's mask of query j = the blob labels of the clip frame before it
+            self.prev_labs = [lab_c[max(qpos[j % len(qpos)] - 1, 0)].contiguous() for j in range(8)]
+        # C-major embeddings as extract_feature produces them (post-ReLU), stored in the producer's type
+        self.local_emb = torch.stack([f.to(self.emb_dtype) for f in f32]).contiguous()
+        self.bank_emb = {fb: e.to(self.emb_dtype).contiguous() for fb, e in bank_f32.items()}
+        self.f32_frames = f32 if keep_f32 else None  # the values before storage rounding (parity of the bf16 legs)
+        self.bank_f32 = bank_f32 if keep_f32 else None
         self.gmap = torch.ones(104, self.H * self.W, self.n_ids, device=device)  # IntVOS.py:617
 
     def blob_labels(self, shift):
@@ -115,13 +151,8 @@ class Workload:
         return self.f32_frames[i % len(self.f32_frames)]
 
     def probe_frame(self):
-        """a resident frame that is NOT one of the bank's frames: the frame the parity figures are taken on (a frame of
-        the bank matches itself at distance 0, which says nothing about the arithmetic)"""
-        n = self.local_emb.shape[0]
-        in_bank = {f % n for f in self.bank_frames}
-        for i in range(n):
-            if i not in in_bank:
-                return i
+        """the resident frame the parity figures are taken on (no resident frame is one of the bank's: a frame of the bank
+        would match itself at distance 0, which says nothing about the arithmetic)"""
         return 0
 
     def local_bytes(self):
@@ -130,10 +161,12 @@ class Workload:
 
     def describe(self, args):
         M = self.T * self.H * self.W
-        return ("BASELINE configs[%d]: grid %dx%d, C=%d, %d-frame fully-labelled bank (M=%d), %d ids, %s arithmetic, "
+        return ("BASELINE configs[%d]: %s embeddings, grid %dx%d, C=%d, %d-frame fully-labelled bank (M=%d), %d ids, %s arithmetic, "
                 "%s-stored embeddings; step = frame prepare (query operand + pooled plane, one read of the embedding)%s + global match + fused "
                 "normalise/min-merge + local match d=%d; bank %s"
-                % (self.cfg - 1, self.H, self.W, C, self.T, M, self.n_ids, self.compute, self.emb,
+                % (self.cfg - 1, {"iid": "i.i.d. relu(randn)*%g" % self.scale}.get(self.data, "%s-like (tools/synth_clip.py, scale %g)"
+                                                                                       % (self.data, self.scale)),
+                   self.H, self.W, C, self.T, M, self.n_ids, self.compute, self.emb,
                    " (done by the producer, untimed)" if args.prepacked else "", self.d,
                    "re-sorted/re-packed every frame (one-shot API)" if args.one_shot else
                    "sorted/packed once per clip inside the timed region"))
@@ -164,23 +197,18 @@ def run_leg(wl, K, Wm, args, lib, use_dist=False, one_shot=False, prepacked=Fals
                     def __getitem__(self, i):
                         return wl.frame_emb(i if i >= 0 else n_local + i)
                 owned = _View()
-            extra = None
-            if ownership == "round_robin":  # bank frame j is extracted + shipped by rank j % world (synthetic here)
-                extra = {}
-                for j, f in enumerate(wl.bank_frames):
-                    if j % wl.world == wl.rank and not (my_start <= f < my_start + n_local):
-                        g = torch.Generator(device=device).manual_seed(977 + f)
-                        extra[f] = (torch.relu(torch.randn(C, wl.H, wl.W, generator=g, device=device)) * 0.1).to(wl.emb_dtype)
-                labels = {f: wl.bank_labels[f] for f in wl.bank_frames}
-            else:
-                labels = wl.bank_labels
+            # the annotated frames' embeddings are their own synthetic frames (never one of the timed queries): the rank
+            # that ships bank frame f -- the owner of its block, or rank j % world (round robin) -- hands it over here
+            slots_, table_ = clip_parallel.bank_slots(wl.bank_frames, wl.F_total, wl.world, ownership)
+            extra = {f: wl.bank_emb[f] for (r_, s_, f) in table_ if r_ == wl.rank}
+            labels = {f: wl.bank_labels[f] for f in wl.bank_frames}
             bank_emb, bank_lab, halo = clip_parallel.exchange_bank_and_halo(
                 owned, my_start, wl.bank_frames, labels, wl.F_total, ownership=ownership, extra_embeddings=extra,
                 timing=True)
             if timed:
                 timing["collective"] = dict(clip_parallel.LAST_EXCHANGE)
         else:
-            bank_emb = torch.stack([wl.frame_emb(f) for f in wl.bank_frames])
+            bank_emb = torch.stack([wl.bank_emb[f] for f in wl.bank_frames])
             bank_lab = torch.stack([wl.bank_labels[f] for f in wl.bank_frames])
             halo = None
         # stacked T-frame bank as the API expects it: rows = pixels of all frames (IntVOS.py:203-204)
@@ -299,15 +327,20 @@ def roofline_blocks(wl, kern_ms, local_ms, overlap=False, prep_ms=None):
             "traffic": traffic, "traffic_source": traffic_src, "kernel": MAIN_KERNEL[wl.compute], "kernel_ms": kern_ms,
             "algorithmic_flops_per_launch": flops}
     b = wl.local_bytes()
-    # the HBM-bound stage of the path: HIP events over the local stage's launches
-    local = None if overlap else {"bound": "hbm", "achieved": b / (local_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": b / (local_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
-                                  "stage_ms": local_ms, "algorithmic_bytes": b, "max_distance": wl.d,
-                                  "launches": "fused window/min kernel only (the pooled planes come out of the frame "
-                                              "prepare launch, which also writes the global match's query operand: "
-                                              "frame_prepare_ms)" if prep_ms is not None else
-                                              "pooling pass + fused kernel (one-shot API)",
-                                  "frame_prepare_ms": prep_ms}
+    # the HBM-bound stage of the path.  DEFINITION: `algorithmic_bytes` = both embeddings read once +
+    # labels + the [h,w,n_ids] result (SURVEY 8d's formula); `stage_ms` = EVERY launch that moves those bytes = the fused
+    # window/min kernel (`window_kernel_ms`, HIP events) + the frame prepare launch (`frame_prepare_ms`), which is the one
+    # that reads the embedding and writes the pooled plane the window kernel consumes -- it also writes the global match's
+    # query operand, so the stage is charged conservatively.  (r3 divided the same bytes by the window kernel alone.)
+    local = None
+    if not overlap:
+        stage_ms = local_ms + (prep_ms or 0.0)
+        local = {"bound": "hbm", "achieved": b / (stage_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": b / (stage_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), "stage_ms": stage_ms,
+                 "window_kernel_ms": local_ms, "frame_prepare_ms": prep_ms, "algorithmic_bytes": b,
+                 "max_distance": wl.d,
+                 "launches": "frame prepare (one read of the embedding -> pooled plane + query operand image) + fused "
+                             "window/min kernel" if prep_ms is not None else "pooling pass + fused kernel (one-shot API)"}
     return roof, local
 
 
@@ -438,7 +471,7 @@ def bf16_parity(wl, bank_rows, bank_lab, budget_s=4.0):
                             "err_vs_fp32_oracle_normalised_mean": mean, "argmin_id_flip_fraction": flips}
     # -- unrounded fp32 inputs
     if wl.f32_frames is not None:
-        bank_f32 = torch.stack([wl.frame_f32(f) for f in wl.bank_frames]).permute(0, 2, 3, 1).reshape(-1, C)
+        bank_f32 = torch.stack([wl.bank_f32[f] for f in wl.bank_frames]).permute(0, 2, 3, 1).reshape(-1, C)
         cur_f32 = wl.frame_f32(p)
         raw, nq2, _, _ = oracle_sample(wl, bank_f32, bank_lab, cur_f32, budget_s, nq_cap=nq)
         want, _ = orc.normalize_merge(raw, None, normalize=True)
@@ -491,7 +524,8 @@ def exact_leg(cfg, device, lib, args):
     K, Wm = args.also_steps, 6  # (warm-up long enough for the caching allocator to have seen every per-step block)
     wx = Workload(cfg, "bf16r", "f32", device, n_local=CONFIGS[cfg]["T"] + 2)
     rx = run_leg(wx, K, Wm, args, lib, spin_up_s=0.2)
-    cands, over = rx["bank"].refine_stats()
+    st = rx["bank"].refine_stats_full()
+    cands, over = st["candidate_rows"], st["list_overflowed"]
     q = wx.frame_emb(wx.probe_frame()).permute(1, 2, 0)
     same = bool(torch.equal(ops.global_match(rx["bank_rows"], q, rx["bank_lab"], wx.n_ids, compute="bf16r"),
                             ops.global_match(rx["bank_rows"], q, rx["bank_lab"], wx.n_ids, compute="f32")))
@@ -499,7 +533,127 @@ def exact_leg(cfg, device, lib, args):
             "ms_per_step": rx["elapsed"] / K * 1e3, "filter_kernel_ms": rx["kern_ms"],
             "result": "the fp32 kernel's distances, bit for bit (tests/test_bf16_refine.py)",
             "bit_equal_to_f32_on_probe_frame": same,
-            "candidate_rows_per_pair": cands / float(wx.H * wx.W * wx.n_ids), "candidate_list_overflowed": int(over)}
+            "candidate_rows_per_pair": cands / float(wx.H * wx.W * wx.n_ids), "candidate_list_overflowed": int(over),
+            "rescued_tile_fraction": st["rescued_tile_fraction"],
+            "data": "i.i.d. embeddings, uniform labels: this mode's BEST case -- `robustness` brackets it"}
+
+
+def robustness_block(device, lib, args):
+    """every distribution-dependent claim bracketed in the driver-run line.  cfg2 shape (480p, T=5,
+    2 ids, d=12), fp32-stored embeddings, data in {iid, video, smooth} (tools/synth_clip.py) x scale in {0.1, 0.3} x
+    compute in {f32, bf16, bf16r}: ms per step of the same step the headline times (K steps over non-bank frames),
+    error of the normalised global map of one non-bank frame against the fp32 result (the f32 kernel, itself checked
+    against the CPU oracle on a pixel sample right here) and, for bf16r, the candidate rows per (query, object) pair and
+    the share of 256-query tiles that went through the rescue pass (the exact fp32 kernel)."""
+    from cvpr2020_manet_amd import ops
+    from oracle import oracle as orc
+    K, Wm = args.robust_steps, 3
+    legs = []
+    for data in ("iid", "video", "smooth"):
+        for scale in (0.1, 0.3):
+            ref_norm, oracle_ok = None, None
+            for compute in ("f32", "bf16", "bf16r"):
+                wl = Workload(2, compute, "f32", device, n_local=CONFIGS[2]["T"] + 2, data=data, scale=scale)
+                r = run_leg(wl, K, Wm, args, lib, spin_up_s=0.05)
+                leg = {"data": data, "scale": scale, "compute": compute, "ms_per_step": r["elapsed"] / K * 1e3,
+                       "frames_per_s": K / r["elapsed"], "main_kernel_ms": r["kern_ms"]}
+                q = wl.frame_emb(wl.probe_frame()).permute(1, 2, 0)
+                g = r["bank"].match(ops.prepare_frames(wl.frame_emb(wl.probe_frame()), compute=compute), normalize=True)
+                if compute == "bf16r":
+                    st = r["bank"].refine_stats_full()
+                    leg["candidate_rows_per_pair"] = st["candidate_rows_per_pair"]
+                    leg["rescued_tile_fraction"] = st["rescued_tile_fraction"]
+                got = g.cpu().numpy()
+                if compute == "f32":
+                    ref_norm = got
+                    if not args.no_cpu_baseline:  # the fp32 kernel against the CPU oracle on a pixel sample of this very frame
+                        raw, nq, _, _ = oracle_sample(wl, r["bank_rows"], r["bank_lab"], wl.frame_emb(wl.probe_frame()), 0.3,
+                                                      nq_cap=512)
+                        want, _ = orc.normalize_merge(raw, None, normalize=True)
+                        oracle_ok = bool(np.array_equal(got[:nq], want))
+                    leg["f32_kernel_equals_cpu_oracle_on_sample"] = oracle_ok
+                    leg["err_vs_fp32_oracle_normalised_max"], leg["argmin_flip_fraction"] = 0.0, 0.0
+                else:
+                    mx, _, flips = err_stats(got, ref_norm)
+                    leg["err_vs_fp32_oracle_normalised_max"], leg["argmin_flip_fraction"] = mx, flips
+                    if compute == "bf16r":
+                        leg["bit_equal_to_f32"] = bool(np.array_equal(got, ref_norm))
+                legs.append(leg)
+                del wl, r, g, q
+                torch.cuda.empty_cache()
+    _CLIP_CACHE.clear()
+    torch.cuda.empty_cache()
+
+    def pick(data, compute, key, scale=0.1):
+        return next(l[key] for l in legs if l["data"] == data and l["compute"] == compute and l["scale"] == scale)
+    summary = {"bf16r_frames_per_s_best_typical_worst": [pick("iid", "bf16r", "frames_per_s"), pick("video", "bf16r", "frames_per_s"),
+                                                         pick("smooth", "bf16r", "frames_per_s")],
+               "f32_frames_per_s": pick("iid", "f32", "frames_per_s"),
+               "bf16_max_err_scale_0.1": max(pick(d, "bf16", "err_vs_fp32_oracle_normalised_max") for d in ("iid", "video", "smooth")),
+               "bf16_max_err_scale_0.3": max(pick(d, "bf16", "err_vs_fp32_oracle_normalised_max", 0.3) for d in ("iid", "video", "smooth"))}
+    return {"shape": "cfg2 (480p grid 120x214, T=5, 2 ids, d=12), fp32-stored embeddings, %d steps per leg over non-bank frames" % K,
+            "data_kinds": "iid = relu(randn) + uniform labels (best case); video = smooth field + per-pixel detail + object "
+                          "clusters, temporally adjacent bank frames, blob labels (typical); smooth = 32-pixel bilinear "
+                          "fields, near-identical frames (worst case) -- tools/synth_clip.py",
+            "reference": "normalised global map of a non-bank frame from the fp32 kernel (checked against the CPU oracle on "
+                         "a 512-pixel sample per data kind: f32_kernel_equals_cpu_oracle_on_sample)",
+            "summary": summary, "legs": legs}
+
+
+def e2e_block(device, args):
+    """the end-to-end propagated frame (matching + DynamicSegHead + mask step, test.py:237-259) in the
+    driver-run line.  examples/propagate_clip.py's loop at 480p, 2 objects; the stand-in encoder runs BEFORE the timed
+    region (test.py:143-154 extracts a clip's embeddings up front).  Headline = the exact-fp32 head (`pointwise: f32`, the
+    module's default); the split-bf16 1x1 kernel beside it with its max |logit| deviation from the fp32 head."""
+    from examples import propagate_clip as pc
+    eargs = pc.parse_args(["--frames", str(args.e2e_frames), "--fused-mask-step"])
+    out = {"workload": "examples/propagate_clip.py: %d-frame synthetic clip at 480x854 (grid 120x214), 2 objects (3 ids), "
+                       "1-frame scribble bank, fp32 match, d=12, int_seghead on the annotated frame + prop_seghead + "
+                       "upsample/argmax per frame; encoder outside the timed region" % args.e2e_frames,
+           "unit": "frames/s", "modes": {}}
+    logits = {}
+    for pw in ("f32", "split"):
+        res, clip, final = pc.run_single(eargs, device, pointwise=pw, want_graph=True, want_stages=(pw == "f32"))
+        with torch.no_grad():
+            lg = {}
+            clip.one_round(keep_logits=lg)
+        logits[pw] = lg
+        out["modes"][pw] = res
+        del clip, final
+        torch.cuda.empty_cache()
+    out["value"] = out["modes"]["f32"]["eager_frames_per_s"]
+    out["value_graph"] = out["modes"]["f32"]["graph_frames_per_s"]
+    # split vs f32 head on the first propagated frame (same inputs: later frames see different previous masks)
+    first = min(k for k in logits["f32"] if k > args.e2e_frames // 2)
+    out["split_vs_f32_head_max_abs_logit_diff"] = float((logits["split"][first] - logits["f32"][first]).abs().max().item())
+    out["split_vs_f32_head_logit_scale"] = float(logits["f32"][first].abs().max().item())
+    out["masks_equal_split_vs_f32"] = out["modes"]["f32"]["mask_digest"] == out["modes"]["split"]["mask_digest"]
+    return out
+
+
+def e2e_parallel_main(args, device, rank, world, backend):
+    """`bench.py --e2e [--gpus N]`: the clip-parallel real propagation as a bench line: a fixed
+    `--e2e-frames` clip (strong scaling), N ranks compute the global maps of their frame blocks, ONE gather per round to the
+    chain rank, which runs local match + head + mask sequentially (examples/propagate_clip.py)."""
+    from examples import propagate_clip as pc
+    eargs = pc.parse_args(["--frames", str(args.e2e_frames), "--fused-mask-step", "--gpus", str(world)])
+    if world > 1:
+        res = pc.run_parallel(eargs, device, rank, world)
+    else:
+        r1, clip, final = pc.run_single(eargs, device)
+        res = {"frames": r1["frames"], "world": 1, "backend": None, "pointwise": r1["pointwise"], "compute": r1["compute"],
+               "parallel_ms_per_round": r1["eager_ms_per_round"], "parallel_frames_per_s": r1["eager_frames_per_s"],
+               "masks_bit_equal_to_single_rank": True, "mask_digest": r1["mask_digest"], "collective": None}
+    if rank != 0:
+        return None
+    return {"metric": "propagated frames/sec at 480p, end to end (matching + head + mask step), clip-parallel",
+            "value": res["parallel_frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": res["frames"] - 1,
+            "warmup": res["frames"] - 1, "ms_per_step": res["parallel_ms_per_round"] / (res["frames"] - 1),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "examples/propagate_clip.py: %d-frame 480p clip, 2 objects, 1-frame scribble bank, exact fp32 "
+                                   "head; ranks compute the global maps of their frame blocks, rank 0 runs the sequential chain"
+                                   % res["frames"], "clip_frames": res["frames"]},
+            "collective": res.get("collective"), "e2e_parallel": res}
 
 
 def spawn_ranks(n, argv):
@@ -547,6 +701,18 @@ def main():
     ap.add_argument("--scaling", type=str, default="weak", choices=["weak", "strong"],
                     help="weak: K frames per rank (the driver's contract); strong: a fixed 64-frame clip (BASELINE "
                          "configs[3]) cut into 64 / N frames per rank (--steps is ignored)")
+    ap.add_argument("--data", type=str, default="iid", choices=["iid", "video", "smooth"],
+                    help="embedding distribution of the main leg (tools/synth_clip.py): iid = SURVEY 8d's relu(randn) with "
+                         "uniform labels (the headline); video / smooth = spatially smooth, temporally redundant, "
+                         "label-coherent clips (N = 1 only).  The default line brackets all three in `robustness`.")
+    ap.add_argument("--scale", type=float, default=0.1, help="embedding scale (SURVEY 8d: 0.1)")
+    ap.add_argument("--no-robustness", action="store_true", help="skip the `robustness` legs of the N=1 line")
+    ap.add_argument("--robust-steps", type=int, default=10)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end `e2e` block of the N=1 line")
+    ap.add_argument("--e2e-frames", type=int, default=32)
+    ap.add_argument("--e2e", action="store_true",
+                    help="print the END-TO-END line instead (matching + head + mask step; with --gpus N the clip-parallel "
+                         "propagation of examples/propagate_clip.py: strong scaling over a fixed --e2e-frames clip)")
     ap.add_argument("--bank-ownership", type=str, default="round_robin", choices=["block", "round_robin"],
                     help="who ships which bank frame in the all-gather (clip_parallel): round_robin bounds every rank's "
                          "slab at ceil(T / N) frames")
@@ -597,13 +763,26 @@ def main():
         k_, v_ = kv.split("=")
         _lib.check(lib.manet_tune_set(int(k_), int(v_)), "manet_tune_set")
 
+    if args.e2e:
+        line = e2e_parallel_main(args, device, rank, world, backend)
+        if use_dist:
+            dist.destroy_process_group()
+        if rank == 0:
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            print(json.dumps(line), flush=True)
+        return
+
     K, Wm = args.steps, args.warmup
     if args.scaling == "strong":
         K = max(1, 64 // world)
     T = CONFIGS[args.cfg]["T"]
     # this rank's K frames of the clip (synthetic embeddings, resident in HBM); the clip is at least long enough to
     # contain T distinct annotated frames; only K are timed
-    wl = Workload(args.cfg, args.compute, args.emb, device, rank, world, n_local=max(K, -(-T // world)))
+    wl = Workload(args.cfg, args.compute, args.emb, device, rank, world, n_local=max(K, -(-T // world)), data=args.data,
+                  scale=args.scale)
     r = run_leg(wl, K, Wm, args, lib, use_dist=use_dist, one_shot=args.one_shot, prepacked=args.prepacked,
                 overlap=args.overlap, ownership=args.bank_ownership)
     elapsed = r["elapsed"]
@@ -654,9 +833,11 @@ def main():
             line["cpu_baseline"], line["parity"] = cpu_baseline(wl, bank_rows, bank_lab, g_chk, l_chk)
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None  # measured on rank 0 at N=1 only (see the N=1 line)
-        if world == 1 and not use_dist and not args.no_also and args.cfg == 2 and args.compute == "f32":
+        default_line = world == 1 and not use_dist and args.cfg == 2 and args.compute == "f32" and args.data == "iid"
+        if default_line:
             del wl, r, bank_rows, bank_lab
             torch.cuda.empty_cache()
+        if default_line and not args.no_also:
             # the headline's own workload through the exact bf16 filter + fp32 re-rank: same bits as the fp32 line above
             line["headline_exact_mode"] = exact_leg(2, device, lib, args)
             torch.cuda.empty_cache()
@@ -664,6 +845,10 @@ def main():
             for cfg_, compute_ in ((3, "bf16"), (5, "bf16")):
                 line["also"].append(also_leg(cfg_, compute_, device, lib, args))
                 torch.cuda.empty_cache()
+        if default_line and not args.no_robustness:
+            line["robustness"] = robustness_block(device, lib, args)
+        if default_line and not args.no_e2e:
+            line["e2e"] = e2e_block(device, args)
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

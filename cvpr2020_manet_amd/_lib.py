@@ -74,6 +74,7 @@ SIGNATURES = {
     "manet_global_match_refine": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "manet_global_match_refine_stats": (_i, [_vp, _i64, _i, _i, ctypes.POINTER(ctypes.c_int64),
                                              ctypes.POINTER(ctypes.c_int64)]),
+    "manet_global_match_refine_stats2": (_i, [_vp, _i64, _i, _i, ctypes.POINTER(ctypes.c_int64)]),
     "manet_frame_workspace_bytes": (_i, [_i, _i, _i, _i, _i, _szp]),
     "manet_frame_prepare": (_i, [_vp, _i, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i64,
                                  ctypes.c_uint32, _vp]),

@@ -33,6 +33,8 @@ import torch.distributed as dist
 # what the last exchange_bank_and_halo() of this process did (bench.py echoes it in its JSON line so that a run with
 # N ranks is self-evidencing): backend, world size seen by the collective, slab bytes, all-gather time
 LAST_EXCHANGE = {}
+# ... and what the last gather_frame_rows() did (the per-round gather of the clip-parallel propagation)
+LAST_GATHER = {}
 
 
 def shard_frames(num_frames, world_size, rank):
@@ -183,3 +185,62 @@ def slab_bytes(C, h, w, bank_frames, num_frames, world_size, elem_size=4, owners
     ceil(T / world)."""
     slots, _ = bank_slots(bank_frames, num_frames, world_size, ownership)
     return slots * (C * h * w * elem_size + h * w * 4) + C * h * w * elem_size
+
+
+def all_gather_clip(local_embeddings, num_frames, group=None):
+    """Every rank contributes the embeddings of its contiguous frame block (shard_frames) and receives the whole clip
+    [num_frames, C, h, w] -- SURVEY 8e's collective after sharded feature extraction: ONE all-gather of equal-size byte
+    slabs (blocks differ by at most one frame; the short ones are padded).  Paid once per clip: the embeddings do not
+    change between interaction rounds."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    f_local, C, h, w = local_embeddings.shape
+    per = -(-num_frames // world)
+    frame_b = C * h * w * local_embeddings.element_size()
+    slab = torch.zeros(per * frame_b, dtype=torch.uint8, device=local_embeddings.device)
+    if f_local:
+        slab[:f_local * frame_b] = _bytes(local_embeddings)
+    gathered = _all_gather_flat(slab, world, group).view(world, per * frame_b)
+    parts = []
+    for r in range(world):
+        s0, e0 = shard_frames(num_frames, world, r)
+        if e0 > s0:
+            parts.append(gathered[r, :(e0 - s0) * frame_b])
+    return torch.cat(parts).view(local_embeddings.dtype).view(num_frames, C, h, w)
+
+
+def gather_frame_rows(local_rows, num_frames, dst=0, group=None, timing=False):
+    """ONE gather to rank `dst` of per-frame float32 rows: `local_rows` [f_local, L] belong to this rank's contiguous
+    frame block (shard_frames); returns [num_frames, L] on `dst` (frames in clip order), None elsewhere.  The
+    clip-parallel propagation ships the normalised + merged global maps of a round this way ([h*w*n_ids] = 205 KB per
+    480p frame and 2 ids: 13 MB for a 64-frame clip -- 0.09 ms on one xGMI link)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    f_local, L = local_rows.shape
+    s0, e0 = shard_frames(num_frames, world, rank)
+    if f_local != e0 - s0:
+        raise ValueError("rank %d holds %d rows for its %d frames" % (rank, f_local, e0 - s0))
+    per = -(-num_frames // world)
+    dev = local_rows.device
+    slab = torch.zeros((per, L), dtype=torch.float32, device=dev)
+    if f_local:
+        slab[:f_local] = local_rows
+    staged = dist.get_backend(group) == "gloo" and slab.is_cuda  # gloo has no device collectives: stage through the host
+    if timing and slab.is_cuda:
+        torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    send = slab.cpu() if staged else slab
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bufs, dst=dst, group=group)
+    out = None
+    if rank == dst:
+        parts = []
+        for r in range(world):
+            a, b = shard_frames(num_frames, world, r)
+            if b > a:
+                parts.append(bufs[r][:b - a])
+        out = torch.cat(parts).to(dev)
+    if timing and slab.is_cuda:
+        torch.cuda.synchronize(dev)
+    LAST_GATHER.clear()
+    LAST_GATHER.update({"backend": dist.get_backend(group), "world": world, "dst": dst, "slab_bytes": int(per * L * 4),
+                        "gathered_bytes": int(world * per * L * 4), "gather_ms": (time.perf_counter() - t0) * 1e3 if timing else None})
+    return out

@@ -3040,6 +3040,41 @@ int manet_global_match_refine_stats(const void *match_ws, int64_t N, int C, int 
     return MANET_OK;
 }
 
+int manet_global_match_refine_stats2(const void *match_ws, int64_t N, int C, int n_ids, int64_t *stats4)
+{
+    if (!match_ws || !stats4) return manet_set_error(MANET_E_INVALID, "null pointer");
+    int rc = check_common(N, 0, C, n_ids, 1, MANET_COMPUTE_BF16_REFINE);
+    if (rc) return rc;
+    MatchLayout ML = match_layout(N, C, n_ids, MANET_COMPUTE_BF16_REFINE, 1);
+    unsigned long long h[2] = {0, 0};
+    const long nb = ML.N_pad / QB;
+    unsigned *bc = (unsigned *)malloc((size_t)nb * sizeof(unsigned));
+    if (!bc) return manet_set_error(MANET_E_INVALID, "out of host memory");
+    if (hipMemcpy(h, (const char *)match_ws + ML.off_stats, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(bc, (const char *)match_ws + ML.off_bcnt, (size_t)nb * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) {
+        free(bc);
+        return manet_set_error(MANET_E_LAUNCH, "reading the statistics failed");
+    }
+    // a 256-query tile goes through the rescue pass (the exact fp32 kernel) iff one of its eight 32-query blocks has an
+    // incomplete bucket -- the same test global_match_f32_pipe_kernel<KS, RESCUE> makes
+    long rescued = 0;
+    const long tiles = ML.N_pad / QT;
+    for (long t = 0; t < tiles; ++t) {
+        bool need = false;
+        for (int i = 0; i < QT / QB; ++i) {
+            const unsigned raw = bc[t * (QT / QB) + i];
+            need = need || (raw >> 31) || (long)raw > ML.bucket_cap;
+        }
+        rescued += need ? 1 : 0;
+    }
+    free(bc);
+    stats4[0] = (int64_t)h[0];
+    stats4[1] = (int64_t)h[1];
+    stats4[2] = (int64_t)rescued;
+    stats4[3] = (int64_t)tiles;
+    return MANET_OK;
+}
+
 int manet_normalize_merge_f32(float *x, float *mem_inout, int64_t n, int normalize, manet_stream_t stream)
 {
     if (n < 0 || (n > 0 && !x)) return manet_set_error(MANET_E_INVALID, "bad arguments");

@@ -43,16 +43,23 @@ WRONG_LABEL_PADDING_DISTANCE = 1e20
 cfg = _default_cfg
 
 # the heads' 1x1 convolutions with 256 output channels (inference fast path):
+#   "f32"   : the exact fp32-MFMA kernel (ops.conv1x1_mfma; True is accepted as an alias) -- the default: the reference's
+#             nn.Conv2d is an fp32 convolution;
 #   "split" : split-bf16 MFMA kernel (ops.conv1x1_split: fp32 factors as hi + lo bf16 pieces, fp32 accumulation; error
 #             <= 2^-16 relative per product -- between fp32 and the TF32 the reference's cuDNN path defaults to) -- the stage
-#             becomes a stream over its activation;
-#   "f32"   : the exact fp32-MFMA kernel (ops.conv1x1_mfma; True is accepted as an alias);
-#   False   : the framework's GEMM as in r2.          (A/B switch: examples/propagate_clip.py --pointwise)
-MFMA_POINTWISE = "split"
+#             becomes a stream over its activation (2.3x faster); opt-in;
+#   False / "framework" : the framework's GEMM as in r2.
+# This global is only the default of heads built OUTSIDE an IntVOS; a model carries its own mode
+# (IntVOS(cfg, fe, pointwise=...) / cfg.MODEL_HEAD_POINTWISE), stamped on its _split_separable_conv2d blocks.
+MFMA_POINTWISE = "f32"
+_POINTWISE_MODES = {"f32": "f32", True: "f32", "split": "split", False: False, "framework": False}
 
 
-def _pointwise_mode():
-    return "f32" if MFMA_POINTWISE is True else MFMA_POINTWISE
+def _pointwise_mode(block=None):
+    mode = getattr(block, "_pw_mode", None) if block is not None else None
+    if mode is None:
+        mode = MFMA_POINTWISE
+    return _POINTWISE_MODES[mode]
 
 # arithmetic of the QK^T contraction used by the MODULE-LEVEL functions: "f32" (exact fp32 MFMA) | "bf16" | "bf16x3" |
 # "bf16r".  An IntVOS instance carries its own (constructor argument / cfg.MODEL_MATCH_COMPUTE).
@@ -232,7 +239,7 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         its weights -- bn2(conv2(x)) == conv2'(x) -- the latter also split at input channel `cs` (forward_shared)."""
         src = [self.bn1.weight, self.bn1.bias, self.bn1.running_mean, self.bn1.running_var, self.bn2.weight,
                self.bn2.bias, self.bn2.running_mean, self.bn2.running_var, self.conv2.weight, self.conv2.bias]
-        key = (cs, _pointwise_mode()) + tuple((t.data_ptr(), t._version) if t is not None else None for t in src)
+        key = (cs, _pointwise_mode(self)) + tuple((t.data_ptr(), t._version) if t is not None else None for t in src)
         hit = getattr(self, "_fold_cache", None)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -243,7 +250,7 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
             b2 = (self.conv2.bias.detach().float() * scale2 + shift2 if self.conv2.bias is not None else shift2).contiguous()
             val = {"scale1": scale1.contiguous(), "shift1": shift1.contiguous(), "w2": w2, "b2": b2,
                    "w2_shared": w2[:, :cs].contiguous(), "w2_object": w2[:, cs:].contiguous()}
-            mode = _pointwise_mode()
+            mode = _pointwise_mode(self)
             if self.conv2.out_channels == ops.PW_COUT and mode and w2.is_cuda:  # the weight transposed [Cin, Cout]
                 w2t = w2.reshape(w2.shape[0], w2.shape[1]).t().contiguous()
                 if mode == "split":  # ops.conv1x1_split: packed hi / lo operand images
@@ -374,7 +381,9 @@ def _obj_ids(n_ids, device):
 
 MAX_CLIP_FRAMES = 104       # hard-coded clip length of the reference's memories (IntVOS.py:617,645)
 MAX_INTERACTIONS = 9        # IntVOS.py:641,645
-MAX_CACHED_FRAMES = 2 * MAX_CLIP_FRAMES + 8  # prepared per-frame operands kept per model (17 MB each at 480p)
+MAX_CACHED_FRAMES = 2 * MAX_CLIP_FRAMES + 8  # most prepared per-frame operands a model ever keeps (17 MB each at 480p)
+DEFAULT_CACHED_FRAMES = 4   # ... and what it keeps unless the driver prepared a clip up front (prepare_clip /
+                            # extract_feature(packed=True)): enough for test.py:259's cur -> prev hand-over + the annotated frame
 MAX_CACHED_BANKS = 2        # prepared memory banks kept per model (one per sequence name)
 _EMB_DTYPES = {"f32": torch.float32, "fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
                "bfloat16": torch.bfloat16, torch.float32: torch.float32, torch.bfloat16: torch.bfloat16}
@@ -383,15 +392,28 @@ _EMB_DTYPES = {"f32": torch.float32, "fp32": torch.float32, "float32": torch.flo
 class IntVOS(nn.Module):
     """reference IntVOS.py:530-764: same constructor, methods, dict conventions, state-dict keys."""
 
-    def __init__(self, cfg, feature_extracter, compute=None, emb_dtype=None):
-        """cfg, feature_extracter: as the reference.  compute / emb_dtype (optional, this implementation only; default:
-        cfg.MODEL_MATCH_COMPUTE / cfg.MODEL_EMB_DTYPE when the cfg has them, else "f32" / "f32"):
-          compute    arithmetic of the global match: "f32" exact | "bf16" | "bf16x3" | "bf16r"
-          emb_dtype  storage type of extract_feature's output: "f32" | "bf16" (the matching kernels then read 2-byte
-                     embeddings end to end; the heads widen them)"""
+    def __init__(self, cfg, feature_extracter, compute=None, emb_dtype=None, pointwise=None, cache_frames=None):
+        """cfg, feature_extracter: as the reference.  The rest is optional and this implementation's only (default: the
+        cfg's MODEL_MATCH_COMPUTE / MODEL_EMB_DTYPE / MODEL_HEAD_POINTWISE / MODEL_CACHE_FRAMES when it has them, else
+        "f32" / "f32" / "f32" / True):
+          compute       arithmetic of the global match: "f32" exact | "bf16" | "bf16x3" | "bf16r"
+          emb_dtype     storage type of extract_feature's output: "f32" | "bf16" (the matching kernels then read 2-byte
+                        embeddings end to end; the heads widen them)
+          pointwise     the heads' 256-channel 1x1 layers in inference: "f32" exact fp32-MFMA kernel | "split" split-bf16
+                        MFMA kernel (<= 2^-16 relative per product, 2.3x faster) | "framework" the framework's GEMM
+          cache_frames  keep prepared per-frame operands keyed on the embedding tensor's identity (_prepared_frame).
+                        False: every call prepares afresh -- REQUIRED when embeddings are rewritten in place without
+                        torch noticing (HIP-graph replay of the encoder into a static buffer, `.data` writes)"""
         super().__init__()
         set_cfg(cfg)
         self.cfg = cfg
+        pw = pointwise if pointwise is not None else getattr(cfg, "MODEL_HEAD_POINTWISE", "f32")
+        if pw not in _POINTWISE_MODES:
+            raise ValueError("pointwise=%r ('f32', 'split' or 'framework')" % (pw,))
+        self.pointwise = pw
+        cf = cache_frames if cache_frames is not None else getattr(cfg, "MODEL_CACHE_FRAMES", True)
+        self.cache_frames = bool(cf)
+        self._frame_cache_cap = DEFAULT_CACHED_FRAMES
         self.compute = compute if compute is not None else getattr(cfg, "MODEL_MATCH_COMPUTE", "f32")
         if self.compute not in ops.COMPUTE:
             raise ValueError("compute=%r (one of %s)" % (self.compute, sorted(ops.COMPUTE)))
@@ -423,6 +445,9 @@ class IntVOS(nn.Module):
             self.inter_seghead = IntSegHead(in_dim=cfg.MODEL_SEMANTIC_EMBEDDING_DIM + 3)
         else:
             self.inter_seghead = DynamicSegHead(in_dim=cfg.MODEL_SEMANTIC_EMBEDDING_DIM + 2)  # interaction head
+        for m in self.modules():  # this model's 1x1 mode (not a process-wide switch: two models may differ)
+            if isinstance(m, _split_separable_conv2d):
+                object.__setattr__(m, "_pw_mode", self.pointwise)
 
     def _prepared_bank(self, seq_name, ref_emb_chw, ref_label, ref_emb_hwc, ref_lab_flat, n_ids):
         """The sorted / packed memory bank of the annotated frame, reused while the caller keeps passing the SAME
@@ -431,10 +456,18 @@ class IntVOS(nn.Module):
         sorted and packed once per interaction instead of once per frame.  One bank per sequence name, the
         MAX_CACHED_BANKS most recently used sequences.  (Writes that bypass torch's version counter -- `.data`, raw
         pointers -- are invisible to the key: call invalidate_caches() after such a write.)"""
-        key = (ref_emb_chw.data_ptr(), tuple(ref_emb_chw.shape), tuple(ref_emb_chw.stride()), ref_emb_chw._version,
-               ref_emb_chw.dtype, ref_label.data_ptr(), tuple(ref_label.shape), ref_label._version, ref_label.dtype,
-               n_ids, self.compute, bool(self.cfg.TEST_MODE))
         hit = self._bank_cache.get(seq_name)
+        try:
+            key = (ref_emb_chw.data_ptr(), tuple(ref_emb_chw.shape), tuple(ref_emb_chw.stride()), ref_emb_chw._version,
+                   ref_emb_chw.dtype, ref_label.data_ptr(), tuple(ref_label.shape), ref_label._version, ref_label.dtype,
+                   n_ids, self.compute, bool(self.cfg.TEST_MODE))
+        except RuntimeError:
+            # inference tensors carry no version counter: nothing trustworthy to key on -- sort / pack afresh (into the
+            # previous bank's workspace) on every call
+            bank = ops.PreparedBank(ref_emb_hwc, ref_lab_flat, n_ids, compute=self.compute,
+                                    reuse=hit[1] if hit is not None else None)
+            self._bank_cache[seq_name] = (None, bank, ref_emb_chw, ref_label)
+            return bank
         if hit is not None and hit[0] == key:
             self._bank_cache.move_to_end(seq_name)
             return hit[1]
@@ -449,8 +482,13 @@ class IntVOS(nn.Module):
 
     # ---- per-frame operands (the producer side of the path) ------------------------------------
     def _frame_key(self, emb_chw, d):
-        return (emb_chw.data_ptr(), tuple(emb_chw.shape), tuple(emb_chw.stride()), emb_chw._version, emb_chw.dtype,
-                self.compute, d)
+        """identity of an embedding tensor, or None when it has none that can be trusted: inference tensors carry no
+        version counter (torch raises on `._version`) -- such frames are prepared afresh on every call"""
+        try:
+            ver = emb_chw._version
+        except RuntimeError:
+            return None
+        return (emb_chw.data_ptr(), tuple(emb_chw.shape), tuple(emb_chw.stride()), ver, emb_chw.dtype, self.compute, d)
 
     def _local_radius(self):
         """window radius the pooled planes are padded for; -1 (no plane) when the fused local kernel does not apply"""
@@ -465,17 +503,18 @@ class IntVOS(nn.Module):
         (frame, preset_done).  Inside a HIP-graph capture nothing is cached (a replay sees new contents in the same
         buffers), the prepare launch is part of the graph."""
         d = self._local_radius()
-        capturing = torch.cuda.is_current_stream_capturing()
-        key = self._frame_key(emb_chw, d)
-        hit = None if capturing else self._frame_cache.get(key)
+        key = None
+        if self.cache_frames and not torch.cuda.is_current_stream_capturing():
+            key = self._frame_key(emb_chw, d)
+        hit = self._frame_cache.get(key) if key is not None else None
         if hit is not None:
             self._frame_cache.move_to_end(key)
             return hit, False
         frame = ops.prepare_frames(emb_chw, compute=self.compute, max_distance=d, preset=preset)
-        if not capturing:
+        if key is not None:
             frame.keep = emb_chw  # the key holds a storage pointer: keep the tensor alive with the entry
             self._frame_cache[key] = frame
-            while len(self._frame_cache) > MAX_CACHED_FRAMES:
+            while len(self._frame_cache) > self._frame_cache_cap:
                 self._frame_cache.popitem(last=False)
         return frame, preset is not None
 
@@ -485,16 +524,20 @@ class IntVOS(nn.Module):
         finds each `embeddings[i]` ready.  Returns `embeddings` (in this model's storage type: pass the result on)."""
         if embeddings.dtype != self.emb_dtype:
             embeddings = embeddings.to(self.emb_dtype)
-        if not embeddings.is_cuda or (torch.is_grad_enabled() and embeddings.requires_grad):
+        if not embeddings.is_cuda or (torch.is_grad_enabled() and embeddings.requires_grad) or not self.cache_frames:
             return embeddings
         d = self._local_radius()
+        if embeddings.shape[0] == 0 or self._frame_key(embeddings[0], d) is None:  # inference tensors: nothing to key on
+            return embeddings
+        # opting in to the clip-sized cache: room for this clip's frames (+ the default few), at most MAX_CACHED_FRAMES
+        self._frame_cache_cap = min(MAX_CACHED_FRAMES, max(self._frame_cache_cap, embeddings.shape[0] + DEFAULT_CACHED_FRAMES))
         for i0 in range(0, embeddings.shape[0], batch):
             chunk = embeddings[i0:i0 + batch]
             for j, fr in enumerate(ops.prepare_frames(chunk, compute=self.compute, max_distance=d)):
                 e = embeddings[i0 + j]
                 fr.keep = e
                 self._frame_cache[self._frame_key(e, d)] = fr
-        while len(self._frame_cache) > max(MAX_CACHED_FRAMES, embeddings.shape[0]):
+        while len(self._frame_cache) > self._frame_cache_cap:
             self._frame_cache.popitem(last=False)
         return embeddings
 
@@ -505,6 +548,7 @@ class IntVOS(nn.Module):
         the identity keys can see."""
         self._bank_cache.clear()
         self._frame_cache.clear()
+        self._frame_cache_cap = DEFAULT_CACHED_FRAMES
         for m in self.modules():
             if hasattr(m, "_fold_cache"):
                 object.__setattr__(m, "_fold_cache", None)
@@ -558,13 +602,50 @@ class IntVOS(nn.Module):
             x = self.prepare_clip(x, batch=max(1, x.shape[0]))
         return x
 
+    def global_maps(self, ref_frame_embedding, ref_scribble_label, embeddings, frame_nums, seq_name, gt_id,
+                    stored_maps=None):
+        """The label-INDEPENDENT half of `prop_seghead` for a block of frames (this implementation only): the global
+        match of every frame of `embeddings` [f, C, h, w] against the annotated frame (`ref_frame_embedding` [1, C, h, w],
+        `ref_scribble_label` [1, 1, h, w] at grid resolution -- TEST_MODE's convention, IntVOS.py:591-592), normalised
+        (IntVOS.py:611-612) and min-merged (:615-622) with `stored_maps` [f, h*w*n_ids] (the frames' rows of
+        `global_map_tmp_dic`; None = the first round's all-ones).  Returns float32 [f, h*w*n_ids]: what
+        `prop_seghead(..., global_map_precomputed=...)` consumes.  Frame t's map needs only (bank, embedding_t, stored
+        map_t): the frames of a clip shard over the GPUs of a node, the sequential chain (local match ->
+        head -> mask) then runs on one.  Same kernels as inside prop_seghead: the same bits."""
+        f, c, h, w = embeddings.shape
+        n_ids = _n_ids_from(gt_id, None)
+        if not embeddings.is_cuda:
+            raise RuntimeError("global_maps: embeddings must be on a HIP device (no CPU fallback)")
+        if self.cfg.TEST_MODE:  # as prop_seghead (IntVOS.py:591-595)
+            lab = ref_scribble_label.float()
+        else:
+            lab = F.interpolate(ref_scribble_label.float(), size=(h, w), mode="nearest")
+        ref_lab = lab.int()[0].permute(1, 2, 0).reshape(-1)
+        bank = self._prepared_bank(seq_name, ref_frame_embedding[0], ref_scribble_label[0],
+                                   ref_frame_embedding[0].permute(1, 2, 0), ref_lab, n_ids)
+        out = torch.empty((f, h * w * n_ids), dtype=torch.float32, device=embeddings.device)
+        if stored_maps is None:
+            mem = torch.ones_like(out)
+        else:
+            mem = stored_maps.reshape(f, h * w * n_ids).to(torch.float32).clone()
+        for i in range(f):
+            fcur, _ = self._prepared_frame(embeddings[i])
+            bank.match(fcur, normalize=True, mem=mem[i], out=out[i].view(h * w, n_ids))
+        return out
+
     # reference IntVOS.py:583-681
     def prop_seghead(self, ref_frame_embedding=None, previous_frame_embedding=None, current_frame_embedding=None,
                      ref_scribble_label=None, previous_frame_mask=None, normalize_nearest_neighbor_distances=True,
                      use_local_map=True, seq_names=None, gt_ids=None, k_nearest_neighbors=1,
                      global_map_tmp_dic=None, local_map_dics=None, interaction_num=None,
-                     start_annotated_frame=None, frame_num=None, dynamic_seghead=None):
-        """return: feature_embedding, global_match_map, local_match_map, previous_frame_mask"""
+                     start_annotated_frame=None, frame_num=None, dynamic_seghead=None, global_map_precomputed=None):
+        """return: feature_embedding, global_match_map, local_match_map, previous_frame_mask
+
+        global_map_precomputed (this implementation only; the reference's signature is a prefix of this one): dict
+        seq_name -> {frame number -> float32 tensor of h*w*n_ids elements}: the normalised, min-merged global map of that
+        frame as `global_maps()` returns it -- computed ahead of the sequential chain, e.g. by the other GPUs of the node
+        (clip_parallel.propagate_round).  The global match of such a frame is skipped; the map is stored into
+        `global_map_tmp_dic` exactly as the fused epilogue would have left it."""
         cfg = self.cfg
         dic_tmp = {}
         bs, c, h, w = current_frame_embedding.size()
@@ -604,7 +685,14 @@ class IntVOS(nn.Module):
                 torch.is_grad_enabled() and (ref_frame_embedding.requires_grad or current_frame_embedding.requires_grad
                                              or previous_frame_embedding.requires_grad))
             fused_local = use_local_map and inference and self._local_radius() >= 0
-            if k_nearest_neighbors == 1 and inference:
+            pre = None
+            if global_map_precomputed is not None and seq_names[n] in global_map_precomputed:
+                pre = global_map_precomputed[seq_names[n]].get(int(frame_num[n]))
+            if pre is not None:
+                if not inference or not normalize_nearest_neighbor_distances or mem is None:
+                    raise ValueError("global_map_precomputed needs inference mode, normalised distances and a "
+                                     "global_map_tmp_dic (it carries the merged map of global_maps())")
+            elif k_nearest_neighbors == 1 and inference:
                 bank = self._prepared_bank(seq_names[n], ref_frame_embedding[n], ref_scribble_label[n], ref_emb,
                                            ref_lab, n_ids)
             if inference and (bank is not None or fused_local):
@@ -613,7 +701,10 @@ class IntVOS(nn.Module):
                 if fused_local and self._local_radius() >= 11:
                     lpre = torch.empty((h, w, n_ids), dtype=torch.float32, device=current_frame_embedding.device)
                 fcur, preset_done = self._prepared_frame(current_frame_embedding[n], preset=lpre)
-            if bank is not None:  # the propagation loop matches every frame against ONE annotated frame (test.py:237-259)
+            if pre is not None:  # computed ahead of the chain (global_maps): out == mem after the fused min-merge
+                mem.view(-1).copy_(pre.reshape(-1))
+                nn_features_n = mem.view(1, h, w, n_ids, 1).clone()
+            elif bank is not None:  # the propagation loop matches every frame against ONE annotated frame (test.py:237-259)
                 nn_features_n = bank.match(fcur, normalize=bool(normalize_nearest_neighbor_distances),
                                            mem=mem).view(1, h, w, n_ids, 1)
             else:

@@ -266,6 +266,22 @@ class PreparedBank:
                                                                ctypes.byref(b)), "manet_global_match_refine_stats")
         return a.value, b.value
 
+    def refine_stats_full(self):
+        """compute='bf16r', the LAST match() on this bank (synchronises): dict with the candidate rows the filter pass
+        listed, the overflow flag, and how many of the frame's 256-query tiles went through the rescue pass (the exact fp32
+        kernel) -- `rescued_tile_fraction` is the distribution-dependent part of this mode's cost.  (The figures live in the
+        stream-shared match workspace: read them before another bf16r match runs on this stream.)"""
+        import ctypes
+        if self.compute != _lib.COMPUTE_BF16_REFINE or getattr(self, "_last", None) is None:
+            raise RuntimeError("refine_stats: no compute='bf16r' match has run on this bank")
+        ws, N = self._last
+        s4 = (ctypes.c_int64 * 4)()
+        _lib.check(_lib.load().manet_global_match_refine_stats2(ws.data_ptr(), N, self.C, self.n_ids, s4),
+                   "manet_global_match_refine_stats2")
+        return {"candidate_rows": int(s4[0]), "candidate_rows_per_pair": s4[0] / float(N * self.n_ids),
+                "list_overflowed": int(s4[1]), "rescued_tiles": int(s4[2]), "query_tiles": int(s4[3]),
+                "rescued_tile_fraction": s4[2] / float(max(1, s4[3]))}
+
 
 class PackedQuery:
     """The query operand image of ONE frame (manet_query_pack): made once per frame of a clip -- the reference

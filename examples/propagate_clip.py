@@ -5,29 +5,44 @@ Mirrors the reference driver's first interaction round (test.py:137-310): extrac
 the whole clip once, run the interaction head on the annotated frame, then propagate forwards and
 backwards frame by frame with `prop_seghead`, feeding each predicted mask to the next frame.
 No dataset, checkpoint or DAVIS session: frames and scribbles are synthetic, weights random --
-this exercises the API and measures end-to-end frames/s (matching kernels + PyTorch/MIOpen heads).
+this exercises the API and measures end-to-end frames/s (matching kernels + heads + mask step; the
+stand-in encoder runs before the timed region, as test.py:143-154 extracts a clip's embeddings up front).
 
     python examples/propagate_clip.py [--frames 16] [--objects 2] [--height 480 --width 854] [--fused-mask-step]
-                                      [--graph]
+                                      [--graph] [--pointwise f32|split|framework] [--gpus N] [--json]
 
 --graph: one propagated frame (global match against the cached PreparedBank + fused local match + head input
 assembly + DynamicSegHead + mask step) is captured ONCE in a HIP graph and replayed per frame: the host issues
 one graph launch (plus five small device copies into / out of the graph's static buffers) instead of ~21 kernel
 launches.  The masks are checked against the eager loop's.
+
+--gpus N (clip-parallel propagation, one process per GPU): what parallelises in test.py:237-259 is the
+label-INDEPENDENT half of a propagated frame -- the global match against the annotated frame (4.7 ms of a 5.3 ms
+frame at a 5-frame fp32 bank) -- while local match -> head -> argmax -> next frame's previous mask is a sequential
+chain.  So every rank extracts the embeddings of its contiguous frame block (ONE all-gather assembles the clip, once
+per clip), computes the normalised + merged global maps of its block (`IntVOS.global_maps`), ONE gather per round
+ships them ([h*w*n_ids] floats per frame) to the chain rank, and rank 0 runs the chain with
+`prop_seghead(..., global_map_precomputed=...)`.  Rank 0 also runs the plain 1-rank loop on the same embeddings and
+asserts the masks are bit-equal.
 """
 import argparse
+import hashlib
+import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 import torch.nn as nn  # noqa: E402
 
-from cvpr2020_manet_amd import ops  # noqa: E402
-from cvpr2020_manet_amd.config import make_cfg  # noqa: E402
-from cvpr2020_manet_amd.networks.IntVOS import IntVOS  # noqa: E402
+SEQ = "synthetic"
 
 
 class StandInEncoder(nn.Module):
@@ -43,111 +58,172 @@ class StandInEncoder(nn.Module):
         return self.net(x)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--frames", type=int, default=16)
-    ap.add_argument("--objects", type=int, default=2)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--width", type=int, default=854)
-    ap.add_argument("--fused-mask-step", action="store_true",
-                    help="use ops.upsample_argmax instead of F.interpolate + argmax (test.py:253-255)")
-    ap.add_argument("--graph", action="store_true", help="capture a propagated frame in a HIP graph and replay it")
-    ap.add_argument("--framework-gemm", action="store_true",
-                    help="A/B: the heads' 1x1 convolutions on the framework's GEMM (r2)")
-    ap.add_argument("--pointwise", type=str, default=None, choices=["split", "f32", "framework"],
-                    help="A/B: the heads' 1x1 convolutions on the split-bf16 MFMA kernel (default), the exact fp32-MFMA kernel, "
-                         "or the framework's GEMM")
-    ap.add_argument("--compute", type=str, default=None, help="arithmetic of the global match (f32 | bf16 | bf16x3 | bf16r)")
-    ap.add_argument("--emb-dtype", type=str, default=None, help="storage of the embeddings (f32 | bf16)")
-    ap.add_argument("--prepare-clip", action="store_true",
-                    help="prepare every frame's operands up front (model.prepare_clip) instead of on first use")
-    args = ap.parse_args()
-    assert torch.cuda.is_available(), "needs the MI355X"
-    dev = torch.device("cuda:0")
-    torch.manual_seed(0)
+def build_model(dev, compute=None, emb_dtype=None, pointwise=None, seed=0):
+    from cvpr2020_manet_amd.config import make_cfg
+    from cvpr2020_manet_amd.networks.IntVOS import IntVOS
+    torch.manual_seed(seed)
     cfg = make_cfg(["--TEST_MODE", "True"])
-    if args.framework_gemm or args.pointwise:
-        from cvpr2020_manet_amd.networks import IntVOS as _M
-        _M.MFMA_POINTWISE = False if (args.framework_gemm or args.pointwise == "framework") else args.pointwise
-    model = IntVOS(cfg, StandInEncoder(cfg.MODEL_ASPP_OUTDIM), compute=args.compute, emb_dtype=args.emb_dtype).to(dev).eval()
-    F_, H, W, nobj = args.frames, args.height, args.width, args.objects
-    seq = "synthetic"
+    model = IntVOS(cfg, StandInEncoder(cfg.MODEL_ASPP_OUTDIM), compute=compute, emb_dtype=emb_dtype,
+                   pointwise=pointwise).to(dev).eval()
+    return cfg, model
 
-    def mask_step(logits):
-        if args.fused_mask_step:
-            mask, _ = ops.upsample_argmax(logits, (H, W), want_small=False)
+
+def synthetic_clip(model, dev, n_frames, H, W, nobj, frames=None, seed=1):
+    """embeddings of the clip's frames `frames` (default: all) -- images drawn from a per-frame seed, so that every rank
+    of a clip-parallel run produces the same frame -- and the scribble of the annotated frame at grid resolution"""
+    frames = range(n_frames) if frames is None else frames
+    embs = []
+    with torch.no_grad():
+        for i in frames:
+            g = torch.Generator(device=dev).manual_seed(1000 * seed + i)
+            embs.append(model.extract_feature(torch.randn(1, 3, H, W, generator=g, device=dev)))
+    emb = torch.cat(embs, 0) if embs else None
+    return emb
+
+
+def make_scribble(dev, eh, ew, nobj):
+    scribble = torch.full((1, 1, eh, ew), -1.0, device=dev)  # -1 = unlabelled
+    scribble[0, 0, 5:9, 10:60] = 0
+    for o in range(1, nobj + 1):
+        scribble[0, 0, 20 * o:20 * o + 6, 30 * o:30 * o + 70] = o
+    return scribble
+
+
+class StageTimer:
+    """HIP-event brackets around the ops the propagated frame is made of (one instrumented round, outside any timed
+    region): per-stage microseconds per frame, each stage = the launches of one ops.* call (named by its dominant kernel)."""
+    STAGES = {"dwconv7x7_bn_relu": "head: dwconv7x7_bn_relu_kernel", "conv1x1_split": "head: conv1x1_x3_kernel",
+              "conv1x1_mfma": "head: conv1x1_mfma_kernel", "relu_conv1x1_c1": "head: relu_conv1x1_c1_kernel",
+              "local_match_frames": "local match: local_fused_kernel", "prepare_frames": "frame_prepare_kernel",
+              "head_inputs": "head_inputs_kernel", "upsample_argmax": "mask step: upsample_argmax_kernel",
+              "label_resize_nearest": "label_resize_kernel"}
+
+    def __init__(self):
+        self.records = []
+        self._saved = []
+
+    def _wrap(self, obj, attr, label):
+        fn = getattr(obj, attr)
+        timer = self
+
+        def wrapped(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            timer.records.append((label, e0, e1))
+            return r
+        self._saved.append((obj, attr, fn))
+        setattr(obj, attr, wrapped)
+
+    def __enter__(self):
+        from cvpr2020_manet_amd import ops
+        for name, label in self.STAGES.items():
+            self._wrap(ops, name, label)
+        self._wrap(ops.PreparedBank, "match", "global match: main kernel + global_finish_kernel")
+        return self
+
+    def __exit__(self, *exc):
+        for obj, attr, fn in reversed(self._saved):
+            setattr(obj, attr, fn)
+        self._saved = []
+
+    def per_frame_us(self, n_frames):
+        torch.cuda.synchronize()
+        tot, cnt = {}, {}
+        for label, e0, e1 in self.records:
+            tot[label] = tot.get(label, 0.0) + e0.elapsed_time(e1) * 1e3
+            cnt[label] = cnt.get(label, 0) + 1
+        return {k: {"us_per_frame": round(tot[k] / n_frames, 2), "calls_per_frame": round(cnt[k] / n_frames, 2)}
+                for k in sorted(tot, key=lambda k: -tot[k])}
+
+
+class Clip:
+    """a clip's embeddings + scribble + everything one interaction round needs"""
+
+    def __init__(self, cfg, model, embedding_memory, H, W, nobj, fused_mask_step=True):
+        self.cfg, self.model, self.emb = cfg, model, embedding_memory
+        self.F, _, self.eh, self.ew = embedding_memory.shape
+        self.H, self.W, self.nobj = H, W, nobj
+        self.dev = embedding_memory.device
+        self.start = self.F // 2
+        self.scribble = make_scribble(self.dev, self.eh, self.ew, nobj)
+        self.gt = torch.Tensor([nobj])
+        self.fused = fused_mask_step
+
+    def mask_step(self, logits):
+        from cvpr2020_manet_amd import ops
+        if self.fused:
+            mask, _ = ops.upsample_argmax(logits, (self.H, self.W), want_small=False)
             return mask
-        pred = nn.functional.interpolate(logits, size=(H, W), mode="bilinear", align_corners=True)
+        pred = nn.functional.interpolate(logits, size=(self.H, self.W), mode="bilinear", align_corners=True)
         return torch.argmax(pred, dim=1)
 
-    with torch.no_grad():
-        imgs = torch.randn(F_, 3, H, W, device=dev)
-        embedding_memory = torch.cat([model.extract_feature(imgs[i:i + 4]) for i in range(0, F_, 4)], 0)
-        if args.prepare_clip:
-            embedding_memory = model.prepare_clip(embedding_memory)
-        _, _, eh, ew = embedding_memory.shape
-        start = F_ // 2
-        scribble = torch.full((1, 1, eh, ew), -1.0, device=dev)  # -1 = unlabelled
-        scribble[0, 0, 5:9, 10:60] = 0
-        for o in range(1, nobj + 1):
-            scribble[0, 0, 20 * o:20 * o + 6, 30 * o:30 * o + 70] = o
-        gt = torch.Tensor([nobj])
+    def propagation_order(self):
+        return (range(self.start + 1, self.F), range(self.start - 1, -1, -1))
 
-        def one_round():
-            gmap, lmaps = {}, ({}, {})
-            ref = embedding_memory[start:start + 1]
-            tmp, lmaps = model.int_seghead(ref_frame_embedding=ref, ref_scribble_label=scribble, prev_round_label=None,
-                                           global_map_tmp_dic=gmap, local_map_dics=lmaps, interaction_num=1,
-                                           seq_names=[seq], gt_ids=gt, frame_num=[start], first_inter=True)
-            ref_label = mask_step(tmp[seq]).unsqueeze(0)
-            masks = {start: ref_label}
-            for order in (range(start + 1, F_), range(start - 1, -1, -1)):
-                prev_label, prev_emb = ref_label, ref
-                for ii in order:
-                    cur = embedding_memory[ii:ii + 1]
-                    tmp, gmap, lmaps = model.prop_seghead(ref, prev_emb, cur, scribble, prev_label,
-                                                          normalize_nearest_neighbor_distances=True,
-                                                          use_local_map=True, seq_names=[seq], gt_ids=gt,
-                                                          k_nearest_neighbors=cfg.KNNS, global_map_tmp_dic=gmap,
-                                                          local_map_dics=lmaps, interaction_num=1,
-                                                          start_annotated_frame=start, frame_num=[ii],
-                                                          dynamic_seghead=model.dynamic_seghead)
-                    prev_label = mask_step(tmp[seq]).unsqueeze(0)
-                    prev_emb = cur
-                    masks[ii] = prev_label
-            return torch.cat([masks[i][0] for i in range(F_)], 0)
+    def one_round(self, precomputed=None, keep_logits=None):
+        """test.py:208-295 for one interaction: int_seghead on the annotated frame, then the chain.  precomputed: dict
+        frame -> merged global map (IntVOS.global_maps) -- the clip-parallel form"""
+        model, cfg, start = self.model, self.cfg, self.start
+        gmap, lmaps = {}, ({}, {})
+        ref = self.emb[start:start + 1]
+        tmp, lmaps = model.int_seghead(ref_frame_embedding=ref, ref_scribble_label=self.scribble, prev_round_label=None,
+                                       global_map_tmp_dic=gmap, local_map_dics=lmaps, interaction_num=1,
+                                       seq_names=[SEQ], gt_ids=self.gt, frame_num=[start], first_inter=True)
+        ref_label = self.mask_step(tmp[SEQ]).unsqueeze(0)
+        masks = {start: ref_label}
+        pre = None if precomputed is None else {SEQ: precomputed}
+        for order in self.propagation_order():
+            prev_label, prev_emb = ref_label, ref
+            for ii in order:
+                cur = self.emb[ii:ii + 1]
+                tmp, gmap, lmaps = model.prop_seghead(ref, prev_emb, cur, self.scribble, prev_label,
+                                                      normalize_nearest_neighbor_distances=True,
+                                                      use_local_map=True, seq_names=[SEQ], gt_ids=self.gt,
+                                                      k_nearest_neighbors=cfg.KNNS, global_map_tmp_dic=gmap,
+                                                      local_map_dics=lmaps, interaction_num=1,
+                                                      start_annotated_frame=start, frame_num=[ii],
+                                                      dynamic_seghead=model.dynamic_seghead,
+                                                      global_map_precomputed=pre)
+                if keep_logits is not None:
+                    keep_logits[ii] = tmp[SEQ].clone()
+                prev_label = self.mask_step(tmp[SEQ]).unsqueeze(0)
+                prev_emb = cur
+                masks[ii] = prev_label
+        return torch.cat([masks[i][0] for i in range(self.F)], 0)
 
-        one_round()  # warm-up (MIOpen find, workspace growth)
+    def timed_round(self, precomputed_fn=None, rounds=1):
+        """warm-up round + `rounds` timed ones -> (masks, seconds per round)"""
+        self.one_round(precomputed_fn() if precomputed_fn else None)  # warm-up (MIOpen find, workspace growth)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        final = one_round()
+        for _ in range(rounds):
+            final = self.one_round(precomputed_fn() if precomputed_fn else None)
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        print("clip of %d frames at %dx%d (grid %dx%d), %d objects: %.1f ms per interaction round, %.1f frames/s "
-              "end to end (matching + heads + mask step); masks %s"
-              % (F_, H, W, eh, ew, nobj, dt * 1e3, (F_ - 1) / dt, tuple(final.shape)))
-        if not args.graph:
-            return
+        return final, (time.perf_counter() - t0) / rounds
 
-        # ---- the same round with the propagated frame captured in a HIP graph -------------------------
-        # static buffers the graph reads / writes; slot 0 of a private global-map memory stands for "this frame"
-        ref = embedding_memory[start:start + 1]
+    # ---- the same round with the propagated frame captured in a HIP graph -------------------------
+    def graph_round_fn(self):
+        model, cfg, start, dev = self.model, self.cfg, self.start, self.dev
+        ref = self.emb[start:start + 1]
         s_prev_emb, s_cur_emb = torch.empty_like(ref), torch.empty_like(ref)
-        s_prev_label = torch.zeros(1, 1, H, W, dtype=torch.int64, device=dev)
-        n_ids = nobj + 1
-        s_gmap = {seq: torch.ones(104, eh, ew, n_ids, 1, device=dev)}
+        s_prev_label = torch.zeros(1, 1, self.H, self.W, dtype=torch.int64, device=dev)
+        n_ids = self.nobj + 1
+        # static buffers the graph reads / writes; slot 0 of a private global-map memory stands for "this frame"
+        s_gmap = {SEQ: torch.ones(104, self.eh, self.ew, n_ids, 1, device=dev)}
 
         def frame_body():
-            tmp, _ = model.prop_seghead(ref, s_prev_emb, s_cur_emb, scribble, s_prev_label,
+            tmp, _ = model.prop_seghead(ref, s_prev_emb, s_cur_emb, self.scribble, s_prev_label,
                                         normalize_nearest_neighbor_distances=True, use_local_map=True,
-                                        seq_names=[seq], gt_ids=gt, k_nearest_neighbors=cfg.KNNS,
+                                        seq_names=[SEQ], gt_ids=self.gt, k_nearest_neighbors=cfg.KNNS,
                                         global_map_tmp_dic=s_gmap, local_map_dics=None, interaction_num=1,
                                         start_annotated_frame=start, frame_num=[0],
                                         dynamic_seghead=model.dynamic_seghead)
-            return mask_step(tmp[seq])
+            return self.mask_step(tmp[SEQ])
 
         side = torch.cuda.Stream()
-        s_cur_emb.copy_(embedding_memory[0:1])
+        s_cur_emb.copy_(self.emb[0:1])
         s_prev_emb.copy_(ref)
         with torch.cuda.stream(side):  # warm the per-stream workspaces and the bank cache outside the capture
             for _ in range(2):
@@ -159,36 +235,210 @@ def main():
 
         def graph_round():
             gmap = {}
-            tmp, _ = model.int_seghead(ref_frame_embedding=ref, ref_scribble_label=scribble, prev_round_label=None,
+            tmp, _ = model.int_seghead(ref_frame_embedding=ref, ref_scribble_label=self.scribble, prev_round_label=None,
                                        global_map_tmp_dic=gmap, local_map_dics=({}, {}), interaction_num=1,
-                                       seq_names=[seq], gt_ids=gt, frame_num=[start], first_inter=True)
-            ref_label = mask_step(tmp[seq]).unsqueeze(0)
+                                       seq_names=[SEQ], gt_ids=self.gt, frame_num=[start], first_inter=True)
+            ref_label = self.mask_step(tmp[SEQ]).unsqueeze(0)
             masks = {start: ref_label}
-            for order in (range(start + 1, F_), range(start - 1, -1, -1)):
+            for order in self.propagation_order():
                 prev_label, prev_emb = ref_label, ref
                 for ii in order:
-                    s_cur_emb.copy_(embedding_memory[ii:ii + 1])
+                    s_cur_emb.copy_(self.emb[ii:ii + 1])
                     s_prev_emb.copy_(prev_emb)
                     s_prev_label.copy_(prev_label)
-                    s_gmap[seq][0].copy_(gmap[seq][ii])
+                    s_gmap[SEQ][0].copy_(gmap[SEQ][ii])
                     graph.replay()
-                    gmap[seq][ii].copy_(s_gmap[seq][0])
+                    gmap[SEQ][ii].copy_(s_gmap[SEQ][0])
                     prev_label = s_mask.clone().unsqueeze(0)
-                    prev_emb = embedding_memory[ii:ii + 1]
+                    prev_emb = self.emb[ii:ii + 1]
                     masks[ii] = prev_label
-            return torch.cat([masks[i][0] for i in range(F_)], 0)
+            return torch.cat([masks[i][0] for i in range(self.F)], 0)
 
-        graph_round()
+        return graph_round
+
+
+def mask_digest(masks):
+    return hashlib.sha256(masks.to(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16]
+
+
+def run_single(args, dev, pointwise=None, want_graph=False, want_stages=False):
+    """one process, one GPU: eager (and graph) frames/s of the end-to-end propagated frame"""
+    cfg, model = build_model(dev, args.compute, args.emb_dtype, pointwise if pointwise is not None else args.pointwise)
+    with torch.no_grad():
+        emb = synthetic_clip(model, dev, args.frames, args.height, args.width, args.objects)
+        if args.prepare_clip:
+            emb = model.prepare_clip(emb)
+        clip = Clip(cfg, model, emb, args.height, args.width, args.objects, fused_mask_step=args.fused_mask_step)
+        final, dt = clip.timed_round()
+        res = {"frames": args.frames, "grid": [clip.eh, clip.ew], "objects": args.objects, "pointwise": model.pointwise,
+               "compute": model.compute, "eager_ms_per_round": dt * 1e3, "eager_frames_per_s": (args.frames - 1) / dt,
+               "mask_digest": mask_digest(final)}
+        if want_stages:
+            with StageTimer() as st:
+                clip.one_round()
+            res["per_frame_stages_us"] = st.per_frame_us(args.frames - 1)
+        if want_graph:
+            ground = clip.graph_round_fn()
+            ground()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gfinal = ground()
+            torch.cuda.synchronize()
+            gdt = time.perf_counter() - t0
+            res.update({"graph_ms_per_round": gdt * 1e3, "graph_frames_per_s": (args.frames - 1) / gdt,
+                        "graph_masks_equal_eager": bool(torch.equal(gfinal, final))})
+    return res, clip, final
+
+
+def run_parallel(args, dev, rank, world):
+    """clip-parallel propagation (module docstring): returns rank 0's result dict (None elsewhere)"""
+    from cvpr2020_manet_amd import clip_parallel as cp
+    cfg, model = build_model(dev, args.compute, args.emb_dtype, args.pointwise)
+    F_ = args.frames
+    s0, e0 = cp.shard_frames(F_, world, rank)
+    with torch.no_grad():
+        # sharded feature extraction, then ONE all-gather assembles the clip on every rank (once per clip)
+        mine = synthetic_clip(model, dev, F_, args.height, args.width, args.objects, frames=range(s0, e0))
+        if mine is None:
+            probe = synthetic_clip(model, dev, F_, args.height, args.width, args.objects, frames=[0])
+            mine = probe[:0]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        gfinal = graph_round()
+        emb = cp.all_gather_clip(mine, F_)
         torch.cuda.synchronize()
-        gdt = time.perf_counter() - t0
-        same = bool(torch.equal(gfinal, final))
-        print("HIP-graph replay of the propagated frame: %.1f ms per round, %.1f frames/s (eager %.1f); masks %s the "
-              "eager loop's; host work per frame: 1 graph launch + 5 small copies instead of one launch per kernel"
-              % (gdt * 1e3, (F_ - 1) / gdt, (F_ - 1) / dt, "identical to" if same else "DIFFER from"))
-        assert same, "graph replay changed the masks"
+        clip_gather_ms = (time.perf_counter() - t0) * 1e3
+        clip = Clip(cfg, model, emb, args.height, args.width, args.objects, fused_mask_step=args.fused_mask_step)
+        start = clip.start
+        ref = emb[start:start + 1]
+        my_frames = [f for f in range(s0, e0)]
+        L = clip.eh * clip.ew * (args.objects + 1)
+        timing = {}
+
+        def maps_for_round():
+            """this rank's block -> normalised + merged global maps; ONE gather ships every rank's to rank 0"""
+            t1 = time.perf_counter()
+            if my_frames:
+                rows = model.global_maps(ref, clip.scribble, emb[s0:e0], my_frames, SEQ, clip.gt)
+            else:
+                rows = torch.empty((0, L), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            timing["global_maps_ms"] = (time.perf_counter() - t1) * 1e3
+            allrows = cp.gather_frame_rows(rows, F_, dst=0, timing=True)
+            timing["gather"] = dict(cp.LAST_GATHER)
+            if rank != 0:
+                return None
+            return {f: allrows[f] for f in range(F_) if f != start}
+
+        def one_parallel_round():
+            pre = maps_for_round()
+            return clip.one_round(pre) if rank == 0 else None
+
+        one_parallel_round()  # warm-up
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        final = one_parallel_round()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        if rank != 0:
+            return None
+        # the plain 1-rank loop on the same embeddings: the masks must be the same bits
+        want, dt1 = clip.timed_round()
+        same = bool(torch.equal(final, want))
+        return {"frames": F_, "world": world, "backend": dist.get_backend(), "pointwise": model.pointwise,
+                "compute": model.compute, "parallel_ms_per_round": dt * 1e3, "parallel_frames_per_s": (F_ - 1) / dt,
+                "single_rank_ms_per_round": dt1 * 1e3, "single_rank_frames_per_s": (F_ - 1) / dt1,
+                "masks_bit_equal_to_single_rank": same, "mask_digest": mask_digest(final),
+                "clip_all_gather_ms": clip_gather_ms, "rank0_global_maps_ms": timing.get("global_maps_ms"),
+                "collective": timing.get("gather")}
+
+
+def spawn_ranks(n, argv):
+    """start the N ranks (one process per GPU, torch.distributed.run, rendezvous on 127.0.0.1) before anything in this
+    process touches the GPU, relay the output, pass the exit code on"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--objects", type=int, default=2)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=854)
+    ap.add_argument("--fused-mask-step", action="store_true",
+                    help="use ops.upsample_argmax instead of F.interpolate + argmax (test.py:253-255)")
+    ap.add_argument("--graph", action="store_true", help="capture a propagated frame in a HIP graph and replay it")
+    ap.add_argument("--pointwise", type=str, default=None, choices=["split", "f32", "framework"],
+                    help="the heads' 1x1 convolutions: exact fp32-MFMA kernel (default), the split-bf16 MFMA kernel, or the "
+                         "framework's GEMM")
+    ap.add_argument("--compute", type=str, default=None, help="arithmetic of the global match (f32 | bf16 | bf16x3 | bf16r)")
+    ap.add_argument("--emb-dtype", type=str, default=None, help="storage of the embeddings (f32 | bf16)")
+    ap.add_argument("--prepare-clip", action="store_true",
+                    help="prepare every frame's operands up front (model.prepare_clip) instead of on first use")
+    ap.add_argument("--stages", action="store_true", help="per-stage microseconds of a propagated frame (HIP events)")
+    ap.add_argument("--gpus", type=int, default=1, help="clip-parallel propagation over N ranks (module docstring)")
+    ap.add_argument("--json", action="store_true", help="print the result as one JSON line")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    backend = os.environ.get("MANET_BENCH_BACKEND", "nccl")  # gloo: dry run of the N-rank flow on fewer GPUs than ranks
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("propagate_clip.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    assert torch.cuda.is_available(), "needs the MI355X"
+    n_dev = torch.cuda.device_count()
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % n_dev)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        res = run_parallel(args, dev, rank, world)
+        dist.destroy_process_group()
+        if rank == 0:
+            if args.json:
+                print(json.dumps(res), flush=True)
+            else:
+                print("clip-parallel propagation, %d ranks (%s): %.1f ms per round = %.1f frames/s (1 rank on the same "
+                      "embeddings: %.1f); masks %s the 1-rank loop's; gather of the round's global maps: %s"
+                      % (world, res["backend"], res["parallel_ms_per_round"], res["parallel_frames_per_s"],
+                         res["single_rank_frames_per_s"],
+                         "bit-equal to" if res["masks_bit_equal_to_single_rank"] else "DIFFER from", res["collective"]))
+            assert res["masks_bit_equal_to_single_rank"], "clip-parallel propagation changed the masks"
+        return
+    res, clip, final = run_single(args, dev, want_graph=args.graph, want_stages=args.stages)
+    if args.json:
+        print(json.dumps(res), flush=True)
+    else:
+        print("clip of %d frames at %dx%d (grid %dx%d), %d objects, head 1x1 = %s: %.1f ms per interaction round, %.1f "
+              "frames/s end to end (matching + heads + mask step); masks %s"
+              % (args.frames, args.height, args.width, clip.eh, clip.ew, args.objects, res["pointwise"],
+                 res["eager_ms_per_round"], res["eager_frames_per_s"], tuple(final.shape)))
+        if args.stages:
+            for k, v in res["per_frame_stages_us"].items():
+                print("  %-55s %8.1f us per frame (%.1f calls)" % (k, v["us_per_frame"], v["calls_per_frame"]))
+        if args.graph:
+            print("HIP-graph replay of the propagated frame: %.1f ms per round, %.1f frames/s (eager %.1f); masks %s the "
+                  "eager loop's; host work per frame: 1 graph launch + 5 small copies instead of one launch per kernel"
+                  % (res["graph_ms_per_round"], res["graph_frames_per_s"], res["eager_frames_per_s"],
+                     "identical to" if res["graph_masks_equal_eager"] else "DIFFER from"))
+    if args.graph:
+        assert res["graph_masks_equal_eager"], "graph replay changed the masks"
 
 
 if __name__ == "__main__":

@@ -60,7 +60,7 @@ typedef void *manet_stream_t; /* a hipStream_t */
 #define MANET_COMPUTE_BF16 1    /* v_mfma_f32_32x32x16_bf16 on inputs rounded to bf16, fp32 accumulate */
 #define MANET_COMPUTE_BF16X3 2  /* split-bf16 (hi+lo, 3 MFMAs): fp32-class accuracy at bf16 rate */
 /* bf16 filter + exact fp32 re-rank (k_nn = 1, C <= 106): IntVOS.py:81-85 is a minimum, so a filter that provably keeps the
- * arg-min row may drop every other one.  A bf16 pre-pass over a quarter of the bank bounds the minimum, a bf16 pass over
+ * arg-min row may drop every other one.  A bf16 pre-pass over every 8th bank tile bounds the minimum, a bf16 pass over
  * the whole bank keeps the rows whose bf16 distance is within the rounding bound of that, and those few are re-evaluated in
  * the reference's fp32 arithmetic (the fmaf chains of MANET_COMPUTE_F32): the result EQUALS MANET_COMPUTE_F32's bit for bit
  * at about 1.4x the cost of MANET_COMPUTE_BF16.  (NaN embeddings: unsupported in this mode.) */
@@ -186,6 +186,10 @@ int manet_global_match_refine(const void *query, int emb_dtype, int64_t q_stride
                               manet_stream_t stream);
 int manet_global_match_refine_stats(const void *match_ws, int64_t N, int C, int n_ids, int64_t *candidates,
                                     int64_t *list_overflowed);
+/* ... and in full (blocking copies; benchmarks): stats4[0] = qualifying rows, [1] = the flag above, [2] = 256-query tiles
+ * that went through the rescue pass, [3] = 256-query tiles of the frame -- [2] / [3] is the share of the frame that cost the
+ * fp32 kernel's time ON TOP of the filter pass (distribution-dependent: 0 on embeddings the bf16 pass can tell apart). */
+int manet_global_match_refine_stats2(const void *match_ws, int64_t N, int C, int n_ids, int64_t *stats4);
 
 /* Stand-alone normalise / min-merge (IntVOS.py:611-622, :718-723), in place on x[n]
  * (and on mem_inout[n] when not NULL). */

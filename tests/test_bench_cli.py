@@ -70,3 +70,56 @@ def test_mismatched_world_size_is_an_error():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)
+
+
+def _run_json(cmd, env, timeout=900):
+    import json
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,frames", [(2, 9), (3, 5)])
+def test_clip_parallel_propagation_masks_bit_equal_to_one_rank(world, frames):
+    """the multi-GPU split that speeds up what test.py does.  N ranks (sharing the one GPU here, gloo)
+    extract the embeddings of their frame blocks (one all-gather assembles the clip), compute the normalised + merged global
+    maps of their blocks, ONE gather ships them to rank 0, rank 0 runs local match -> head -> mask sequentially; rank 0 also
+    runs the plain 1-rank loop on the same embeddings: the masks must be the same bits."""
+    env = dict(os.environ, MANET_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    res = _run_json([sys.executable, os.path.join(ROOT, "examples", "propagate_clip.py"), "--gpus", str(world), "--frames",
+                     str(frames), "--fused-mask-step", "--json"], env)
+    assert res["world"] == world and res["frames"] == frames and res["backend"] == "gloo"
+    assert res["masks_bit_equal_to_single_rank"] is True
+    col = res["collective"]
+    L = 120 * 214 * 3
+    assert col["world"] == world and col["dst"] == 0 and col["slab_bytes"] == -(-frames // world) * L * 4
+    assert res["parallel_frames_per_s"] > 0 and res["single_rank_frames_per_s"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_e2e_line_two_ranks_on_one_gpu():
+    """`bench.py --e2e --gpus 2`: the clip-parallel propagation as a bench line (strong scaling over a fixed clip), with the
+    `collective` echo of the round's gather"""
+    env = dict(os.environ, MANET_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    line = _run_json([sys.executable, os.path.join(ROOT, "bench.py"), "--e2e", "--gpus", "2", "--e2e-frames", "9"], env)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["unit"] == "frames/s"
+    assert line["collective"]["world"] == 2 and line["e2e_parallel"]["masks_bit_equal_to_single_rank"] is True
+    line1 = _run_json([sys.executable, os.path.join(ROOT, "bench.py"), "--e2e", "--e2e-frames", "9"], env)
+    assert line1["n_gpus"] == 1 and line1["collective"] is None and line1["value"] > 0
+
+
+def test_e2e_flag_needs_a_gpu_and_spawns():
+    env = dict(os.environ, MANET_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--e2e", "--gpus", "2", "--e2e-frames", "5"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and (r.stdout + r.stderr).count("bench.py needs an MI355X") == 2

@@ -114,3 +114,51 @@ def test_exchange_bank_and_halo_gloo(world, F, bank, bf16, ownership):
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(world))
     assert res == [(r, True) for r in range(world)]
+
+
+def _worker_gather(rank, world, port, F, bf16, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        C, h, w = 5, 6, 7
+        emb, _ = _clip(F, C, h, w)
+        if bf16:
+            emb = emb.bfloat16()
+        s, e = cp.shard_frames(F, world, rank)
+        # the clip assembled from the ranks' frame blocks (SURVEY 8e's all-gather after sharded feature extraction)
+        clip = cp.all_gather_clip(emb[s:e].clone(), F)
+        ok = clip.dtype == emb.dtype and torch.equal(clip, emb)
+        # the per-round gather of per-frame rows (the global maps of the clip-parallel propagation) to the chain rank
+        L = 11
+        rows = torch.arange(F * L, dtype=torch.float32).view(F, L) * 0.5 - 3.0
+        got = cp.gather_frame_rows(rows[s:e].clone(), F, dst=0, timing=True)
+        info = cp.LAST_GATHER
+        ok = ok and info["world"] == world and info["backend"] == "gloo" and info["slab_bytes"] == -(-F // world) * L * 4
+        if rank == 0:
+            ok = ok and got is not None and torch.equal(got, rows) and info["gather_ms"] is not None
+        else:
+            ok = ok and got is None
+        try:  # a block of the wrong size is an error, not a silent mis-assembly
+            cp.gather_frame_rows(rows[:e - s + 1].clone(), F, dst=0)
+            ok = False
+        except ValueError:
+            pass
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,F,bf16", [(2, 8, False), (3, 7, True), (3, 2, False)])
+def test_all_gather_clip_and_gather_frame_rows_gloo(world, F, bf16):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_gather, args=(r, world, port, F, bf16, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert res == [(r, True) for r in range(world)]

@@ -299,10 +299,13 @@ def test_cfg_defaults_equal_reference():
     from conftest import GOLDEN
     from cvpr2020_manet_amd.config import make_cfg
     ref = json.load(open(os.path.join(GOLDEN, "config_defaults.json")))
-    # (MODEL_MATCH_COMPUTE / MODEL_EMB_DTYPE are this implementation's two extension flags, absent from the reference)
-    mine = {k: v for k, v in vars(make_cfg([])).items() if k not in ("ROOT_DIR", "MODEL_MATCH_COMPUTE", "MODEL_EMB_DTYPE")}
+    # (MODEL_MATCH_COMPUTE / MODEL_EMB_DTYPE / MODEL_HEAD_POINTWISE / MODEL_CACHE_FRAMES are this implementation's
+    # extension flags, absent from the reference)
+    ext = ("MODEL_MATCH_COMPUTE", "MODEL_EMB_DTYPE", "MODEL_HEAD_POINTWISE", "MODEL_CACHE_FRAMES")
+    mine = {k: v for k, v in vars(make_cfg([])).items() if k != "ROOT_DIR" and k not in ext}
     assert mine == ref
     assert make_cfg([]).MODEL_MATCH_COMPUTE == "f32" and make_cfg([]).MODEL_EMB_DTYPE == "f32"
+    assert make_cfg([]).MODEL_HEAD_POINTWISE == "f32" and make_cfg([]).MODEL_CACHE_FRAMES is True  # exact head by default
     assert make_cfg(["--TEST_MODE", "True", "--unknown-flag", "1"]).TEST_MODE is True
 
 
@@ -320,8 +323,17 @@ def test_constructor_switches_and_cache_hooks_on_cpu():
     m = M.IntVOS(cfg, TinyExtractor())
     assert m.compute == "bf16x3" and m.emb_dtype == torch.bfloat16
     ref_cfg = argparse.Namespace(**{k: v for k, v in vars(tiny_cfg()).items()
-                                    if k not in ("MODEL_MATCH_COMPUTE", "MODEL_EMB_DTYPE")})
-    assert M.IntVOS(ref_cfg, TinyExtractor()).compute == "f32"  # a reference cfg object without the extension flags
+                                    if k not in ("MODEL_MATCH_COMPUTE", "MODEL_EMB_DTYPE", "MODEL_HEAD_POINTWISE",
+                                                 "MODEL_CACHE_FRAMES")})
+    mref = M.IntVOS(ref_cfg, TinyExtractor())  # a reference cfg object without the extension flags
+    assert mref.compute == "f32" and mref.pointwise == "f32" and mref.cache_frames is True
+    # the heads' 1x1 arithmetic is per model: two models in one process may differ, exact fp32 by default
+    ma, mb = M.IntVOS(tiny_cfg(), TinyExtractor()), M.IntVOS(tiny_cfg(), TinyExtractor(), pointwise="split")
+    assert M._pointwise_mode(ma.dynamic_seghead.layer2) == "f32" and M._pointwise_mode(mb.dynamic_seghead.layer2) == "split"
+    assert M._pointwise_mode(M._split_separable_conv2d(4, 4)) == "f32"  # a stand-alone block: the module default
+    assert M.IntVOS(tiny_cfg(), TinyExtractor(), cache_frames=False).cache_frames is False
+    with pytest.raises(ValueError):
+        M.IntVOS(tiny_cfg(), TinyExtractor(), pointwise="fp8")
     with pytest.raises(ValueError):
         M.IntVOS(tiny_cfg(), TinyExtractor(), compute="fp8")
     with pytest.raises(ValueError):
