@@ -13,7 +13,7 @@ python bench.py > gpurun_out/$R/${R}_bench_line.json 2> gpurun_out/$R/${R}_bench
 for c in "2 f32 auto" "3 bf16 auto" "5 bf16 auto" "3 bf16r f32" "2 bf16r f32"; do
   set -- $c
   tag=${R}_cfg$1_$2
-  tools/profile_gpu.sh ${R}/$tag --cfg $1 --compute $2 --emb $3 --steps 20 --no-also > gpurun_out/$R/${tag}_profile.log 2>&1
+  tools/profile_gpu.sh ${R}/$tag --cfg $1 --compute $2 --emb $3 --steps 20 --no-also --no-robustness --no-e2e > gpurun_out/$R/${tag}_profile.log 2>&1
   cp gpurun_out/${R}/$tag/pmc_summary.csv gpurun_out/$R/${tag}_pmc_summary.csv
   cp $(find gpurun_out/${R}/$tag/stats -name "*kernel_stats.csv" | head -1) gpurun_out/$R/${tag}_kernel_stats.csv
   cp gpurun_out/${R}/$tag/bench_line_under_rocprof.json gpurun_out/$R/${tag}_bench_line_under_rocprof.json
