@@ -141,21 +141,30 @@ def exchange_bank_and_halo(local_embeddings, local_start, bank_frames, bank_labe
     slab = torch.cat(parts)
     assert slab.numel() == slab_b
 
-    if timing:
+    ag_ms, ag_clock = None, None
+    device_events = timing and slab.is_cuda and dist.get_backend(group) != "gloo"
+    if device_events:
+        # RCCL: the collective runs on the backend's own stream, which this stream waits on -- two events on THIS stream
+        # bracket it on the device's clock (host wall time around two device syncs also counted the syncs' latency)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    elif timing:
         if slab.is_cuda:
             torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
     gathered = _all_gather_flat(slab, world, group).view(world, slab_b)
-    if timing:
+    if device_events:
+        e1.record()
+        e1.synchronize()
+        ag_ms, ag_clock = e0.elapsed_time(e1), "device events"
+    elif timing:
         if slab.is_cuda:
             torch.cuda.synchronize(dev)
-        ag_ms = (time.perf_counter() - t0) * 1e3
-    else:
-        ag_ms = None
+        ag_ms, ag_clock = (time.perf_counter() - t0) * 1e3, "host wall time (staged through host memory)" if slab.is_cuda else "host wall time"
     LAST_EXCHANGE.clear()
     LAST_EXCHANGE.update({"backend": dist.get_backend(group), "world": world, "slab_bytes": int(slab_b),
                           "gathered_bytes": int(world * slab_b), "bank_slots_per_rank": int(slots),
-                          "ownership": ownership, "allgather_ms": ag_ms})
+                          "ownership": ownership, "allgather_ms": ag_ms, "allgather_clock": ag_clock})
 
     # bank frames in ascending frame order: one index_select over the [world * slots] slot rows of the gathered
     # buffer (rank stride slab_b, slot stride frame_b / lab_b) -- no per-frame Python copies

@@ -793,8 +793,10 @@ __device__ __forceinline__ void topk_insert(float (&m)[K], float d)
 // ARG (with KNN = 1): also track WHICH bank row attains the minimum (training: the gradient of torch.min flows to
 //          that row only, IntVOS.py:84); splits meet through a 64-bit atomicMin on (distance key << 32 | bank slot)
 //          in `keys64` -- equal distances resolve to the smallest slot, i.e. the first row in the sorted bank.
+// (KS = 64 -- C in 105..128 -- with the top-k lists or the arg-min slots does not fit 256 VGPRs: those two forms take one
+// workgroup per CU instead of spilling)
 template <int KS, int KNN, bool ARG = false>
-__global__ __launch_bounds__(256, 2) void global_match_f32_kernel(const char *__restrict__ qpack,
+__global__ __launch_bounds__(256, (KS == 64 && (KNN > 1 || ARG)) ? 1 : 2) void global_match_f32_kernel(const char *__restrict__ qpack,
                                                                   const char *__restrict__ bpack,
                                                                   const int *__restrict__ meta,
                                                                   int n_ids, int nQT, int S,
@@ -2438,48 +2440,60 @@ template <int KSB, bool X3>
 void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S, long N_pad,
                       unsigned *keys, hipStream_t st, int prof_channel = 0)
 {
+#ifdef MANET_ABLATION
     const int v = manet_tune_get(MANET_TUNE_BF16_VARIANT, 0);
-    const int tps = v & 3, reg = (v >> 2) & 1, flat = (v >> 4) & 1;
+#else
+    const int v = 0;  // (the default build carries the shipped kernels only: make EXTRA=-DMANET_ABLATION for the rest)
+#endif
+    const int flat = (v >> 4) & 1;
     int prio = (v >> 3) & 1;
-    if (!X3 && !flat) {  // plain-bf16 kernels: software-pipelined fragments, barrier in front of the step's last pass
-        // the 8-wave 64x64-wave-tile form: tuning, and KSB = 9 (C > 106), whose 144 operand VGPRs do not fit the wide form
-        const int narrow = ((v >> 6) & 1) || KSB == 9;
-        const int abl = KSB == 7 ? manet_tune_get(MANET_TUNE_ABLATION, 0) : 0;  // timing experiments only
-        const void *fn = nullptr;
-        unsigned threads = 512;
-        size_t lds = (size_t)2 * 2 * bank_tile_bytes_u(2 * KSB, false);
-        if (narrow) {
+    if constexpr (!X3) {
+        if (!flat) {  // plain-bf16 kernels: software-pipelined fragments, barrier in front of the step's last pass
+            // the 8-wave 64x64-wave-tile form: KSB = 9 (C > 106), whose 144 operand VGPRs do not fit the wide form; tuning
+            constexpr bool NARROW_ONLY = (KSB == 9);
+            const bool narrow = NARROW_ONLY || ((v >> 6) & 1);
+            const void *fn = nullptr;
+#ifdef MANET_ABLATION
+            const int abl = KSB == 7 ? manet_tune_get(MANET_TUNE_ABLATION, 0) : 0;  // timing experiments only
+            if (narrow) {
 #define MANET_PK(AB_) \
     if (abl == AB_) fn = (const void *)global_match_bf16_pipe_kernel<KSB, (KSB == 7 ? AB_ : 0)>;
-            MANET_PK(0) MANET_PK(1) MANET_PK(2) MANET_PK(4) MANET_PK(8) MANET_PK(15)
+                MANET_PK(0) MANET_PK(1) MANET_PK(2) MANET_PK(4) MANET_PK(8) MANET_PK(15)
 #undef MANET_PK
-            if (!fn) fn = (const void *)global_match_bf16_pipe_kernel<KSB, 0>;
-        } else {
-            threads = 256;
-            lds = (size_t)2 * 2 * bank_tile_bytes_u(2 * KSB, false);
+                if (!fn) fn = (const void *)global_match_bf16_pipe_kernel<KSB, 0>;
+            } else if constexpr (!NARROW_ONLY) {
 #define MANET_WK(AB_) \
     if (abl == AB_) fn = (const void *)global_match_bf16_wide_kernel<KSB, (KSB == 7 ? AB_ : 0)>;
-            MANET_WK(0) MANET_WK(1) MANET_WK(2) MANET_WK(4) MANET_WK(8) MANET_WK(15)
+                MANET_WK(0) MANET_WK(1) MANET_WK(2) MANET_WK(4) MANET_WK(8) MANET_WK(15)
 #undef MANET_WK
-            if (!fn) fn = (const void *)global_match_bf16_wide_kernel<KSB, 0>;
+                if (!fn) fn = (const void *)global_match_bf16_wide_kernel<KSB, 0>;
+            }
+#else
+            if constexpr (NARROW_ONLY) fn = (const void *)global_match_bf16_pipe_kernel<KSB, 0>;
+            else fn = (const void *)global_match_bf16_wide_kernel<KSB, 0>;
+#endif
+            const unsigned threads = narrow ? 512 : 256;
+            const size_t lds = (size_t)2 * 2 * bank_tile_bytes_u(2 * KSB, false);
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            int bm = block_map_arg(nQT, narrow ? 256 : 512, S);
+            unsigned *no_thr = nullptr;
+            const float *no_slack = nullptr;
+            unsigned long long *no_stats = nullptr;
+            uint2 *no_list = nullptr;
+            unsigned *no_bcnt = nullptr;
+            long no_cap = 0;
+            // (the narrow kernel takes the first ten arguments; the wide one also the FILTER form's five, unused here)
+            void *args[] = {(void *)&qpack, (void *)&bpack, (void *)&meta, (void *)&n_ids, (void *)&nQT, (void *)&S,
+                            (void *)&N_pad, (void *)&keys, (void *)&bm, (void *)&prio, (void *)&no_thr, (void *)&no_slack,
+                            (void *)&no_stats, (void *)&no_list, (void *)&no_cap, (void *)&no_bcnt};
+            manet_profile_record(st, true, prof_channel);
+            (void)hipLaunchKernel(fn, dim3((unsigned)(nQT * S)), dim3(threads), args, lds, st);
+            manet_profile_record(st, false, prof_channel);
+            return;
         }
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        int bm = block_map_arg(nQT, narrow ? 256 : 512, S);
-        unsigned *no_thr = nullptr;
-        const float *no_slack = nullptr;
-        unsigned long long *no_stats = nullptr;
-        uint2 *no_list = nullptr;
-        unsigned *no_bcnt = nullptr;
-        long no_cap = 0;
-        // (the narrow kernel takes the first ten arguments; the wide one also the FILTER form's five, unused here)
-        void *args[] = {(void *)&qpack, (void *)&bpack, (void *)&meta, (void *)&n_ids, (void *)&nQT, (void *)&S,
-                        (void *)&N_pad, (void *)&keys, (void *)&bm, (void *)&prio, (void *)&no_thr, (void *)&no_slack,
-                        (void *)&no_stats, (void *)&no_list, (void *)&no_cap, (void *)&no_bcnt};
-        manet_profile_record(st, true, prof_channel);
-        (void)hipLaunchKernel(fn, dim3((unsigned)(nQT * S)), dim3(threads), args, lds, st);
-        manet_profile_record(st, false, prof_channel);
-        return;
     }
+#ifdef MANET_ABLATION
+    const int tps = v & 3, reg = (v >> 2) & 1;
 #define MANET_BV(TPS_)                                                                                         \
     if (reg) launch_main_bf16_v<KSB, X3, TPS_, false>(qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, prio, st); \
     else launch_main_bf16_v<KSB, X3, TPS_, true>(qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, prio, st);
@@ -2487,6 +2501,10 @@ void launch_main_bf16(const char *qpack, const char *bpack, const int *meta, int
     else if (tps == 2) { MANET_BV((X3 ? 2 : 4)) }
     else { MANET_BV((X3 ? 1 : 2)) }
 #undef MANET_BV
+#else
+    // split-bf16: global_match_bf16_kernel<KSB, true, 1, true> (1 tile per step, asm LDS-DMA staging)
+    if constexpr (X3) launch_main_bf16_v<KSB, true, 1, true>(qpack, bpack, meta, n_ids, nQT, S, N_pad, keys, prio, st);
+#endif
 }
 
 // MANET_COMPUTE_BF16_REFINE on a prepared bank (see the kernels' header comment).  `qimg` = the query's bf16 operand
@@ -2516,12 +2534,14 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
         const size_t lds = (size_t)2 * 2 * bank_tile_bytes_u(2 * ML.G.steps, false) + (size_t)REFINE_LDS_LIST * 8 + 4 * 256 * 4;  // + the published keys
         const void *fn = ML.G.steps == 2 ? (const void *)global_match_bf16_wide_kernel<2, 0, true>
                                          : (const void *)global_match_bf16_wide_kernel<7, 0, true>;
+#ifdef MANET_ABLATION
         if (ML.G.steps != 2) {  // timing experiments only (results are wrong): 16 no slow path, 32 no threshold exchange
             const int fabl = manet_tune_get(MANET_TUNE_ABLATION, 0);
             if (fabl == 16) fn = (const void *)global_match_bf16_wide_kernel<7, 16, true>;
             if (fabl == 32) fn = (const void *)global_match_bf16_wide_kernel<7, 32, true>;
             if (fabl == 48) fn = (const void *)global_match_bf16_wide_kernel<7, 48, true>;
         }
+#endif
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const char *bpack = bws + BL.off_pack;
         int nQT = ML.nQT, Sv = S, bm = block_map_arg(ML.nQT, 512), prio = 0;
@@ -2640,7 +2660,11 @@ int manet_frame_prepare(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y
     if (fill_words < 0 || (fill_words > 0 && !fill_ptr)) return manet_set_error(MANET_E_INVALID, "bad fill request");
     const ManetFrameLayout F = manet_frame_layout(h, w, C, compute, max_distance);
     const Geom G = geom_of(C, compute);
+#ifdef MANET_ABLATION
     const int XC = manet_tune_get(MANET_TUNE_FRAME_XC, 0) == 1 ? 64 : 32;  // (tuning: 64-column workgroups)
+#else
+    const int XC = 32;
+#endif
     FramePrep A;
     A.emb = emb;
     A.s_f = (long)s_f; A.s_y = (long)s_y; A.s_x = (long)s_x; A.s_c = (long)s_c;
@@ -2663,10 +2687,13 @@ int manet_frame_prepare(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y
     hipStream_t st = (hipStream_t)stream;
     if (emb_dtype != MANET_EMB_F32 && emb_dtype != MANET_EMB_BF16)
         return manet_set_error(MANET_E_INVALID, "embedding dtype %d (MANET_EMB_F32 / MANET_EMB_BF16)", emb_dtype);
-    const void *fn = emb_dtype == MANET_EMB_F32
-                         ? (XC == 64 ? (const void *)frame_prepare_kernel<float, 64> : (const void *)frame_prepare_kernel<float, 32>)
-                         : (XC == 64 ? (const void *)frame_prepare_kernel<unsigned short, 64>
-                                     : (const void *)frame_prepare_kernel<unsigned short, 32>);
+    const void *fn = emb_dtype == MANET_EMB_F32 ? (const void *)frame_prepare_kernel<float, 32>
+                                                : (const void *)frame_prepare_kernel<unsigned short, 32>;
+#ifdef MANET_ABLATION
+    if (XC == 64)
+        fn = emb_dtype == MANET_EMB_F32 ? (const void *)frame_prepare_kernel<float, 64>
+                                        : (const void *)frame_prepare_kernel<unsigned short, 64>;
+#endif
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     void *args[] = {(void *)&A};
     manet_profile_record(st, true, 2);
@@ -2839,7 +2866,11 @@ int manet_global_match_prepared_ex(const void *query, int emb_dtype, int64_t q_s
     }
     // resident workgroup slots: f32 and plain bf16 (wide kernel) = 2 x 256-thread workgroups per CU,
     // split-bf16 (and the tuning-only narrow/flat bf16 forms) = 1 x 512-thread workgroup per CU
+#ifdef MANET_ABLATION
     const int bv = manet_tune_get(MANET_TUNE_BF16_VARIANT, 0);
+#else
+    const int bv = 0;
+#endif
     const bool two_per_cu = compute == MANET_COMPUTE_F32 ||
                             (compute == MANET_COMPUTE_BF16 && !(bv & (16 | 64)) && ML.G.steps != 9);
     int S = pick_splits(ML.nQT, BL.T_max, two_per_cu ? 512 : 256);
@@ -2872,22 +2903,29 @@ int manet_global_match_prepared_ex(const void *query, int emb_dtype, int64_t q_s
         }
 #undef MANET_GB_CASE
     } else {
+#ifdef MANET_ABLATION
         const bool pipe = !manet_tune_get(MANET_TUNE_F32_UNPIPED, 0);  // tuning: 1 = the un-pipelined k = 1 kernel
+#define MANET_GM_UNPIPED(KS_) launch_main_f32<KS_, 1>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st)
+#else
+        const bool pipe = true;
+#define MANET_GM_UNPIPED(KS_) (void)0
+#endif
 #define MANET_GM_CASE(KS_)                                                                                    \
     case KS_:                                                                                                 \
         if (k_nn == 1 && pipe) launch_main_f32_pipe<KS_>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st); \
-        else if (k_nn == 1) launch_main_f32<KS_, 1>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st); \
+        else if (k_nn == 1) MANET_GM_UNPIPED(KS_);                                                            \
         else launch_main_f32<KS_, MANET_MAX_KNN>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st); \
         break;
     switch (pick_ks(C)) {
         MANET_GM_CASE(16) MANET_GM_CASE(50) MANET_GM_CASE(52)
     default:
         if (k_nn == 1 && pipe) launch_main_f32_pipe<64>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, st);
-        else if (k_nn == 1) launch_main_f32<64, 1>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st);
+        else if (k_nn == 1) MANET_GM_UNPIPED(64);
         else launch_main_f32<64, MANET_MAX_KNN>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, keys, topk, st);
         break;
     }
 #undef MANET_GM_CASE
+#undef MANET_GM_UNPIPED
     }
     long total = (long)(armed ? ML.N_pad : N) * n_ids;
     if (k_nn == 1)

@@ -53,6 +53,13 @@ int manet_tune_set(int key, int value)
     if (!opt || opt[0] != '1')
         return manet_set_error(MANET_E_INVALID, "manet_tune_set is for experiments: set MANET_TUNING=1 in the environment");
     if (key < 0 || key >= MANET_TUNE_COUNT) return manet_set_error(MANET_E_INVALID, "tune key %d", key);
+#ifndef MANET_ABLATION
+    // the default build carries only the kernels the data path can reach; the variant / ablation instantiations these keys
+    // select are compiled in by `make EXTRA=-DMANET_ABLATION`
+    if (key == MANET_TUNE_BF16_VARIANT || key == MANET_TUNE_ABLATION || key == MANET_TUNE_F32_UNPIPED || key == MANET_TUNE_FRAME_XC)
+        return manet_set_error(MANET_E_INVALID, "tune key %d selects kernel variants this library was built without: rebuild "
+                                                "with `make -C cvpr2020_manet_amd/csrc clean all EXTRA=-DMANET_ABLATION`", key);
+#endif
     g_tune[key] = value;
     g_tune_set[key] = value != INT32_MIN;  // INT32_MIN: back to "not set" (the shipped default, e.g. the automatic block map)
     return MANET_OK;

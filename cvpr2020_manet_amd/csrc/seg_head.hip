@@ -624,12 +624,16 @@ extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, 
     hipLaunchKernelGGL((dwconv7x7_bn_relu_kernel<F_, A_>), grid, dim3(256), 0, (hipStream_t)stream, in, B, C, h, w, weight, bias, \
                        bn_scale, bn_shift, relu, relu_in, out)
     if (w % 2 == 0 && w >= 2 && ((size_t)in & 7) == 0 && ((size_t)out & 7) == 0) {
+#ifdef MANET_ABLATION
         switch (manet_tune_get(MANET_TUNE_ABLATION, 0)) {  // timing experiments only (tools/pw_bench.py --dw)
         case 1: DW_LAUNCH(true, 1); break;
         case 2: DW_LAUNCH(true, 2); break;
         case 3: DW_LAUNCH(true, 3); break;
         default: DW_LAUNCH(true, 0);
         }
+#else
+        DW_LAUNCH(true, 0);
+#endif
     } else
         DW_LAUNCH(false, 0);
 #undef DW_LAUNCH
@@ -691,6 +695,7 @@ extern "C" int manet_conv1x1_x3_f32(const float *in, int64_t in_batch_stride, in
 #define X3_LAUNCH(A_)                                                                                                        \
     hipLaunchKernelGGL(conv1x1_x3_kernel<A_>, grid, dim3(X3_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin, (long)HW, \
                        (const char *)wpk, b2, add, relu_out, out, head_w, head_b, head_out)
+#ifdef MANET_ABLATION
     switch (manet_tune_get(MANET_TUNE_ABLATION, 0)) {  // timing experiments only (tools/pw_bench.py)
     case 1: X3_LAUNCH(1); break;
     case 2: X3_LAUNCH(2); break;
@@ -703,6 +708,9 @@ extern "C" int manet_conv1x1_x3_f32(const float *in, int64_t in_batch_stride, in
     case 25: X3_LAUNCH(25); break;
     default: X3_LAUNCH(0);
     }
+#else
+    X3_LAUNCH(0);
+#endif
 #undef X3_LAUNCH
     return manet_check_launch("manet_conv1x1_x3_f32");
 }

@@ -123,3 +123,20 @@ def test_e2e_flag_needs_a_gpu_and_spawns():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--e2e", "--gpus", "2", "--e2e-frames", "5"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and (r.stdout + r.stderr).count("bench.py needs an MI355X") == 2
+
+
+def test_preflight_script_argument_plumbing():
+    """tools/preflight_multigpu.sh --dry-run prints the commands it would run: RCCL with one rank, then N ranks weak / strong /
+    end to end -- over RCCL when the box has the GPUs, over gloo (ranks sharing a device) when it has not"""
+    sh = os.path.join(ROOT, "tools", "preflight_multigpu.sh")
+    r = subprocess.run(["bash", sh, "--dry-run", "--gpus", "4"], env=dict(os.environ, PREFLIGHT_VISIBLE_GPUS="8"), cwd=ROOT,
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0
+    out = r.stdout
+    assert "MANET_BENCH_FORCE_DIST=1 python3 bench.py" in out
+    assert "== weak_n4: python3 bench.py --gpus 4" in out and "--scaling strong" in out and "bench.py --e2e --gpus 4" in out
+    assert "MANET_BENCH_BACKEND=gloo" not in out and "HSA_ENABLE_IPC_MODE_LEGACY=0" in out
+    r = subprocess.run(["bash", sh, "--dry-run"], env=dict(os.environ, PREFLIGHT_VISIBLE_GPUS="1"), cwd=ROOT,
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "== weak_n2: MANET_BENCH_BACKEND=gloo python3 bench.py --gpus 2" in r.stdout
+    assert subprocess.run(["bash", sh, "--bogus"], cwd=ROOT, capture_output=True).returncode == 2

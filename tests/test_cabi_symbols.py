@@ -55,3 +55,32 @@ def test_argument_validation_without_a_gpu(built_lib):
     oc, oh, ow = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.manet_correlation_out_dims(20, 30, 4, 1, 4, 1, 1, ctypes.byref(oc), ctypes.byref(oh), ctypes.byref(ow)) == 0
     assert (oc.value, oh.value, ow.value) == (81, 20, 30)
+
+
+def test_default_build_carries_no_ablation_variants(built_lib):
+    """VERDICT r3 hygiene: the default build compiles only the kernels the data path can reach.  The tuning keys that select
+    variant / ablation instantiations are refused (with the rebuild recipe) unless the library was built with
+    -DMANET_ABLATION; the keys that only steer the shipped kernels (block map, split count, the unfused local route) work."""
+    import subprocess as sp
+    import sys
+    code = (
+        "import os, sys; os.environ['MANET_TUNING']='1'; sys.path.insert(0, %r)\n"
+        "from cvpr2020_manet_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "assert lib.manet_tune_set(0, 4) == 0 and lib.manet_tune_set(0, -2**31) == 0\n"
+        "assert lib.manet_tune_set(1, 16) == 0 and lib.manet_tune_set(1, -2**31) == 0\n"
+        "res = [lib.manet_tune_set(k, 1) for k in (2, 3, 5, 6)]\n"
+        "msg = lib.manet_last_error_string().decode()\n"
+        "print(res, msg)\n" % ROOT)
+    out = sp.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    nm = sp.run(["nm", "-C", "--defined-only", built_lib], capture_output=True, text=True).stdout
+    ablation_build = "global_match_bf16_wide_kernel<7, 15" in nm
+    if ablation_build:
+        assert "[0, 0, 0, 0]" in out.stdout
+    else:
+        assert "[-1, -1, -1, -1]" in out.stdout and "MANET_ABLATION" in out.stdout
+        # none of the spilled / unreachable instantiations r3's build carried
+        for sym in ("global_match_bf16_wide_kernel<9", "global_match_bf16_wide_kernel<7, 4", "global_match_bf16_kernel<9, true, 2",
+                    "global_match_f32_kernel<64, 1, false>", "frame_prepare_kernel<float, 64>"):
+            assert sym not in nm, sym
