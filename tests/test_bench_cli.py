@@ -122,7 +122,8 @@ def test_e2e_flag_needs_a_gpu_and_spawns():
         pytest.skip("CPU-only check")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--e2e", "--gpus", "2", "--e2e-frames", "5"], env=env,
                        capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and (r.stdout + r.stderr).count("bench.py needs an MI355X") == 2
+    # (the launcher tears the other rank down as soon as one fails: one or both refusals make it to the log)
+    assert r.returncode != 0 and (r.stdout + r.stderr).count("bench.py needs an MI355X") >= 1 and '"metric"' not in r.stdout
 
 
 def test_preflight_script_argument_plumbing():
