@@ -30,6 +30,7 @@
 // Numerics of the fp32 path: the MFMA is a k-ascending fmaf chain from 0, d = fmaf(-2, mm, xs+ys);
 // min is exact -- so the result is bit-identical to oracle/manet_oracle.c.
 #include "manet_common.h"
+#include <type_traits>
 #include "local_geom.h"
 
 namespace {
@@ -522,7 +523,15 @@ struct FramePrep {
     long fill_words;
     unsigned fill_value;
     int n_data, nxc;
+    int vec2;   // s_x == 1, even w / strides, aligned base: two pixels per load
+    int rcopy;  // fp32 source + MANET_COMPUTE_BF16: LDS also holds a bf16-rounded copy
+    int abl;  // -DMANET_ABLATION builds, timing experiments: 1 no loads, 2 no plane stores, 4 no image stores, 8 no norm chain, 16 no data blocks, 32 no aux blocks
 };
+#ifdef MANET_ABLATION
+#define MANET_FP_ABL(bit_) (A.abl & (bit_))
+#else
+#define MANET_FP_ABL(bit_) false
+#endif
 template <typename SRC, int XC>
 __global__ __launch_bounds__(256) void frame_prepare_kernel(const FramePrep A)
 {
@@ -533,6 +542,8 @@ __global__ __launch_bounds__(256) void frame_prepare_kernel(const FramePrep A)
     char *ws = A.ws + (long)blockIdx.z * A.ws_stride;
     float *plane = (float *)(ws + A.off_plane);
     const int C = A.C, kpad = A.kpad, units = A.units;
+    if (MANET_FP_ABL(16) && (int)blockIdx.x < A.n_data) return;
+    if (MANET_FP_ABL(32) && (int)blockIdx.x >= A.n_data) return;
     if ((int)blockIdx.x >= A.n_data) {  // ---- auxiliary blocks
         const long gid = (long)(blockIdx.x - A.n_data) * 256 + tid, gstride = (long)(gridDim.x - A.n_data) * 256;
         if (A.d >= 0) {
@@ -546,6 +557,16 @@ __global__ __launch_bounds__(256) void frame_prepare_kernel(const FramePrep A)
                 const int rb = rem / WS4, q = rem - rb * WS4;
                 const int r = rb < A.d ? rb : A.hp + rb;  // rows [0, d) and [d + hp, HPAD)
                 *(f32x4 *)(plane + (long)c * A.PS + (long)r * A.WS + 4 * q) = pad;
+            }
+            {  // ... and the left / right border columns of the data rows [d, d + hp): columns [0, d) and [d + wp, WS)
+                const int nb = A.WS - A.wp;  // border floats per row
+                const long items2 = (long)C * A.hp * nb;
+                for (long i = gid; i < items2; i += gstride) {
+                    const int c = (int)(i / ((long)A.hp * nb));
+                    const int rem = (int)(i - (long)c * A.hp * nb);
+                    const int r = rem / nb, j = rem - r * nb;
+                    plane[(long)c * A.PS + (long)(A.d + r) * A.WS + (j < A.d ? j : A.wp + j)] = MANET_WRONG_LABEL_PADDING_DISTANCE;
+                }
             }
             int *tab = (int *)(ws + A.off_tab);
             for (long i = gid; i <= A.nty + 1 + A.ntx; i += gstride)
@@ -569,109 +590,173 @@ __global__ __launch_bounds__(256) void frame_prepare_kernel(const FramePrep A)
         return;
     }
     // ---- data blocks
+    // LDS: rows [PIX][KP] = the embedding as stored (what the pooled plane, the f32 and the split-bf16 image are made from);
+    // rq = the values the bf16 image and its |q|^2 are made from: bf16-rounded.  2-byte sources ARE rounded already (rq = rows);
+    // fp32 sources with plain-bf16 arithmetic get a second, rounded copy (A.rcopy) so that neither the norm chain nor the image
+    // assembly rounds per use (r3: 5 us of norm chain and 7 us of image assembly in a 20 us launch).
     const int KP = kpad + 1;
     float *rows = (float *)pack_smem;           // [PIX][KP]
-    float *s_norm = rows + (long)PIX * KP;      // [PIX]
+    float *rq = A.rcopy ? rows + (long)PIX * KP : rows;
     const int rp = blockIdx.x / A.nxc, cx = blockIdx.x - rp * A.nxc;
     const int x0 = cx * XC, y0 = 2 * rp;
-    {  // stage [pixel][k]: lanes along x (row segments of the C-major source), KB unconditional loads in flight per thread
-        constexpr int NKQ = 256 / PIX, KB = 5;
+    const bool bf16_exact = (A.compute == MANET_COMPUTE_BF16) && (A.rcopy || sizeof(SRC) == 2);  // rq holds bf16-exact values
+    // The launch is LATENCY-bound, not bandwidth-bound (1.6 workgroups per CU, 27 MB per frame; ablations in DESIGN 3.3): every
+    // load of the workgroup is issued before the first one is waited for -- one memory round trip per workgroup.
+    if (A.vec2) {  // two horizontally adjacent pixels per lane (8-byte / 4-byte loads): half the load instructions
+        constexpr int NP2 = PIX / 2, NKQ = 256 / NP2;
+        const int pp = tid % NP2, kq = tid / NP2;
+        const int p = 2 * pp, y = y0 + p / XC, x = x0 + p % XC;  // (XC is even: both pixels in one row; w is even)
+        const bool in = (y < A.h && x < A.w);
+        const SRC *sp = src + (long)(y < A.h ? y : A.h - 1) * A.s_y + (long)(x < A.w ? x : A.w - 2);
+        long sc_ = A.s_c;
+        if (MANET_FP_ABL(1)) { sp = src; sc_ = 0; }  // (timing ablation: every load hits one cached line)
+        float *r0 = rows + p * KP, *q0 = rq + p * KP;
+        auto stage2 = [&](auto kb_tag) __attribute__((always_inline)) {
+            constexpr int KB = decltype(kb_tag)::value;
+            for (int k0 = kq; k0 < C; k0 += NKQ * KB) {
+                float va[KB], vb[KB];
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    const int k = k0 + j * NKQ;
+                    const SRC *a = sp + (long)(k < C ? k : C - 1) * sc_;
+                    if (sizeof(SRC) == 4) {
+                        const float2 t = *(const float2 *)a;
+                        va[j] = t.x; vb[j] = t.y;
+                    } else {
+                        const unsigned t = *(const unsigned *)a;
+                        va[j] = bf2f(t & 0xffffu); vb[j] = bf2f(t >> 16);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    const int k = k0 + j * NKQ;
+                    if (k < C) {
+                        const float a = in ? va[j] : 0.0f, b = in ? vb[j] : 0.0f;
+                        r0[k] = a; r0[KP + k] = b;
+                        if (A.rcopy) { q0[k] = bf2f(f2bf(a)); q0[KP + k] = bf2f(f2bf(b)); }
+                    }
+                }
+            }
+        };
+        if (C <= 13 * NKQ) stage2(std::integral_constant<int, 13>{});
+        else stage2(std::integral_constant<int, 16>{});
+    } else {  // generic strides: one pixel per lane, lanes along x
+        constexpr int NKQ = 256 / PIX;
         const int p = tid % PIX, kq = tid / PIX;
         const int y = y0 + p / XC, x = x0 + p % XC;
         const bool in = (y < A.h && x < A.w);
         const SRC *sp = src + (long)(y < A.h ? y : A.h - 1) * A.s_y + (long)(x < A.w ? x : A.w - 1) * A.s_x;
-        float *rp_ = rows + p * KP;
-        for (int k0 = kq; k0 < C; k0 += NKQ * KB) {
-            float v[KB];
+        long sc_ = A.s_c;
+        if (MANET_FP_ABL(1)) { sp = src; sc_ = 0; }
+        float *rp_ = rows + p * KP, *qp_ = rq + p * KP;
+        auto stage = [&](auto kb_tag) __attribute__((always_inline)) {
+            constexpr int KB = decltype(kb_tag)::value;
+            for (int k0 = kq; k0 < C; k0 += NKQ * KB) {
+                float v[KB];
 #pragma unroll
-            for (int j = 0; j < KB; ++j) {
-                const int k = k0 + j * NKQ;
-                v[j] = emb_load(sp, (long)(k < C ? k : C - 1) * A.s_c);
-            }
+                for (int j = 0; j < KB; ++j) {
+                    const int k = k0 + j * NKQ;
+                    v[j] = emb_load(sp, (long)(k < C ? k : C - 1) * sc_);
+                }
 #pragma unroll
-            for (int j = 0; j < KB; ++j) {
-                const int k = k0 + j * NKQ;
-                if (k < C) rp_[k] = in ? v[j] : 0.0f;
+                for (int j = 0; j < KB; ++j) {
+                    const int k = k0 + j * NKQ;
+                    if (k < C) {
+                        const float a = in ? v[j] : 0.0f;
+                        rp_[k] = a;
+                        if (A.rcopy) qp_[k] = bf2f(f2bf(a));
+                    }
+                }
             }
-        }
+        };
+        // (the whole channel range in one batch: C <= 100 -> 25 x NKQ, C <= 128 -> 32 x NKQ channels in flight per thread)
+        if (C <= 25 * NKQ) stage(std::integral_constant<int, 25>{});
+        else stage(std::integral_constant<int, 32>{});
     }
     for (int idx = tid; idx < PIX * (kpad - C); idx += 256) {
         const int p = idx / (kpad - C), k = C + idx - p * (kpad - C);
         rows[p * KP + k] = 0.0f;
+        if (A.rcopy) rq[p * KP + k] = 0.0f;
     }
     __syncthreads();
-    if (tid < PIX) {  // |q|^2: the k-ascending fmaf chain of the oracle, as pack_rows_kernel (reads batched ahead of the chain)
-        const float *row = rows + tid * KP;
-        float n = 0.0f;
-        const bool rnd = (A.compute == MANET_COMPUTE_BF16);
-        int k = 0;
-        for (; k + 10 <= C; k += 10) {
-            float v[10];
+    // ---- roles (no further barrier): wave 0 walks the |q|^2 chain -- 100 dependent fmaf, 1.5 us -- and then writes what needs
+    // it (the f32 image's norm block / the bf16 image's units with norm slots) and the plane's border columns; waves 1..3 write
+    // the pooled plane and the image units that do not depend on the norm while that chain runs.
+    const bool f32img = (A.compute == MANET_COMPUTE_F32);
+    const int hi_units = (A.compute == MANET_COMPUTE_BF16X3) ? units / 2 : units;
+    // bf16 images: unit u carries norm slots iff its k range reaches past C (both halves of the split image are handled alike)
+    auto unit_is_special = [&](int u) { const int uu = u >= hi_units ? u - hi_units : u; return 16 * (uu >> 1) + 8 * (uu & 1) + 8 > C; };
+    auto image_addr = [&](long n, int u) { return ws + (n >> 5) * A.qblk_bytes + ((long)u * QB + (n & 31)) * 16; };
+    // the bf16 image unit from bf16-EXACT staged values: -2 x is exact, its upper 16 bits are the bf16 (no rounding, no NaN fix-up:
+    // identical bits to f2bf(-2 * bf2f(f2bf(x))))
+    auto unit_bf16_exact = [&](const float *row, int u) {
+        const int k0 = 16 * (u >> 1) + 8 * (u & 1);
+        unsigned e8[8];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) v[j] = row[k + j];
+        for (int e = 0; e < 8; ++e) e8[e] = __float_as_uint(-2.0f * row[k0 + e]) >> 16;
+        return make_uint4(e8[0] | (e8[1] << 16), e8[2] | (e8[3] << 16), e8[4] | (e8[5] << 16), e8[6] | (e8[7] << 16));
+    };
+    // (f32 image: the last units / 6 units of every pixel are wave 0's as well -- its share of the store work behind the chain)
+    const int u_split = f32img ? units - units / 6 : units;
+    if (tid < PIX) {  // ---- wave 0 (PIX = 64 lanes; XC = 64 builds: two waves)
+        const int p = tid;
+        const int y = y0 + p / XC, x = x0 + p % XC;
+        const bool in = (y < A.h && x < A.w);
+        const long n = (long)y * A.w + x;
+        float nrm = 0.0f;
+        if (!MANET_FP_ABL(8)) {  // |q|^2: the k-ascending fmaf chain of the oracle, as pack_rows_kernel (reads batched ahead)
+            const float *row = (A.compute == MANET_COMPUTE_BF16 ? rq : rows) + p * KP;
+            const bool rnd = (A.compute == MANET_COMPUTE_BF16) && !bf16_exact;
+            int k = 0;
+            for (; k + 10 <= C; k += 10) {
+                float v[10];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                const float x = rnd ? bf2f(f2bf(v[j])) : v[j];
-                n = fmaf(x, x, n);
+                for (int j = 0; j < 10; ++j) v[j] = row[k + j];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const float xv = rnd ? bf2f(f2bf(v[j])) : v[j];
+                    nrm = fmaf(xv, xv, nrm);
+                }
+            }
+            for (; k < C; ++k) {
+                const float xv = rnd ? bf2f(f2bf(row[k])) : row[k];
+                nrm = fmaf(xv, xv, nrm);
             }
         }
-        for (; k < C; ++k) {
-            const float x = rnd ? bf2f(f2bf(row[k])) : row[k];
-            n = fmaf(x, x, n);
-        }
-        s_norm[tid] = n;
-    }
-    // pooled plane row d + rp (IntVOS.py:282-284: window summed row-major, times 1/4)
-    if (A.d >= 0 && rp < A.hp) {
-        float *prow = plane + (long)(A.d + rp) * A.WS + A.d + x0 / 2;
-        for (int idx = tid; idx < (XC / 2) * C; idx += 256) {
-            const int c = idx / (XC / 2), px = idx - c * (XC / 2);
-            if (x0 / 2 + px < A.wp) {
-                const float *q = rows + (2 * px) * KP + c;
-                prow[(long)c * A.PS + px] = (((q[0] + q[KP]) + q[XC * KP]) + q[(XC + 1) * KP]) * 0.25f;
-            }
-        }
-        // the row's left / right border columns (the first / last column block of the row pair)
-        if (cx == 0)
-            for (int idx = tid; idx < A.d * C; idx += 256) {
-                const int c = idx / A.d, j = idx - c * A.d;
-                plane[(long)c * A.PS + (long)(A.d + rp) * A.WS + j] = MANET_WRONG_LABEL_PADDING_DISTANCE;
-            }
-        if (cx == A.nxc - 1) {
-            const int r0 = A.d + A.wp, nr = A.WS - r0;
-            for (int idx = tid; idx < nr * C; idx += 256) {
-                const int c = idx / nr, j = idx - c * nr;
-                plane[(long)c * A.PS + (long)(A.d + rp) * A.WS + r0 + j] = MANET_WRONG_LABEL_PADDING_DISTANCE;
+        if (in && !MANET_FP_ABL(4)) {
+            if (f32img) {
+                *(float *)(ws + (n >> 5) * A.qblk_bytes + (long)units * QB * 16 + (n & 31) * 4) = nrm;
+                for (int u = u_split; u < units; ++u) *(f32x4 *)image_addr(n, u) = image_unit_f32(rows + p * KP, u);
+            } else {
+                for (int u = 0; u < units; ++u)
+                    if (unit_is_special(u)) *(uint4 *)image_addr(n, u) = image_unit_bf16<true>(rows + p * KP, u, hi_units, C, nrm);
             }
         }
     }
-    __syncthreads();
-    // operand image: pixel (y, x) is query row n = y w + x -> block n / 32, row n % 32
-    if (A.compute == MANET_COMPUTE_F32) {
-        for (int item = tid; item < units * PIX; item += 256) {
-            const int p = item % PIX, u = item / PIX;
-            const int y = y0 + p / XC, x = x0 + p % XC;
-            if (y < A.h && x < A.w) {
-                const long n = (long)y * A.w + x;
-                *(f32x4 *)(ws + (n >> 5) * A.qblk_bytes + ((long)u * QB + (n & 31)) * 16) = image_unit_f32(rows + p * KP, u);
+    if (tid >= PIX) {  // ---- the other waves
+        const int t = tid - PIX, NT = 256 - PIX;
+        // pooled plane row d + rp (IntVOS.py:282-284: window summed row-major, times 1/4)
+        if (A.d >= 0 && rp < A.hp && !MANET_FP_ABL(2)) {
+            float *prow = plane + (long)(A.d + rp) * A.WS + A.d + x0 / 2;
+            for (int idx = t; idx < (XC / 2) * C; idx += NT) {
+                const int c = idx / (XC / 2), px = idx - c * (XC / 2);
+                if (x0 / 2 + px < A.wp) {
+                    const float *q = rows + (2 * px) * KP + c;
+                    prow[(long)c * A.PS + px] = (((q[0] + q[KP]) + q[XC * KP]) + q[(XC + 1) * KP]) * 0.25f;
+                }
             }
         }
-        if (tid < PIX) {
-            const int y = y0 + tid / XC, x = x0 + tid % XC;
-            if (y < A.h && x < A.w) {
+        // operand image: pixel (y, x) is query row n = y w + x -> block n / 32, row n % 32
+        if (!MANET_FP_ABL(4)) {
+            for (int item = t; item < u_split * PIX; item += NT) {
+                const int p = item % PIX, u = item / PIX;
+                const int y = y0 + p / XC, x = x0 + p % XC;
+                if (y >= A.h || x >= A.w) continue;
                 const long n = (long)y * A.w + x;
-                *(float *)(ws + (n >> 5) * A.qblk_bytes + (long)units * QB * 16 + (n & 31) * 4) = s_norm[tid];
-            }
-        }
-    } else {
-        const int hi_units = (A.compute == MANET_COMPUTE_BF16X3) ? units / 2 : units;
-        for (int item = tid; item < units * PIX; item += 256) {
-            const int p = item % PIX, u = item / PIX;
-            const int y = y0 + p / XC, x = x0 + p % XC;
-            if (y < A.h && x < A.w) {
-                const long n = (long)y * A.w + x;
-                *(uint4 *)(ws + (n >> 5) * A.qblk_bytes + ((long)u * QB + (n & 31)) * 16) =
-                    image_unit_bf16<true>(rows + p * KP, u, hi_units, C, s_norm[p]);
+                if (f32img) *(f32x4 *)image_addr(n, u) = image_unit_f32(rows + p * KP, u);
+                else if (unit_is_special(u)) continue;  // (wave 0, behind the norm chain)
+                else if (bf16_exact) *(uint4 *)image_addr(n, u) = unit_bf16_exact(rq + p * KP, u);
+                else *(uint4 *)image_addr(n, u) = image_unit_bf16<true>(rows + p * KP, u, hi_units, C, 0.0f);
             }
         }
     }
@@ -2676,13 +2761,22 @@ int manet_frame_prepare(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y
     A.N = (long)h * w; A.N_pad = F.N_pad;
     A.fill_ptr = (unsigned *)fill_ptr; A.fill_words = (long)fill_words; A.fill_value = fill_value;
     A.nxc = (w + XC - 1) / XC;
+#ifdef MANET_ABLATION
+    A.abl = manet_tune_get(MANET_TUNE_ABLATION, 0);
+#else
+    A.abl = 0;
+#endif
     A.n_data = ((h + 1) / 2) * A.nxc;
     long aux_items = (long)(F.N_pad - A.N) * G.units + fill_words + 64;
-    if (max_distance >= 0) aux_items += (long)C * (F.HPAD - F.hp) * (F.WS / 4);
+    if (max_distance >= 0) aux_items += (long)C * (F.HPAD - F.hp) * (F.WS / 4) + (long)C * F.hp * (F.WS - F.wp) / 4;
     long aux = (aux_items + 1023) / 1024;
     if (aux < 1) aux = 1;
     if (aux > 256) aux = 256;
-    const size_t lds = (size_t)2 * XC * (G.kpad + 1) * sizeof(float) + 2 * XC * sizeof(float);
+    const size_t esz = emb_dtype == MANET_EMB_F32 ? 4 : 2;
+    A.vec2 = (s_x == 1 && (w & 1) == 0 && (s_y & 1) == 0 && (s_c & 1) == 0 && (n_frames == 1 || (s_f & 1) == 0) &&
+              ((size_t)emb % (2 * esz)) == 0) ? 1 : 0;
+    A.rcopy = (emb_dtype == MANET_EMB_F32 && G.compute == MANET_COMPUTE_BF16) ? 1 : 0;
+    const size_t lds = (size_t)(A.rcopy ? 2 : 1) * 2 * XC * (G.kpad + 1) * sizeof(float) + 2 * XC * sizeof(float);
     const dim3 grid((unsigned)(A.n_data + aux), 1, (unsigned)n_frames);
     hipStream_t st = (hipStream_t)stream;
     if (emb_dtype != MANET_EMB_F32 && emb_dtype != MANET_EMB_BF16)

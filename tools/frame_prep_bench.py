@@ -24,6 +24,24 @@ def timeit(fn, n=50):
     return a.elapsed_time(b) / n * 1e3
 
 
+def kernel_us(lib, fn, channel, n=40):
+    """HIP events the library records right around the kernel (manet_profile_*): the launch's own duration -- the Python
+    call above it costs more than the kernel (host-bound loop), so wall / loop timing says nothing about it"""
+    import ctypes
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    _lib.check(lib.manet_profile_begin(n + 1), "manet_profile_begin")
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    ms, cnt = (ctypes.c_float * (n + 1))(), ctypes.c_int(0)
+    _lib.check(lib.manet_profile_read(channel, ms, n + 1, ctypes.byref(cnt)), "manet_profile_read")
+    vals = sorted(ms[i] for i in range(cnt.value))
+    _lib.check(lib.manet_profile_end(None, 0, None), "manet_profile_end")
+    return vals[len(vals) // 2] * 1e3 if vals else float("nan")
+
+
 def main():
     os.environ["MANET_TUNING"] = "1"
     lib = _lib.load()
@@ -32,10 +50,15 @@ def main():
         e = (torch.relu(torch.randn(2, 100, h, w, device="cuda")) * 0.1).to(st)
         lab = torch.zeros(h, w, dtype=torch.int32, device="cuda")
         for xc in (0, 1):
-            lib.manet_tune_set(6, xc)
+            if lib.manet_tune_set(6, xc) != 0:  # (the 64-column variant lives in -DMANET_ABLATION builds only)
+                if xc:
+                    continue
             t_prep = timeit(lambda: ops.prepare_frames(e[0], compute=compute, max_distance=d))
             t_prep_nopool = timeit(lambda: ops.prepare_frames(e[0], compute=compute, max_distance=-1))
-            print("%dx%d d=%d %s/%s XC=%d: frame_prepare %.1f us (image only %.1f us)" % (h, w, d, compute, st, 64 if xc else 32, t_prep, t_prep_nopool))
+            k_prep = kernel_us(lib, lambda: ops.prepare_frames(e[0], compute=compute, max_distance=d), 2)
+            k_nopool = kernel_us(lib, lambda: ops.prepare_frames(e[0], compute=compute, max_distance=-1), 2)
+            print("%dx%d d=%d %s/%s XC=%d: frame_prepare KERNEL %.1f us (image only %.1f us); python loop %.1f / %.1f us per call"
+                  % (h, w, d, compute, st, 64 if xc else 32, k_prep, k_nopool, t_prep, t_prep_nopool))
         t_pack = timeit(lambda: ops.PackedQuery(e[0].permute(1, 2, 0), compute=compute))
         fr = ops.prepare_frames(e, compute=compute, max_distance=d)
         t_old = timeit(lambda: ops.local_match(e[0].permute(1, 2, 0), e[1].permute(1, 2, 0), lab, 2, d))
