@@ -46,10 +46,15 @@ constexpr int META_KMAX = 200;     // [200]      max |k|^2 over the bank's rows,
 // MANET_COMPUTE_BF16_REFINE: a pre-pass over every REFINE_SUB-th bank tile gives an upper bound of the minimum; the full
 // bf16 pass then keeps, per (query, object), the bank rows that could beat it; up to REFINE_CAP of them are re-evaluated in
 // the reference's fp32 arithmetic
-#ifndef MANET_REFINE_SUB
-#define MANET_REFINE_SUB 8
-#endif
-constexpr int REFINE_SUB = MANET_REFINE_SUB;
+// REFINE_SUB by bank size (refine_sub): the pre-pass costs 1 / REFINE_SUB of the filter pass's matrix work; a sparser sample
+// leaves ~ln more candidates per pair for the cheap re-rank -- the larger the bank, the sparser the sample that pays.
+constexpr int META_NAN = 66;       // [66..129]  object o's bank rows contain a NaN (MANET_COMPUTE_BF16_REFINE)
+int refine_sub(long T_max)
+{
+    const int forced = manet_tune_get(MANET_TUNE_REFINE_SUB, 0);  // (experiments)
+    if (forced > 0) return forced;
+    return T_max <= 2500 ? 8 : 16;  // 480p x 5 frames: 2 007 tiles; 720p x 10 frames: 9 006
+}
 #ifndef MANET_REFINE_XCHG_MASK
 #define MANET_REFINE_XCHG_MASK 3
 #endif
@@ -163,7 +168,7 @@ BankLayout bank_layout(int64_t M0, int C, int n_ids, int compute)
     L.off_rows = L.off_norms = L.off_sub_meta = L.off_sub_pack = L.off_pack32 = 0;
     L.G32 = L.G;
     if (compute == MANET_COMPUTE_BF16_REFINE) {
-        L.T_sub_max = L.T_max / REFINE_SUB + n_ids + 1;
+        L.T_sub_max = L.T_max / refine_sub(L.T_max) + n_ids + 1;
         L.off_rows = L.total;
         L.off_norms = manet_align_up(L.off_rows + (size_t)L.T_max * BT * C * sizeof(float), 256);
         L.off_sub_meta = manet_align_up(L.off_norms + (size_t)L.T_max * BT * sizeof(float), 256);
@@ -1716,7 +1721,7 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
             for (int k = 0; k < KSB; ++k)
                 q[j][k] = *(const u32x4 *)(qb + (size_t)j * QBLK_BYTES + ((size_t)(k * 2 + h) * QB + l31) * 16);
     }
-    const long qbase = (long)qt * QTB + wave * (NQB * QB) + l31;
+    const unsigned qbase = (unsigned)(qt * QTB + wave * (NQB * QB) + l31);  // (N_pad < 2^31: check_common)
 #pragma unroll
     for (int j = 0; j < NQB; ++j)
 #pragma unroll
@@ -1742,9 +1747,9 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     auto load_thr = [&](int obj) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NQB; ++j) {
-            const unsigned kpub = FILTER ? thr[(size_t)obj * N_pad + qbase + 32 * j] : 0u;
+            const unsigned kpub = FILTER ? (thr + (size_t)obj * N_pad)[qbase + 32u * j] : 0u;
             tq[j] = FILTER ? float_of(kpub) : 0.0f;
-            sq[j] = FILTER ? slack[(size_t)obj * N_pad + qbase + 32 * j] : 0.0f;
+            sq[j] = FILTER ? (slack + (size_t)obj * N_pad)[qbase + 32u * j] : 0.0f;
             if (FILTER) pks[64 * j] = kpub;
         }
     };
@@ -1756,7 +1761,7 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
                 const float a = fminf(tq[j], __shfl_xor(tq[j], 32));
                 const unsigned ka = key_of(a);
                 if (h == 0 && a == a && ka < pks[64 * j]) {
-                    atomicMin(thr + (size_t)obj * N_pad + qbase + 32 * j, ka);
+                    atomicMin(&(thr + (size_t)obj * N_pad)[qbase + 32u * j], ka);
                     pks[64 * j] = ka;
                 }
             }
@@ -1766,7 +1771,7 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         for (int j = 0; j < NQB; ++j) {
             const float v = min3p(ma[j], mb[j], mb[j]);
             const float a = min3p(v, v, __shfl_xor(v, 32));
-            if (h == 0) atomicMin(keys + (size_t)obj * N_pad + qbase + 32 * j, key_of(a));
+            if (h == 0) atomicMin(&(keys + (size_t)obj * N_pad)[qbase + 32u * j], key_of(a));
         }
     };
     (void)young_prio;
@@ -1794,15 +1799,21 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     auto flush_sub = [&](int j) {
         const int cnt = wl_n[j];
         if (cnt == 0) return;  // (wave-uniform)
-        const long b = (long)qt * (QTB / QB) + wave * NQB + j;
+        // (the bucket's address arithmetic stays HERE, in scalar registers: hipcc otherwise hoists four per-lane 64-bit list
+        // addresses + four LDS addresses out of the step loop, 15 VGPRs it can only spill at this kernel's register budget --
+        // r3: scratch_load + s_waitcnt vmcnt(0) in the flush path, which drained the LDS-DMA prefetch on every flush)
+        int b32 = qt * (QTB / QB) + wave * NQB + j, sub_off = j * WL;
+        asm volatile("" : "+s"(b32), "+s"(sub_off));
+        const long b = (long)b32;
         unsigned base = 0u;
         if (lane == 0) base = atomicAdd(&bcnt[b], (unsigned)cnt) & 0x7fffffffu;  // (bit 31 = the bucket's "incomplete" mark)
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        uint2 *dst = list + b * bucket_cap + base;  // (wave-uniform)
+        const long room = bucket_cap - (long)base;
         for (int i = lane; i < cnt; i += 64) {
-            const uint2 e = fl[j * WL + i];  // (this wave's own ds_writes: ordered behind them in the LDS queue)
-            if ((long)base + i < bucket_cap)
-                list[b * bucket_cap + base + i] =
-                    make_uint2((unsigned)((size_t)(e.x >> 16) * N_pad + (size_t)qt * QTB + (e.x & 0xffffu)), e.y);
+            const uint2 e = fl[sub_off + i];  // (this wave's own ds_writes: ordered behind them in the LDS queue)
+            if ((long)i < room)
+                dst[i] = make_uint2((unsigned)((size_t)(e.x >> 16) * N_pad + (size_t)qt * QTB + (e.x & 0xffffu)), e.y);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the sub-list was read before it is refilled
         wl_n[j] = 0;
@@ -2008,7 +2019,7 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
                 flush(o);
                 xo = o;
 #pragma unroll
-                for (int j = 0; j < NQB; ++j) xk[j] = thr[(size_t)o * N_pad + qbase + 32 * j];
+                for (int j = 0; j < NQB; ++j) xk[j] = (thr + (size_t)o * N_pad)[qbase + 32u * j];
             }
         }
         if (t + 2 * TPS < t1) stage_dma(t + 2 * TPS, buf);
@@ -2080,14 +2091,20 @@ __global__ __launch_bounds__(256) void bank_rows_f32_kernel(const SRC *__restric
                 const float x = emb_load(src, (long)sr * s_row + (long)k * s_c);
                 n = fmaf(x, x, n);
             }
-            atomicMax((unsigned *)&meta[META_KMAX], __float_as_uint(n));  // n >= 0: the bit pattern orders like the value
+            if (n == n) {
+                atomicMax((unsigned *)&meta[META_KMAX], __float_as_uint(n));  // n >= 0: the bit pattern orders like the value
+            } else {  // a NaN row: its object's minimum is NaN for every query (what MANET_COMPUTE_F32's min3p gives); keep it out
+                int o = 0;  // of max |k|^2, which would void every OTHER object's threshold
+                while (meta[META_SEG + o + 1] <= tile) ++o;
+                meta[META_NAN + o] = 1;
+            }
         }
         norms[slot] = n;
     }
 }
 
 // sub-sampled bank of the pre-pass: every REFINE_SUB-th tile of every object (at least one per non-empty object)
-__global__ void sub_segments_kernel(int n_ids, const int *__restrict__ meta, int *__restrict__ sub_meta)
+__global__ void sub_segments_kernel(int n_ids, const int *__restrict__ meta, int *__restrict__ sub_meta, int REFINE_SUB)
 {
     if (threadIdx.x == 0) {
         int t = 0;
@@ -2101,7 +2118,7 @@ __global__ void sub_segments_kernel(int n_ids, const int *__restrict__ meta, int
 }
 __global__ __launch_bounds__(256) void sub_copy_kernel(int n_ids, const int *__restrict__ meta,
                                                        const int *__restrict__ sub_meta, const char *__restrict__ bpack,
-                                                       char *__restrict__ spack, long tile_bytes)
+                                                       char *__restrict__ spack, long tile_bytes, int REFINE_SUB)
 {
     const int j = blockIdx.x;
     if (j >= sub_meta[META_T]) return;
@@ -2136,21 +2153,28 @@ __global__ void refine_threshold_kernel(const unsigned *__restrict__ keys, const
     if (i < N_pad / QB) bcnt[i] = 0u;
     if (i >= (long)n_ids * N_pad) return;
     const long n = i % N_pad;
-    keys2[i] = 0xffffffffu;  // "no row": the exact distances meet here by atomicMin
+    const int o = (int)(i / N_pad);
+    unsigned k2 = 0xffffffffu;  // "no row": the exact distances meet here by atomicMin
     const unsigned k = keys[i];
     float t = -INFINITY, sl = 0.0f;  // no row of this object anywhere: no candidates, the result is the padding distance
     if (k != 0xffffffffu && n < N) {
         const float U = float_of(k);
         const float u = 0.001953125f;  // 2^-9
-        const float qn = sqrtf(fmaxf(query_norm_from_image(qimg, qblk_bytes, n, C), 0.0f)) * 1.004f;  // |q| <= |q~| / (1 - u)
+        const float qn2 = query_norm_from_image(qimg, qblk_bytes, n, C);
+        // NaN embeddings: a NaN in the query row, or in any row of this object, makes every distance of the pair's
+        // minimum NaN in MANET_COMPUTE_F32 (min3p propagates it): the pair's exact key is NaN's (0, it wins every atomicMin) --
+        // no threshold is meaningful for it, and none is needed
+        if (qn2 != qn2 || meta[META_NAN + o]) k2 = 0u;
+        const float qn = sqrtf(fmaxf(qn2, 0.0f)) * 1.004f;  // |q| <= |q~| / (1 - u)
         const float kn = sqrtf(__uint_as_float((unsigned)meta[META_KMAX])) * 1.0001f;
         const float s = qn + kn, s2 = s * s;
         const float a = 8.0f * (float)(C + 8) * 5.9604645e-8f * s2;
         const float E0 = (2.0f * u + u * u) * s2 + a;
         const float E = 2.0f * u * s * sqrtf(fmaxf(U, 0.0f) + E0 + a) + u * u * s2 + a;
         sl = 2.1f * E;
-        t = U + sl;  // (NaN stays NaN: no candidates)
+        t = U + sl;  // (NaN stays NaN: no candidates; such a pair's result was settled above)
     }
+    keys2[i] = k2;
     thr[i] = key_of(t);  // as an order-preserving key: the filter pass's workgroups tighten it by atomicMin
     slack[i] = sl;       // ... to (smallest bf16 distance they met) + slack: E only shrinks with U
 }
@@ -2880,9 +2904,10 @@ int manet_bank_prepare_ex(const void *bank, int emb_dtype, int64_t b_stride_m, i
                                    rows, norms);
         }
         fill32(sub_meta, 0u, META_INTS, st);
-        hipLaunchKernelGGL(sub_segments_kernel, dim3(1), dim3(64), 0, st, n_ids, (const int *)meta, sub_meta);
+        const int sub = refine_sub(L.T_max);
+        hipLaunchKernelGGL(sub_segments_kernel, dim3(1), dim3(64), 0, st, n_ids, (const int *)meta, sub_meta, sub);
         hipLaunchKernelGGL(sub_copy_kernel, dim3((unsigned)L.T_sub_max), dim3(256), 0, st, n_ids, (const int *)meta,
-                           (const int *)sub_meta, (const char *)(ws + L.off_pack), ws + L.off_sub_pack, (long)L.tile_bytes);
+                           (const int *)sub_meta, (const char *)(ws + L.off_pack), ws + L.off_sub_pack, (long)L.tile_bytes, sub);
     }
     return manet_check_launch("manet_bank_prepare");
 }

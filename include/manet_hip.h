@@ -63,7 +63,10 @@ typedef void *manet_stream_t; /* a hipStream_t */
  * arg-min row may drop every other one.  A bf16 pre-pass over every 8th bank tile bounds the minimum, a bf16 pass over
  * the whole bank keeps the rows whose bf16 distance is within the rounding bound of that, and those few are re-evaluated in
  * the reference's fp32 arithmetic (the fmaf chains of MANET_COMPUTE_F32): the result EQUALS MANET_COMPUTE_F32's bit for bit
- * at about 1.4x the cost of MANET_COMPUTE_BF16.  (NaN embeddings: unsupported in this mode.) */
+ * at about 1.4x the cost of MANET_COMPUTE_BF16 on embeddings the bf16 pass can tell apart (blocks of queries it cannot are
+ * re-done by the exact fp32 kernel: the worst case costs the fp32 path's time plus the filter's; manet_global_match_refine_stats2).
+ * NaN embeddings propagate as in MANET_COMPUTE_F32: a NaN bank row makes its own object's minimum NaN for every query, a NaN
+ * query row its own pixel's, every other pair keeps the fp32 bits. */
 #define MANET_COMPUTE_BF16_REFINE 3
 
 /* storage type of an embedding operand of the *_ex entry points (take the producer's layout) */

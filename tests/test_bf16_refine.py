@@ -163,3 +163,39 @@ def test_partly_degenerate_embeddings_rescue_only_their_blocks(ops):
     assert torch.equal(bank.match(q.permute(1, 2, 0)), want)
     _, over = bank.refine_stats()
     assert over == 1  # (the band's blocks were rescued)
+
+
+def _same_with_nans(a, b):
+    na, nb = torch.isnan(a), torch.isnan(b)
+    return bool(torch.equal(na, nb)) and bool(torch.equal(torch.where(na, torch.zeros_like(a), a),
+                                                          torch.where(nb, torch.zeros_like(b), b)))
+
+
+@pytest.mark.parametrize("where", ["bank_row_in_prepass_sample", "bank_row_outside_sample", "query_row", "both"])
+def test_nan_embeddings_propagate_like_the_fp32_kernel(ops, where):
+    """one NaN bank row used to turn max |k|^2 -- hence EVERY pair's threshold -- into NaN: no candidates, no
+    rescue, the whole map came out as the padding distance.  Now: a NaN row poisons its own object only (as in the fp32 kernel,
+    whose NaN-propagating minimum returns NaN for every query of that object), a NaN query row its own pixel only, and every
+    other pair is still the fp32 kernel's bits."""
+    N, M, C, n_ids = 700, 9000, 100, 3
+    q, k, lab = _case(77, N, M, C, n_ids, 0.2)
+    if where in ("bank_row_in_prepass_sample", "both"):
+        k[int(torch.nonzero(lab == 1)[0])] = float("nan")       # first row of object 1: tile 0 of the object, always sampled
+    if where == "bank_row_outside_sample":
+        k[int(torch.nonzero(lab == 1)[200])] = float("nan")     # a row of the object's 4th tile: not in the 1-in-8 sample
+    if where in ("query_row", "both"):
+        q[123, 7] = float("nan")
+    want = ops.global_match(k, q, lab, n_ids, compute="f32")
+    got = ops.global_match(k, q, lab, n_ids, compute="bf16r")
+    assert _same_with_nans(got, want)
+    if where != "query_row":
+        clean = torch.ones(N, dtype=torch.bool, device="cuda")
+        clean[123] = where != "both"
+        assert bool(torch.isnan(want[:, 1]).all()) and not bool(torch.isnan(want[clean][:, 0]).any())
+    if where != "bank_row_in_prepass_sample" and where != "bank_row_outside_sample":
+        assert bool(torch.isnan(want[123]).all())
+    # normalised + merged epilogue on top (NaN stays NaN through sigmoid; `g <= mem` is false for NaN: the stored value wins)
+    mem_a, mem_b = torch.full((N, n_ids), 0.4, device="cuda"), torch.full((N, n_ids), 0.4, device="cuda")
+    a = ops.global_match(k, q, lab, n_ids, compute="f32", normalize=True, mem=mem_a)
+    b = ops.global_match(k, q, lab, n_ids, compute="bf16r", normalize=True, mem=mem_b)
+    assert _same_with_nans(a, b) and _same_with_nans(mem_a, mem_b)
