@@ -591,6 +591,177 @@ __global__ __launch_bounds__(X3_NT, 3) void conv1x1_x3_kernel(const float *__res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same fp32 contraction with the WEIGHTS RESIDENT IN REGISTERS (r4).  conv1x1_mfma_kernel streams a 16 KiB weight slice
+// per 16 input channels into LDS for every 64-pixel tile (256 KiB of L2 -> LDS traffic per tile, two operand reads per MFMA
+// pair) and measured 0.49 .. 0.58 of the fp32 matrix peak.  Here a wave owns 32 output channels and keeps their whole
+// [Cin <= 256][32] weight block as the MFMA A operand -- Cin / 2 VGPRs, loaded once -- while the activation streams through
+// a ring of LDS stage buffers by LDS-DMA: one ds_read_b32 per MFMA, no weight traffic after the prologue.  It is the
+// global-match kernel's shape (one operand in registers, the other through LDS), which runs at 0.90 of the same peak.
+//   workgroup = 4 waves = 128 output channels (one HALF of the 256) x a contiguous range of 64-pixel tiles (persistent);
+//   two workgroups per CU (<= 256 VGPRs): a half-0 and a half-1 workgroup of the same pixel range sit 8 blocks apart, i.e.
+//   on the same XCD (block b runs on XCD b % 8 -- observed, used for speed only), so the second reader of an activation row
+//   hits that XCD's L2; while one workgroup drains its tile's stores (vmcnt counts stores too: the epilogue ends in the
+//   only vmcnt(0) of the tile) the other keeps the matrix pipe busy.
+//   FOUR accumulator chains per wave: tools/ubench/mfma_f32_chains.hip -- the fp32 pipe needs four independent chains per
+//   wave (0.98 of the peak with one or two waves per SIMD); two chains reach 0.92 alone and 0.66 beside a second wave, which
+//   is where this kernel's first form (32 channels x 2 pixel blocks = 2 chains) sat: 0.60.  64 channels per wave would need
+//   256 weight registers, so the two extra chains come from K: even and odd k-steps accumulate separately and are added once
+//   per tile -- still pure fp32 (every product and sum an fmaf / add in fp32), but the k-ascending chain of
+//   conv1x1_mfma_kernel becomes two interleaved ones: results agree to summation-order rounding, not bit for bit.
+//   stage = 32 input channels x 64 pixels (8 KiB, 2 DMA pieces per wave), ring of 4, fetched 3 steps ahead ACROSS tile
+//   boundaries; a step's fragments F[s] are refilled with the next step's k-step s right behind the MFMAs that consumed them.
+constexpr int RW_P = 64, RW_KC = 32, RW_NB = 4, RW_NT = 256, RW_KMAX = 256;
+__device__ __forceinline__ void rw_wait_vmcnt(int n)  // wave-uniform n: 0, 2, 4 (pieces of the steps still in flight)
+{
+    if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__restrict__ in, long in_bs, int Cin, long HW,
+                                                              const float *__restrict__ w2t, const float *__restrict__ b2,
+                                                              int relu_out, float *__restrict__ out, int tpp, int total_tiles,
+                                                              int G, int abl)
+{
+    // abl (-DMANET_ABLATION builds, timing only): 1 no output stores, 2 no barrier, 4 no DMA after the prologue, 8 no refills
+    __shared__ __attribute__((aligned(1024))) float xbuf[RW_NB][RW_KC * RW_P];
+    __shared__ float bsh[128];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int half = j & 1, grp = xcd + 8 * (j >> 1);
+    if (grp >= G) return;
+    const int t0 = (int)((long)grp * total_tiles / G), t1 = (int)((long)(grp + 1) * total_tiles / G);
+    if (t0 >= t1) return;
+    const int co0 = half * 128 + wave * 32;
+    if (tid < 128) bsh[tid] = b2[half * 128 + tid];
+    // A operand: lane (co = l31, kk) holds w[2 s + kk][co0 + co] for every k-step s (zero past Cin)
+    float a[RW_KMAX / 2];
+#pragma unroll
+    for (int s = 0; s < RW_KMAX / 2; ++s) {
+        const int k = 2 * s + kk;
+        a[s] = k < Cin ? w2t[(long)k * PW_CO + co0 + l31] : 0.0f;
+    }
+    const int nch = (Cin + RW_KC - 1) / RW_KC;  // (Cin % 32 == 0: checked by the launcher)
+    const unsigned xbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&xbuf[0][0]);
+    // step = (tile, chunk); step number n lives in ring slot n % RW_NB.  All of a step's address arithmetic is SCALAR (the
+    // tile / chunk counters advance incrementally: no division, no per-lane 64-bit multiply): a lane contributes one 32-bit
+    // byte offset, computed once.
+    const int b0 = t0 / tpp;
+    int pf_b = b0, pf_p = t0 - b0 * tpp, pf_c = 0, pf_left = (t1 - t0), issued = 0;
+    const unsigned lane_off = (unsigned)(((long)(lane >> 4) * HW + 4 * (lane & 15)) * 4);
+    // the plane's last tile may be partial: clamped columns are computed and never stored
+    const long last_p0 = (long)(tpp - 1) * RW_P;
+    long lpix = 4 * (lane & 15);
+    if (last_p0 + lpix > HW - 4) lpix = HW - 4 - last_p0;
+    const unsigned lane_off_last = (unsigned)(((long)(lane >> 4) * HW + lpix) * 4);
+    auto issue = [&]() __attribute__((always_inline)) {
+        if (pf_left <= 0 || ((abl & 4) && issued >= RW_NB - 1)) return;  // (uniform)
+        const float *sbase = in + (long)pf_b * in_bs + (long)(pf_c * RW_KC + wave * 8) * HW + (long)pf_p * RW_P;
+        const unsigned voff = (pf_p == tpp - 1) ? lane_off_last : lane_off;
+        const unsigned dst = xbase + (unsigned)(issued % RW_NB) * (unsigned)(RW_KC * RW_P * 4) + (unsigned)wave * 2048u;
+        lds_dma16_s(sbase, voff, dst);                       // channel rows 8 wave .. 8 wave + 3 of the chunk
+        lds_dma16_s(sbase + 4 * HW, voff, dst + 1024u);      // ... + 4 .. + 7
+        ++issued;
+        if (++pf_c == nch) {
+            pf_c = 0;
+            --pf_left;
+            if (++pf_p == tpp) {
+                pf_p = 0;
+                ++pf_b;
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < RW_NB - 1; ++i) issue();
+    // the compiler waits for the weights HERE (its counted vmcnt waits must not sink into the loop, where they would drain
+    // the LDS-DMA it does not know about) -- and with them for the first steps' pieces
+#pragma unroll
+    for (int s = 0; s < RW_KMAX / 2; ++s) asm volatile("" : "+v"(a[s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // F holds the NEXT eight k-steps' fragments: the first half of a step refills it with the step's own second half, the
+    // second half with the first eight k-steps of the next stage (16 registers; a whole step's 32 would not fit beside 128
+    // weights and 64 accumulators)
+    constexpr int FH = RW_KC / 4;  // k-steps per half step
+    float F0[FH], F1[FH];
+    {
+        const float *X = &xbuf[0][kk * RW_P + l31];
+#pragma unroll
+        for (int s = 0; s < FH; ++s) {
+            F0[s] = X[2 * s * RW_P];
+            F1[s] = X[2 * s * RW_P + 32];
+        }
+    }
+    int st = 0;  // step number of (t, c); its stage was read into F during step st - 1, step st reads stage st + 1
+    int cur_b = b0, cur_p = t0 - b0 * tpp;
+    for (int t = t0; t < t1; ++t) {
+        f32x16 acc[2][2];  // [pixel block][k-step parity]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < RW_KMAX / RW_KC; ++c) {
+            if (c < nch) {  // (uniform)
+                issue();  // step st + RW_NB - 1 -> the slot of step st - 1 (read during step st - 2: free)
+                const float *Xc = &xbuf[st % RW_NB][kk * RW_P + l31], *Xn = &xbuf[(st + 1) % RW_NB][kk * RW_P + l31];
+#pragma unroll
+                for (int s = 0; s < RW_KC / 2; s += 2) {
+                    const int ks = c * (RW_KC / 2) + s, f = s % FH;
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], F0[f], acc[0][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], F1[f], acc[1][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks + 1], F0[f + 1], acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks + 1], F1[f + 1], acc[1][1], 0, 0, 0);
+                    if (!(abl & 8)) {
+                        // k-steps s, s + 1 of this step's second half (s < FH), or of the next stage's first half (a stale
+                        // read behind the last step)
+                        const float *X = s < FH ? Xc + 2 * (s + FH) * RW_P : Xn + 2 * (s - FH) * RW_P;
+                        F0[f] = X[0];
+                        F1[f] = X[32];
+                        F0[f + 1] = X[2 * RW_P];
+                        F1[f + 1] = X[2 * RW_P + 32];
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the refills right behind them
+                }
+                rw_wait_vmcnt(2 * (issued - 1 - (st + 2)));  // step st + 2 has landed: only the steps behind it may be out
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of stages st, st + 1 have returned
+                if (!(abl & 2)) __syncthreads();
+                ++st;
+            }
+        }
+        // C/D layout: column = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (output channel); a store = a
+        // scalar row base + this lane's 32-bit offset
+        {
+            const long p0 = (long)cur_p * RW_P;
+            float *dst = out + ((long)cur_b * PW_CO + co0) * HW + p0;
+            const unsigned voff = (unsigned)((long)(4 * kk) * HW + l31);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                if (p0 + pb * 32 + l31 < HW) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2);
+                        float v = (acc[pb][0][r] + acc[pb][1][r]) + bsh[wave * 32 + row + 4 * kk];
+                        if (relu_out) v = fmaxf(v, 0.0f);
+                        if (!(abl & 1)) (dst + (long)row * HW + pb * 32)[voff] = v;
+                    }
+                }
+            }
+            if (++cur_p == tpp) {
+                cur_p = 0;
+                ++cur_b;
+            }
+            // stores count in vmcnt too and return out of order with loads: drain them before the next counted wait
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int manet_relu_conv1x1_c1_f32(const float *in, int B, int C, long HW, const float *weight, const float *bias,
@@ -659,6 +830,22 @@ extern "C" int manet_conv1x1_head_f32(const float *in, int64_t in_batch_stride, 
         return manet_set_error(MANET_E_INVALID, "Cin=%d and HW=%lld must be multiples of 4 (16-byte LDS-DMA rows)", Cin, (long long)HW);
     if (((size_t)w2t & 15) != 0 || ((size_t)in & 15) != 0 || (in_batch_stride & 3) != 0)
         return manet_set_error(MANET_E_INVALID, "in / w2t must be 16-byte aligned, the batch stride a multiple of 4 elements");
+    // weights resident in registers (conv1x1_rw_kernel) when the layer allows: whole 32-channel stages, no fused output layer
+    if (!head_w && Cin % RW_KC == 0 && Cin <= RW_KMAX && manet_tune_get(MANET_TUNE_CONV1X1, 0) != 1) {
+        const int tpp = (int)((HW + RW_P - 1) / RW_P);
+        const long total = (long)tpp * B;
+        int G = 256;  // pixel-range groups: one per CU; each is served by two workgroups (the output-channel halves)
+        if (total < G) G = (int)total;
+        const unsigned blocks = (unsigned)(((G + 7) / 8) * 16);
+#ifdef MANET_ABLATION
+        const int rw_abl = manet_tune_get(MANET_TUNE_ABLATION, 0);
+#else
+        const int rw_abl = 0;
+#endif
+        hipLaunchKernelGGL(conv1x1_rw_kernel, dim3(blocks), dim3(RW_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin,
+                           (long)HW, w2t, b2, relu_out, out, tpp, (int)total, G, rw_abl);
+        return manet_check_launch("manet_conv1x1_f32 (resident weights)");
+    }
     dim3 grid((unsigned)((HW + PW_P - 1) / PW_P), (unsigned)B);
     hipLaunchKernelGGL(conv1x1_mfma_kernel, grid, dim3(PW_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin, (long)HW,
                        w2t, b2, relu_out, out, head_w, head_b, head_out);

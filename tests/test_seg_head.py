@@ -279,3 +279,34 @@ def _pointwise_module_cases(M, ops, torch):
         ref = head.conv(ref)
         scale = float(ref.abs().max())
         torch.testing.assert_close(head(xs), ref, rtol=1e-3, atol=1e-3 * max(scale, 1.0))
+
+
+@pytest.mark.gpu
+def test_resident_weights_1x1_kernel_against_the_lds_weights_kernel():
+    """r4 conv1x1_rw_kernel (weights in registers, activation through a ring of LDS stages, persistent over pixel ranges) against
+    conv1x1_mfma_kernel: both are fp32 fmaf chains on v_mfma_f32_32x32x2_f32 + folded bias [+ ReLU] (one k-ascending chain
+    there, two k-interleaved ones here), on whole and partial last tiles, 1..3 batch items, Cin = 32 .. 256, tiny planes (fewer tiles than CUs)."""
+    import os
+    import torch
+    from cvpr2020_manet_amd import _lib, ops
+    lib = _lib.load()
+    os.environ["MANET_TUNING"] = "1"
+    g = torch.Generator(device="cuda").manual_seed(11)
+    try:
+        for (B, cin, h, w, relu) in ((3, 256, 120, 214, False), (2, 256, 30, 54, True), (1, 32, 4, 16, False), (3, 64, 21, 36, True),
+                                     (1, 128, 9, 12, False), (2, 96, 7, 20, True), (1, 256, 1, 4, False)):
+            x = torch.randn(B, cin, h, w, generator=g, device="cuda")
+            w2t = torch.randn(cin, 256, generator=g, device="cuda") * 0.1
+            b2 = torch.randn(256, generator=g, device="cuda")
+            _lib.check(lib.manet_tune_set(8, 1), "manet_tune_set")       # the LDS-weights kernel
+            want = ops.conv1x1_mfma(x, w2t, b2, relu_out=relu)
+            _lib.check(lib.manet_tune_set(8, -2 ** 31), "manet_tune_set")  # automatic: resident weights where it applies
+            got = ops.conv1x1_mfma(x, w2t, b2, relu_out=relu)
+            # (the resident-weights kernel sums even and odd k-steps in two chains: the same fp32 products, another summation
+            # order -- a few ulp of the accumulated magnitude, not bit for bit)
+            scale = float(x.abs().max() * w2t.abs().max()) * cin
+            assert float((got - want).abs().max()) <= 4e-7 * scale, (B, cin, h, w)
+            ref = torch.nn.functional.conv2d(x, w2t.t().reshape(256, cin, 1, 1).contiguous(), b2)
+            torch.testing.assert_close(got, ref.relu() if relu else ref, rtol=2e-4, atol=2e-4)
+    finally:
+        lib.manet_tune_set(8, -2 ** 31)
