@@ -78,6 +78,7 @@ SIGNATURES = {
     "manet_frame_workspace_bytes": (_i, [_i, _i, _i, _i, _i, _szp]),
     "manet_frame_prepare": (_i, [_vp, _i, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i64,
                                  ctypes.c_uint32, _vp]),
+    "manet_embed_finish": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "manet_local_match_frames": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "manet_profile_read": (_i, [_i, ctypes.POINTER(ctypes.c_float), _i, _ip]),
     "manet_correlation_backward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

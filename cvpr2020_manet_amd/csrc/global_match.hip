@@ -528,6 +528,11 @@ struct FramePrep {
     long fill_words;
     unsigned fill_value;
     int n_data, nxc;
+    // manet_embed_finish: the embedding layer's epilogue in front of the staging -- y = relu(x * scale[c] + shift[c]), rounded to
+    // the embedding's storage type, written to emb_out [frame][C][h][w] -- `emb` then is the 1x1 convolution's raw fp32 output
+    const float *scale, *shift;
+    void *emb_out;
+    int emb_out_bf16, relu;
     int vec2;   // s_x == 1, even w / strides, aligned base: two pixels per load
     int rcopy;  // fp32 source + MANET_COMPUTE_BF16: LDS also holds a bf16-rounded copy
     int abl;  // -DMANET_ABLATION builds, timing experiments: 1 no loads, 2 no plane stores, 4 no image stores, 8 no norm chain, 16 no data blocks, 32 no aux blocks
@@ -604,7 +609,8 @@ __global__ __launch_bounds__(256) void frame_prepare_kernel(const FramePrep A)
     float *rq = A.rcopy ? rows + (long)PIX * KP : rows;
     const int rp = blockIdx.x / A.nxc, cx = blockIdx.x - rp * A.nxc;
     const int x0 = cx * XC, y0 = 2 * rp;
-    const bool bf16_exact = (A.compute == MANET_COMPUTE_BF16) && (A.rcopy || sizeof(SRC) == 2);  // rq holds bf16-exact values
+    // rq holds bf16-exact values (a 2-byte source, the rounded copy, or the embedding epilogue's 2-byte output)
+    const bool bf16_exact = (A.compute == MANET_COMPUTE_BF16) && (A.rcopy || sizeof(SRC) == 2 || (A.scale && A.emb_out_bf16));
     // The launch is LATENCY-bound, not bandwidth-bound (1.6 workgroups per CU, 27 MB per frame; ablations in DESIGN 3.3): every
     // load of the workgroup is issued before the first one is waited for -- one memory round trip per workgroup.
     if (A.vec2) {  // two horizontally adjacent pixels per lane (8-byte / 4-byte loads): half the load instructions
@@ -630,6 +636,24 @@ __global__ __launch_bounds__(256) void frame_prepare_kernel(const FramePrep A)
                     } else {
                         const unsigned t = *(const unsigned *)a;
                         va[j] = bf2f(t & 0xffffu); vb[j] = bf2f(t >> 16);
+                    }
+                }
+                if (sizeof(SRC) == 4 && A.scale) {  // the embedding layer's epilogue (block-uniform)
+#pragma unroll
+                    for (int j = 0; j < KB; ++j) {
+                        const int k = k0 + j * NKQ, kc = k < C ? k : C - 1;
+                        const float sc = A.scale[kc], sh = A.shift[kc];
+                        float a = fmaf(va[j], sc, sh), b = fmaf(vb[j], sc, sh);
+                        if (A.relu) { a = fmaxf(a, 0.0f); b = fmaxf(b, 0.0f); }
+                        const long eo = (((long)blockIdx.z * C + kc) * A.h + (y < A.h ? y : A.h - 1)) * A.w + (x < A.w ? x : A.w - 2);
+                        if (A.emb_out_bf16) {
+                            const unsigned ba = f2bf(a), bb = f2bf(b);
+                            a = bf2f(ba); b = bf2f(bb);  // the operands are made from the embedding AS STORED
+                            if (in && k < C) *(unsigned *)((unsigned short *)A.emb_out + eo) = ba | (bb << 16);
+                        } else if (in && k < C) {
+                            *(float2 *)((float *)A.emb_out + eo) = float2{a, b};
+                        }
+                        va[j] = a; vb[j] = b;
                     }
                 }
 #pragma unroll
@@ -662,6 +686,23 @@ __global__ __launch_bounds__(256) void frame_prepare_kernel(const FramePrep A)
                 for (int j = 0; j < KB; ++j) {
                     const int k = k0 + j * NKQ;
                     v[j] = emb_load(sp, (long)(k < C ? k : C - 1) * sc_);
+                }
+                if (sizeof(SRC) == 4 && A.scale) {  // the embedding layer's epilogue (block-uniform)
+#pragma unroll
+                    for (int j = 0; j < KB; ++j) {
+                        const int k = k0 + j * NKQ, kc = k < C ? k : C - 1;
+                        float a = fmaf(v[j], A.scale[kc], A.shift[kc]);
+                        if (A.relu) a = fmaxf(a, 0.0f);
+                        const long eo = (((long)blockIdx.z * C + kc) * A.h + (y < A.h ? y : A.h - 1)) * A.w + (x < A.w ? x : A.w - 1);
+                        if (A.emb_out_bf16) {
+                            const unsigned ba = f2bf(a);
+                            a = bf2f(ba);
+                            if (in && k < C) ((unsigned short *)A.emb_out)[eo] = (unsigned short)ba;
+                        } else if (in && k < C) {
+                            ((float *)A.emb_out)[eo] = a;
+                        }
+                        v[j] = a;
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < KB; ++j) {
@@ -2754,9 +2795,35 @@ int manet_frame_workspace_bytes(int h, int w, int C, int compute, int max_distan
     return MANET_OK;
 }
 
+static int frame_prepare_impl(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y, int64_t s_x, int64_t s_c, int n_frames,
+                              int h, int w, int C, int compute, int max_distance, void *frames_ws, size_t frame_ws_stride,
+                              void *fill_ptr, int64_t fill_words, uint32_t fill_value, const float *scale, const float *shift,
+                              int relu, void *emb_out, int emb_out_dtype, manet_stream_t stream);
+
 int manet_frame_prepare(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y, int64_t s_x, int64_t s_c, int n_frames,
                         int h, int w, int C, int compute, int max_distance, void *frames_ws, size_t frame_ws_stride,
                         void *fill_ptr, int64_t fill_words, uint32_t fill_value, manet_stream_t stream)
+{
+    return frame_prepare_impl(emb, emb_dtype, s_f, s_y, s_x, s_c, n_frames, h, w, C, compute, max_distance, frames_ws,
+                              frame_ws_stride, fill_ptr, fill_words, fill_value, nullptr, nullptr, 0, nullptr, MANET_EMB_F32, stream);
+}
+
+int manet_embed_finish(const float *conv_out, int64_t s_f, int64_t s_y, int64_t s_x, int64_t s_c, const float *scale,
+                       const float *shift, int relu, void *emb_out, int emb_out_dtype, int n_frames, int h, int w, int C,
+                       int compute, int max_distance, void *frames_ws, size_t frame_ws_stride, manet_stream_t stream)
+{
+    if (!scale || !shift || !emb_out) return manet_set_error(MANET_E_INVALID, "null pointer");
+    if (emb_out_dtype != MANET_EMB_F32 && emb_out_dtype != MANET_EMB_BF16)
+        return manet_set_error(MANET_E_INVALID, "embedding dtype %d (MANET_EMB_F32 / MANET_EMB_BF16)", emb_out_dtype);
+    if (((size_t)emb_out & 7) != 0) return manet_set_error(MANET_E_INVALID, "emb_out must be 8-byte aligned");
+    return frame_prepare_impl(conv_out, MANET_EMB_F32, s_f, s_y, s_x, s_c, n_frames, h, w, C, compute, max_distance, frames_ws,
+                              frame_ws_stride, nullptr, 0, 0u, scale, shift, relu, emb_out, emb_out_dtype, stream);
+}
+
+static int frame_prepare_impl(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y, int64_t s_x, int64_t s_c, int n_frames,
+                              int h, int w, int C, int compute, int max_distance, void *frames_ws, size_t frame_ws_stride,
+                              void *fill_ptr, int64_t fill_words, uint32_t fill_value, const float *scale, const float *shift,
+                              int relu, void *emb_out, int emb_out_dtype, manet_stream_t stream)
 {
     size_t need = 0;
     int rc = manet_frame_workspace_bytes(h, w, C, compute, max_distance, &need);
@@ -2799,7 +2866,10 @@ int manet_frame_prepare(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y
     const size_t esz = emb_dtype == MANET_EMB_F32 ? 4 : 2;
     A.vec2 = (s_x == 1 && (w & 1) == 0 && (s_y & 1) == 0 && (s_c & 1) == 0 && (n_frames == 1 || (s_f & 1) == 0) &&
               ((size_t)emb % (2 * esz)) == 0) ? 1 : 0;
-    A.rcopy = (emb_dtype == MANET_EMB_F32 && G.compute == MANET_COMPUTE_BF16) ? 1 : 0;
+    A.scale = scale; A.shift = shift; A.relu = relu; A.emb_out = emb_out; A.emb_out_bf16 = (scale && emb_out_dtype == MANET_EMB_BF16) ? 1 : 0;
+    // (the epilogue form stores 2-pixel pairs: emb_out rows must pair up as the source's do)
+    if (scale && (w & 1)) A.vec2 = 0;
+    A.rcopy = (emb_dtype == MANET_EMB_F32 && G.compute == MANET_COMPUTE_BF16 && !A.emb_out_bf16) ? 1 : 0;
     const size_t lds = (size_t)(A.rcopy ? 2 : 1) * 2 * XC * (G.kpad + 1) * sizeof(float) + 2 * XC * sizeof(float);
     const dim3 grid((unsigned)(A.n_data + aux), 1, (unsigned)n_frames);
     hipStream_t st = (hipStream_t)stream;

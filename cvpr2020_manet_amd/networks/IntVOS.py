@@ -382,8 +382,9 @@ def _obj_ids(n_ids, device):
 MAX_CLIP_FRAMES = 104       # hard-coded clip length of the reference's memories (IntVOS.py:617,645)
 MAX_INTERACTIONS = 9        # IntVOS.py:641,645
 MAX_CACHED_FRAMES = 2 * MAX_CLIP_FRAMES + 8  # most prepared per-frame operands a model ever keeps (17 MB each at 480p)
-DEFAULT_CACHED_FRAMES = 4   # ... and what it keeps unless the driver prepared a clip up front (prepare_clip /
-                            # extract_feature(packed=True)): enough for test.py:259's cur -> prev hand-over + the annotated frame
+DEFAULT_CACHED_FRAMES = 8   # ... and what it keeps unless the driver prepared a clip up front (prepare_clip /
+                            # extract_feature(packed=True)): test.py:259's cur -> prev hand-over, the annotated frames of a few
+                            # rounds (136 MB at 480p; r3 kept up to 216 frames of every tensor that ever came by: ADVICE r3)
 MAX_CACHED_BANKS = 2        # prepared memory banks kept per model (one per sequence name)
 _EMB_DTYPES = {"f32": torch.float32, "fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
                "bfloat16": torch.bfloat16, torch.float32: torch.float32, torch.bfloat16: torch.bfloat16}
@@ -530,7 +531,8 @@ class IntVOS(nn.Module):
         if embeddings.shape[0] == 0 or self._frame_key(embeddings[0], d) is None:  # inference tensors: nothing to key on
             return embeddings
         # opting in to the clip-sized cache: room for this clip's frames (+ the default few), at most MAX_CACHED_FRAMES
-        self._frame_cache_cap = min(MAX_CACHED_FRAMES, max(self._frame_cache_cap, embeddings.shape[0] + DEFAULT_CACHED_FRAMES))
+        self._frame_cache_cap = min(MAX_CACHED_FRAMES, max(self._frame_cache_cap,
+                                                           len(self._frame_cache) + embeddings.shape[0] + DEFAULT_CACHED_FRAMES))
         for i0 in range(0, embeddings.shape[0], batch):
             chunk = embeddings[i0:i0 + batch]
             for j, fr in enumerate(ops.prepare_frames(chunk, compute=self.compute, max_distance=d)):
@@ -595,6 +597,28 @@ class IntVOS(nn.Module):
         worthwhile when the caller keeps using THIS tensor's frames (a `torch.cat` of several batches copies them to new
         storage -- then call prepare_clip on the concatenated tensor instead)."""
         x = self.feature_extracter(x)
+        if (packed and x.is_cuda and not self.training and not torch.is_grad_enabled() and self.cache_frames
+                and x.dtype == torch.float32):
+            # the embedding layer's epilogue fused with the frame prepare (ops.embed_finish): bn2 + relu2 + the storage cast +
+            # the operands of every frame of the batch in ONE launch behind the framework's 1x1 GEMM -- the embedding is
+            # written once and never re-read for packing (r3: three elementwise passes, then manet_frame_prepare's re-read)
+            y = self.embedding_conv(self.relu1(self.bn1(self.seperate_conv(x))))
+            scale, shift = ops.fold_bn(self.bn2)
+            d = self._local_radius()
+            emb, frames = ops.embed_finish(y, scale, shift, relu=True, emb_dtype=self.emb_dtype, compute=self.compute,
+                                           max_distance=d)
+            # (opting in to the clip-sized cache: room for what is cached already + this batch)
+            self._frame_cache_cap = min(MAX_CACHED_FRAMES, max(self._frame_cache_cap,
+                                                               len(self._frame_cache) + emb.shape[0] + DEFAULT_CACHED_FRAMES))
+            for i, fr in enumerate(frames):
+                e = emb[i]
+                key = self._frame_key(e, d)
+                if key is not None:
+                    fr.keep = e
+                    self._frame_cache[key] = fr
+            while len(self._frame_cache) > self._frame_cache_cap:
+                self._frame_cache.popitem(last=False)
+            return emb
         x = self.semantic_embedding(x)
         if x.dtype != self.emb_dtype and not (torch.is_grad_enabled() and x.requires_grad):
             x = x.to(self.emb_dtype)

@@ -365,6 +365,37 @@ def prepare_frames(embeddings, compute="f32", max_distance=-1, preset=None, pres
     return frames[0] if single else frames
 
 
+def embed_finish(conv_out, scale, shift, relu=True, emb_dtype=torch.float32, compute="f32", max_distance=-1):
+    """manet_embed_finish: the embedding layer's epilogue fused with the frame prepare (IntVOS.py:537-543, :578-581).
+    conv_out [B, C, h, w] float32 = embedding_conv's raw output; scale / shift [C] = eval-mode bn2 folded (ops.fold_bn).
+    ONE launch -> (embedding [B, C, h, w] in emb_dtype = relu(conv_out * scale + shift), list of PreparedFrames made from the
+    embedding as stored -- bit-identical to prepare_frames(embedding))."""
+    lib = _lib.load()
+    _need_gpu(conv_out, "conv_out")
+    _refuse_autograd("embed_finish", conv_out, scale, shift)
+    if conv_out.dim() != 4 or conv_out.dtype != torch.float32:
+        raise ValueError("conv_out must be float32 [B, C, h, w]")
+    B, C, h, w = conv_out.shape
+    if emb_dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("emb_dtype must be torch.float32 or torch.bfloat16")
+    scale, shift = scale.detach().float().contiguous(), shift.detach().float().contiguous()
+    if scale.numel() != C or shift.numel() != C:
+        raise ValueError("scale / shift must have C elements")
+    cmp_ = COMPUTE[compute]
+    emb = torch.empty((B, C, h, w), dtype=emb_dtype, device=conv_out.device)
+    if B == 0:
+        return emb, []
+    per = frame_workspace_bytes(h, w, C, compute, max_distance)
+    ws = torch.empty((B, per), dtype=torch.uint8, device=conv_out.device)
+    with torch.cuda.device(conv_out.device):
+        rc = lib.manet_embed_finish(conv_out.data_ptr(), conv_out.stride(0), conv_out.stride(2), conv_out.stride(3),
+                                    conv_out.stride(1), scale.data_ptr(), shift.data_ptr(), int(bool(relu)), emb.data_ptr(),
+                                    _emb_code(emb), B, h, w, C, cmp_, max_distance, ws.data_ptr(), per, _stream_ptr(conv_out.device))
+    _lib.check(rc, "manet_embed_finish")
+    frames = [PreparedFrame(ws[i], h, w, C, cmp_, max_distance, raw=emb[i].permute(1, 2, 0)) for i in range(B)]
+    return emb, frames
+
+
 def local_match_frames(prev_frame, cur_frame, prev_frame_labels, n_ids, out=None, out_is_preset=False):
     """local_previous_frame_nearest_neighbor_features_per_object (IntVOS.py:345-434, downsample configuration) on two
     PreparedFrames: the fused window / min kernel alone -> [h, w, n_ids]; bit-identical to local_match on the

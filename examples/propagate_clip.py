@@ -68,17 +68,44 @@ def build_model(dev, compute=None, emb_dtype=None, pointwise=None, seed=0):
     return cfg, model
 
 
-def synthetic_clip(model, dev, n_frames, H, W, nobj, frames=None, seed=1):
+def synthetic_clip(model, dev, n_frames, H, W, nobj, frames=None, seed=1, batch=14, packed=False):
     """embeddings of the clip's frames `frames` (default: all) -- images drawn from a per-frame seed, so that every rank
-    of a clip-parallel run produces the same frame -- and the scribble of the annotated frame at grid resolution"""
-    frames = range(n_frames) if frames is None else frames
+    of a clip-parallel run produces the same frame.  Extracted in batches as test.py:143-154 does (batch 14); packed=True: the
+    embedding layer's fused epilogue (ops.embed_finish) also leaves every frame's operands in the model's cache -- the
+    batches then are NOT concatenated (a cat would copy them to storage the cache does not know): a list-backed view is
+    returned instead."""
+    frames = list(range(n_frames) if frames is None else frames)
     embs = []
     with torch.no_grad():
-        for i in frames:
-            g = torch.Generator(device=dev).manual_seed(1000 * seed + i)
-            embs.append(model.extract_feature(torch.randn(1, 3, H, W, generator=g, device=dev)))
-    emb = torch.cat(embs, 0) if embs else None
-    return emb
+        for i0 in range(0, len(frames), batch):
+            imgs = []
+            for i in frames[i0:i0 + batch]:
+                g = torch.Generator(device=dev).manual_seed(1000 * seed + i)
+                imgs.append(torch.randn(1, 3, H, W, generator=g, device=dev))
+            embs.append(model.extract_feature(torch.cat(imgs, 0), packed=packed))
+    if not embs:
+        return None
+    if packed and len(embs) > 1:
+        return BatchedClip(embs)
+    return embs[0] if len(embs) == 1 else torch.cat(embs, 0)
+
+
+class BatchedClip:
+    """[F, C, h, w] embeddings kept as the extraction batches they were produced in (frame i = batches[i // B][i % B]): indexing
+    and one-frame slices return views of the batch tensors, whose identity the model's frame cache is keyed on"""
+
+    def __init__(self, batches):
+        self.batches = batches
+        self.B = batches[0].shape[0]
+        self.shape = (sum(b.shape[0] for b in batches),) + tuple(batches[0].shape[1:])
+        self.device, self.dtype = batches[0].device, batches[0].dtype
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            start, stop, step = idx.indices(self.shape[0])
+            assert step == 1 and stop - start == 1, "one-frame slices only"
+            return self.batches[start // self.B][start % self.B:start % self.B + 1]
+        return self.batches[idx // self.B][idx % self.B]
 
 
 def make_scribble(dev, eh, ew, nobj):
@@ -265,8 +292,9 @@ def run_single(args, dev, pointwise=None, want_graph=False, want_stages=False):
     """one process, one GPU: eager (and graph) frames/s of the end-to-end propagated frame"""
     cfg, model = build_model(dev, args.compute, args.emb_dtype, pointwise if pointwise is not None else args.pointwise)
     with torch.no_grad():
-        emb = synthetic_clip(model, dev, args.frames, args.height, args.width, args.objects)
-        if args.prepare_clip:
+        # (the producer's fused epilogue: embeddings + every frame's operands from one launch per extraction batch)
+        emb = synthetic_clip(model, dev, args.frames, args.height, args.width, args.objects, packed=not args.no_packed)
+        if args.prepare_clip and not isinstance(emb, BatchedClip):
             emb = model.prepare_clip(emb)
         clip = Clip(cfg, model, emb, args.height, args.width, args.objects, fused_mask_step=args.fused_mask_step)
         final, dt = clip.timed_round()
@@ -384,6 +412,9 @@ def parse_args(argv=None):
     ap.add_argument("--emb-dtype", type=str, default=None, help="storage of the embeddings (f32 | bf16)")
     ap.add_argument("--prepare-clip", action="store_true",
                     help="prepare every frame's operands up front (model.prepare_clip) instead of on first use")
+    ap.add_argument("--no-packed", action="store_true",
+                    help="extract the embeddings through the stock module chain (bn2, relu2, cast as separate passes; frames "
+                         "prepared on first use) instead of the fused embedding epilogue (extract_feature(packed=True))")
     ap.add_argument("--stages", action="store_true", help="per-stage microseconds of a propagated frame (HIP events)")
     ap.add_argument("--gpus", type=int, default=1, help="clip-parallel propagation over N ranks (module docstring)")
     ap.add_argument("--json", action="store_true", help="print the result as one JSON line")

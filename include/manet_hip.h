@@ -175,6 +175,17 @@ int manet_frame_prepare(const void *emb, int emb_dtype, int64_t s_f, int64_t s_y
                         size_t frame_ws_stride, void *fill_ptr, int64_t fill_words, uint32_t fill_value,
                         manet_stream_t stream);
 
+/* The embedding layer's epilogue fused with manet_frame_prepare (IntVOS.py:537-543, :578-581): `conv_out`
+ * is the raw fp32 output of the 1x1 embedding convolution (embedding_conv, bias included), n_frames x [h][w][C] with element
+ * strides as above.  One launch computes y = relu(x * scale[c] + shift[c]) (eval-mode bn2 folded by the caller + relu2),
+ * stores the embedding in emb_out [n_frames][C][h][w] in emb_out_dtype storage (MANET_EMB_F32 / MANET_EMB_BF16, contiguous,
+ * 8-byte aligned) and, from the same registers, the frames' operands -- exactly what manet_frame_prepare would make from the
+ * embedding AS STORED.  The batch-norm, ReLU, storage-cast and prepare launches of the producer (three elementwise passes and a
+ * re-read of the embedding) collapse into this one. */
+int manet_embed_finish(const float *conv_out, int64_t s_f, int64_t s_y, int64_t s_x, int64_t s_c, const float *scale,
+                       const float *shift, int relu, void *emb_out, int emb_out_dtype, int n_frames, int h, int w, int C,
+                       int compute, int max_distance, void *frames_ws, size_t frame_ws_stride, manet_stream_t stream);
+
 /* MANET_COMPUTE_BF16_REFINE on a prepared bank when the query's packed image exists already (manet_frame_prepare /
  * manet_query_pack with MANET_COMPUTE_BF16 or _BF16_REFINE): the fp32 re-rank also needs the query as stored, so this entry
  * point takes both.  query_image == NULL: same as manet_global_match_prepared_ex(..., MANET_COMPUTE_BF16_REFINE, ...).

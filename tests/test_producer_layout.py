@@ -95,3 +95,86 @@ def test_module_prepares_the_bank_once_per_interaction(ops):
         model.prop_seghead(embs[0:1], embs[0:1], embs[1:2], scrib, prev_label, True, True, ["s"], torch.Tensor([1]), 1, gmap,
                            None, 1, 0, [1], model.dynamic_seghead)
         assert model._bank_cache["s"][1] is not seen[0]
+
+
+@pytest.mark.parametrize("storage", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("compute", ["f32", "bf16", "bf16r", "bf16x3"])
+@pytest.mark.parametrize("shape,d", [((3, 100, 120, 214), 12), ((2, 100, 21, 30), 4), ((1, 100, 12, 15), 2), ((2, 37, 9, 16), -1)])
+def test_embed_finish_is_bn_relu_cast_plus_frame_prepare_in_one_launch(ops, storage, compute, shape, d):
+    """manet_embed_finish: eval-mode bn2 + relu2 + the storage cast + manet_frame_prepare behind the
+    framework's 1x1 embedding GEMM (IntVOS.py:537-543).  The embedding it stores equals the stock elementwise chain (BatchNorm
+    folded into one fmaf: a rounding of the last place); the frame operands are BIT-IDENTICAL to manet_frame_prepare run on
+    that stored embedding (so everything downstream -- global match, local match -- is the separate route's bits)."""
+    B, C, h, w = shape
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + h)
+    conv_out = torch.randn(B, C, h, w, generator=g, device="cuda") * 0.3
+    bn = torch.nn.BatchNorm2d(C).cuda().eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.2, generator=g); bn.running_var.uniform_(0.5, 2.0, generator=g)
+        bn.weight.normal_(1, 0.2, generator=g); bn.bias.normal_(0, 0.2, generator=g)
+        want = torch.relu(bn(conv_out)).to(storage)
+        scale, shift = ops.fold_bn(bn)
+        emb, frames = ops.embed_finish(conv_out, scale, shift, relu=True, emb_dtype=storage, compute=compute, max_distance=d)
+    assert emb.dtype == storage and emb.shape == conv_out.shape and len(frames) == B
+    # folded BatchNorm: one fmaf instead of (x - mean) * invstd * weight + bias -- last-place differences, one bf16 ulp after rounding
+    tol = dict(rtol=1e-5, atol=1e-6) if storage == torch.float32 else dict(rtol=2 ** -7, atol=1e-6)
+    torch.testing.assert_close(emb.float(), want.float(), **tol)
+    ref_frames = ops.prepare_frames(emb, compute=compute, max_distance=d)
+    _same_operands(ops, frames, ref_frames, emb, compute, d)
+    # a strided batch view of the conv output (channels-last-like storage) goes through the generic-stride path
+    conv_cl = conv_out.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    emb2, frames2 = ops.embed_finish(conv_cl, scale, shift, relu=True, emb_dtype=storage, compute=compute, max_distance=d)
+    assert torch.equal(emb2, emb)
+    _same_operands(ops, frames2, ref_frames, emb, compute, d)
+
+
+def _same_operands(ops, frames, ref_frames, emb, compute, d):
+    """two sets of prepared frames carry the same operands: the global match against one bank and the local match between
+    neighbouring frames give the same bits (the workspaces' alignment gaps are never written, so bytes cannot be compared)"""
+    B, C, h, w = emb.shape
+    g = torch.Generator(device="cuda").manual_seed(99)
+    n_ids = 3
+    bank_rows = (torch.relu(torch.randn(700, C, generator=g, device="cuda")) * 0.3).to(emb.dtype)
+    bank_lab = torch.randint(0, n_ids, (700,), generator=g, device="cuda", dtype=torch.int32)
+    bank = ops.PreparedBank(bank_rows, bank_lab, n_ids, compute=compute)
+    lab = torch.randint(0, n_ids, (h, w), generator=g, device="cuda", dtype=torch.int32)
+    for i, (a, b) in enumerate(zip(frames, ref_frames)):
+        assert torch.equal(bank.match(a), bank.match(b)), "query operand image"
+        if d >= 0:
+            j = (i + 1) % B
+            assert torch.equal(ops.local_match_frames(frames[j], a, lab, n_ids), ops.local_match_frames(ref_frames[j], b, lab, n_ids)), "pooled plane"
+
+
+def test_extract_feature_packed_route_feeds_the_frame_cache(ops):
+    """IntVOS.extract_feature(packed=True) in inference: embeddings equal the stock route's (to BatchNorm-folding rounding), every
+    frame's operands are in the model's cache afterwards (no manet_frame_prepare launch in the propagation loop)."""
+    from cvpr2020_manet_amd.config import make_cfg
+    from cvpr2020_manet_amd.networks.IntVOS import IntVOS
+
+    class Enc(torch.nn.Module):
+        def __init__(self, out_dim):
+            super().__init__()
+            self.net = torch.nn.Conv2d(3, out_dim, 3, stride=4, padding=1)
+
+        def forward(self, x):
+            return self.net(x)
+
+    torch.manual_seed(5)
+    cfg = make_cfg(["--TEST_MODE", "True"])
+    for emb_dtype in ("f32", "bf16"):
+        model = IntVOS(cfg, Enc(cfg.MODEL_ASPP_OUTDIM), compute="bf16" if emb_dtype == "bf16" else "f32", emb_dtype=emb_dtype).cuda().eval()
+        with torch.no_grad():
+            for m in (model.bn1, model.bn2):
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 2.0)
+            x = torch.randn(3, 3, 96, 128, device="cuda")
+            stock = model.extract_feature(x)
+            assert len(model._frame_cache) == 0
+            fused = model.extract_feature(x, packed=True)
+            assert fused.dtype == stock.dtype
+            tol = dict(rtol=1e-4, atol=1e-5) if emb_dtype == "f32" else dict(rtol=2 ** -7, atol=1e-5)
+            torch.testing.assert_close(fused.float(), stock.float(), **tol)
+            assert len(model._frame_cache) == 3
+            hit, _ = model._prepared_frame(fused[1])
+            assert len(model._frame_cache) == 3  # (a hit: nothing new was prepared)
+            fresh = ops.prepare_frames(fused, compute=model.compute, max_distance=model._local_radius())
+            _same_operands(ops, [model._prepared_frame(fused[i])[0] for i in range(3)], fresh, fused, model.compute, model._local_radius())
