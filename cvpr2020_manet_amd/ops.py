@@ -251,6 +251,10 @@ class PreparedBank:
                                                         self.ws.data_ptr(), N, self.M0, C, self.n_ids,
                                                         k_nearest_neighbors, self.compute, out.data_ptr(), mem_ptr,
                                                         flags, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+        if rc != 0 and armed:
+            # the armed workspace is only all-0xff again once the finish kernel has run: after a failed call nothing is
+            # known about it -- drop it, the next armed call fills a fresh one
+            _ws_cache.pop((dev.index, _stream_ptr(dev), "match_armed"), None)
         _lib.check(rc, "manet_global_match_prepared_ex")
         return out
 
