@@ -26,4 +26,8 @@ tools/e2e_launch_count.sh $R/e2e > gpurun_out/$R/${R}_e2e.log 2>&1
 cp gpurun_out/$R/e2e/per_frame_kernels.csv gpurun_out/$R/${R}_e2e_per_frame_kernels.csv
 tail -3 gpurun_out/$R/${R}_e2e.log
 python tools/pw_bench.py > gpurun_out/$R/${R}_head_pointwise.log 2>&1
+python tools/pw_rw_bench.py >> gpurun_out/$R/${R}_head_pointwise.log 2>&1
 tail -8 gpurun_out/$R/${R}_head_pointwise.log
+python tools/frame_prep_bench.py > gpurun_out/$R/${R}_frame_prepare.log 2>&1
+python tools/local_kernel_us.py >> gpurun_out/$R/${R}_frame_prepare.log 2>&1
+tail -12 gpurun_out/$R/${R}_frame_prepare.log
