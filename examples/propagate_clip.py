@@ -297,7 +297,7 @@ def run_single(args, dev, pointwise=None, want_graph=False, want_stages=False):
         if args.prepare_clip and not isinstance(emb, BatchedClip):
             emb = model.prepare_clip(emb)
         clip = Clip(cfg, model, emb, args.height, args.width, args.objects, fused_mask_step=args.fused_mask_step)
-        final, dt = clip.timed_round()
+        final, dt = clip.timed_round(rounds=args.rounds)
         res = {"frames": args.frames, "grid": [clip.eh, clip.ew], "objects": args.objects, "pointwise": model.pointwise,
                "compute": model.compute, "eager_ms_per_round": dt * 1e3, "eager_frames_per_s": (args.frames - 1) / dt,
                "mask_digest": mask_digest(final)}
@@ -415,6 +415,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-packed", action="store_true",
                     help="extract the embeddings through the stock module chain (bn2, relu2, cast as separate passes; frames "
                          "prepared on first use) instead of the fused embedding epilogue (extract_feature(packed=True))")
+    ap.add_argument("--rounds", type=int, default=1, help="timed interaction rounds (after one warm-up round)")
     ap.add_argument("--stages", action="store_true", help="per-stage microseconds of a propagated frame (HIP events)")
     ap.add_argument("--gpus", type=int, default=1, help="clip-parallel propagation over N ranks (module docstring)")
     ap.add_argument("--json", action="store_true", help="print the result as one JSON line")
