@@ -421,7 +421,28 @@ def cpu_baseline(wl, bank_rows, bank_lab, gpu_global=None, gpu_local=None):
             break
     t_loc = (time.perf_counter() - t0) / lreps
     frame_s = t_glob / nq * N + t_loc
-    res = {"value": 1.0 / frame_s, "unit": "frames/s", "cores": cores, "kind": "port",
+    # the same global match in the reference's own shape on the host's BLAS (oracle.global_match_blas: torch's CPU GEMM per query
+    # chunk, d materialised, masked min per object) -- VERDICT r3 weak #6: whichever form is faster is the baseline
+    blas = None
+    try:
+        import torch as _t
+        _t.set_num_threads(cores)
+        nb = int(min(N, max(1024, nq // 4)))
+        ref_np, lab_np = bank_rows.float().cpu().numpy(), bank_lab.cpu().numpy()
+        q_np = np.ascontiguousarray(qry.reshape(-1, C)[:nb])
+        orc.global_match_blas(ref_np, q_np[:256], lab_np, wl.n_ids)  # warm-up
+        t0 = time.perf_counter()
+        got_b = orc.global_match_blas(ref_np, q_np, lab_np, wl.n_ids)
+        t_b = time.perf_counter() - t0
+        blas = {"frames_per_s": 1.0 / (t_b / nb * N + t_loc), "query_pixels": nb, "seconds": t_b,
+                "max_abs_dev_from_the_fused_port": float(np.abs(got_b - raw[:nb]).max())}
+    except Exception as e:  # (a baseline, never a reason for the line to fail)
+        blas = {"error": str(e)[:200]}
+    fused_fps = 1.0 / frame_s
+    best = max(fused_fps, blas.get("frames_per_s", 0.0))
+    res = {"value": best, "unit": "frames/s", "cores": cores, "kind": "port",
+           "forms": {"fused_c_port_frames_per_s": fused_fps, "blas_port": blas,
+                     "reported": "blas_port" if best > fused_fps else "fused_c_port"},
            "sample": "global match: %d of %d query pixels x full %d-row bank, %d repetition(s), %.2f s each (scaled "
                      "linearly to the frame); local match d=%d: whole frame, %d repetition(s), %.2f s each; "
                      "oracle/manet_oracle.c, OpenMP on %d threads, distance loop vectorised across bank rows "

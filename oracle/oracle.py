@@ -254,3 +254,31 @@ def dwconv7x7_bn_relu(x, weight, bias=None, scale=None, shift=None, relu=True):
     lib().oracle_dwconv7x7_bn_relu_f32(_ptr(x), B, C, h, w, _ptr(wt), *[None if k is None else _ptr(k) for k in keep],
                                        int(bool(relu)), _ptr(out))
     return out
+
+
+def global_match_blas(reference_embeddings, query_embeddings, reference_labels, n_ids, chunk=1024):
+    """The reference's own formulation of the k = 1 global match on the host's BLAS: per query chunk the dense product
+    x @ y^T (torch's CPU GEMM, all cores), d = (xs + ys) - 2 mm (IntVOS.py:32-39), then the masked minimum per object
+    (IntVOS.py:81-85) -- on a bank pre-sorted by object id, so the mask is a column slice.  The arithmetic ORDER of the GEMM is the
+    library's, not the reference chain's: this is the CPU BASELINE's fast form (bench.py `cpu_baseline`, kind "port": a BLAS-shaped
+    port), not the parity oracle -- results agree with `global_match` to accumulation-order rounding.
+    reference_embeddings [M, C], query_embeddings [N, C] float32, reference_labels [M] int -> float32 [N, n_ids]."""
+    import torch
+    ref = torch.from_numpy(np.ascontiguousarray(_f32(reference_embeddings).reshape(-1, reference_embeddings.shape[-1])))
+    qry = torch.from_numpy(np.ascontiguousarray(_f32(query_embeddings).reshape(-1, query_embeddings.shape[-1])))
+    lab = torch.from_numpy(np.ascontiguousarray(reference_labels).reshape(-1).astype(np.int64))
+    order = torch.argsort(lab, stable=True)
+    lab_s, ref_s = lab[order], ref[order].contiguous()
+    bounds = torch.searchsorted(lab_s, torch.arange(0, n_ids + 1))
+    ys = (ref_s * ref_s).sum(1)[None, :]
+    out = torch.full((qry.shape[0], n_ids), 1e20, dtype=torch.float32)
+    ref_t = ref_s.t().contiguous()
+    for i0 in range(0, qry.shape[0], chunk):
+        x = qry[i0:i0 + chunk]
+        d = (x * x).sum(1, keepdim=True) + ys
+        d.addmm_(x, ref_t, beta=1.0, alpha=-2.0)
+        for o in range(n_ids):
+            a, b = int(bounds[o]), int(bounds[o + 1])
+            if b > a:
+                out[i0:i0 + chunk, o] = d[:, a:b].min(1).values
+    return out.numpy()
