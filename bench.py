@@ -305,6 +305,8 @@ def run_leg(wl, K, Wm, args, lib, use_dist=False, one_shot=False, prepacked=Fals
         step(i, bank, bank_rows, bank_lab, halo)
     barrier()
     elapsed = time.perf_counter() - t0
+    if bank is not None:
+        bank.last_match_forced_exact_timed = getattr(bank, "last_match_forced_exact", False)
     ms, lms = (ctypes.c_float * K)(), (ctypes.c_float * K)()
     nrec, nloc = ctypes.c_int(0), ctypes.c_int(0)
     pms, npr = (ctypes.c_float * (K + 1))(), ctypes.c_int(0)
@@ -579,8 +581,11 @@ def robustness_block(device, lib, args):
                 leg = {"data": data, "scale": scale, "compute": compute, "ms_per_step": r["elapsed"] / K * 1e3,
                        "frames_per_s": K / r["elapsed"], "main_kernel_ms": r["kern_ms"]}
                 q = wl.frame_emb(wl.probe_frame()).permute(1, 2, 0)
-                g = r["bank"].match(ops.prepare_frames(wl.frame_emb(wl.probe_frame()), compute=compute), normalize=True)
+                # (the diagnostic match runs the filter whatever the adaptive policy decided for the timed frames)
+                g = r["bank"].match(ops.prepare_frames(wl.frame_emb(wl.probe_frame()), compute=compute), normalize=True,
+                                    **({"adaptive": False} if compute == "bf16r" else {}))
                 if compute == "bf16r":
+                    leg["timed_frames_skipped_the_filter"] = bool(getattr(r["bank"], "last_match_forced_exact_timed", False))
                     st = r["bank"].refine_stats_full()
                     leg["candidate_rows_per_pair"] = st["candidate_rows_per_pair"]
                     leg["rescued_tile_fraction"] = st["rescued_tile_fraction"]

@@ -75,6 +75,7 @@ SIGNATURES = {
     "manet_global_match_refine_stats": (_i, [_vp, _i64, _i, _i, ctypes.POINTER(ctypes.c_int64),
                                              ctypes.POINTER(ctypes.c_int64)]),
     "manet_global_match_refine_stats2": (_i, [_vp, _i64, _i, _i, ctypes.POINTER(ctypes.c_int64)]),
+    "manet_global_match_refine_rescued_async": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "manet_frame_workspace_bytes": (_i, [_i, _i, _i, _i, _i, _szp]),
     "manet_frame_prepare": (_i, [_vp, _i, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i64,
                                  ctypes.c_uint32, _vp]),
@@ -88,6 +89,7 @@ COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3, COMPUTE_BF16_REFINE = 0, 1, 2, 3
 EMB_F32, EMB_BF16, EMB_PACKED = 0, 1, 2
 EPI_NORMALIZE = 1
 EPI_KEYS_ARMED = 2
+EPI_REFINE_EXACT = 4
 
 _lib = None
 

@@ -2220,6 +2220,45 @@ __global__ void refine_threshold_kernel(const unsigned *__restrict__ keys, const
     slack[i] = sl;       // ... to (smallest bf16 distance they met) + slack: E only shrinks with U
 }
 
+// MANET_EPI_REFINE_EXACT: no filter at all -- every 32-query block is marked incomplete, so the re-rank launch only writes the
+// fp32 query images and the rescue pass (the exact fp32 kernel) takes every tile: the fp32 path's cost + ~0.03 ms, for callers
+// that KNOW (ops.PreparedBank: from the previous frame's rescue share) that the bf16 pass cannot tell these embeddings apart
+__global__ void refine_force_kernel(long N_pad, int n_ids, unsigned *__restrict__ keys2, unsigned long long *__restrict__ stats,
+                                    unsigned *__restrict__ bcnt)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        stats[0] = 0ull;
+        stats[1] = 1ull;
+    }
+    if (i < N_pad / QB) bcnt[i] = 0x80000000u;
+    if (i < (long)n_ids * N_pad) keys2[i] = 0xffffffffu;
+}
+
+// how many 256-query tiles of the last filter pass went through the rescue pass -> out2 = {rescued, tiles} (device memory: the
+// caller copies it out asynchronously and reads it a frame later)
+__global__ void refine_rescued_kernel(const unsigned *__restrict__ bcnt, long tiles, long bucket_cap, int *__restrict__ out2)
+{
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int mine = 0;
+    for (long t = threadIdx.x; t < tiles; t += blockDim.x) {
+        bool need = false;
+        for (int i = 0; i < QT / QB; ++i) {
+            const unsigned raw = bcnt[t * (QT / QB) + i];
+            need = need || (raw >> 31) || (long)raw > bucket_cap;
+        }
+        mine += need ? 1 : 0;
+    }
+    atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out2[0] = cnt;
+        out2[1] = (int)tiles;
+    }
+}
+
 // exact re-rank: one workgroup per bucket of the candidate list (= 32 neighbouring queries, every object), one thread per
 // candidate {pair, bank slot}: the reference's fp32 distance (the oracle's fmaf chains, IntVOS.py:32-39) of that (query,
 // bank row), reduced per pair by atomicMin on the order-preserving key; the usual finish kernel decodes the keys.
@@ -2669,13 +2708,19 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
     uint2 *list = (uint2 *)(mws + ML.off_list);
     unsigned long long *stats = (unsigned long long *)(mws + ML.off_stats);
     unsigned *bcnt = (unsigned *)(mws + ML.off_bcnt);
+    const bool force_exact = (flags & MANET_EPI_REFINE_EXACT) != 0;
+    flags &= ~MANET_EPI_REFINE_EXACT;
+    const long pairs = (long)n_ids * ML.N_pad;
+    if (force_exact) {
+        hipLaunchKernelGGL(refine_force_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, ML.N_pad, n_ids, keys2, stats,
+                           bcnt);
+    } else {
     // 1. pre-pass over the sub-sampled bank -> keys = U
     const int S1 = pick_splits(ML.nQT, BL.T_sub_max, 512);
     tl_bank_bytes_hint = (double)BL.T_sub_max * (double)BL.tile_bytes;  // (block_map_arg: the pre-pass's bank)
     if (ML.G.steps == 2) launch_main_bf16<2, false>(qimg, bws + BL.off_sub_pack, sub_meta, n_ids, ML.nQT, S1, ML.N_pad, keys, st, 3);
     else launch_main_bf16<7, false>(qimg, bws + BL.off_sub_pack, sub_meta, n_ids, ML.nQT, S1, ML.N_pad, keys, st, 3);
     // 2. thresholds; exact keys and counters reset
-    const long pairs = (long)n_ids * ML.N_pad;
     hipLaunchKernelGGL(refine_threshold_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, (const unsigned *)keys,
                        qimg, (long)ML.qblk_bytes, C, meta, N, ML.N_pad, n_ids, thr, slack, keys2, stats, bcnt);
     // 3. filter pass over the whole bank -> candidate list
@@ -2709,6 +2754,7 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
         (void)hipLaunchKernel(fn, dim3((unsigned)(nQT * S)), dim3(256), args, lds, st);
         manet_profile_record(st, false, 0);
     }
+    }  // (!force_exact)
     // 4. exact re-rank of the candidates
     const float *rows = (const float *)(bws + BL.off_rows), *norms = (const float *)(bws + BL.off_norms);
     const dim3 rgrid((unsigned)(ML.N_pad / QB));
@@ -2732,7 +2778,8 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
         // (at most 16 splits: a healthy frame pays for the dispatch of nQT32 x S32 workgroups that return at once -- 7.7 us
         // at 48 splits -- and a full rescue loses ~10 % to the coarser last round)
         int S32 = pick_splits(nQT32, BL.T_max, 512);
-        S32 = S32 > 16 ? 16 : S32;
+        if (!force_exact) S32 = S32 > 16 ? 16 : S32;  // (forced: every tile is matched -- the fp32 kernel's own split count)
+        if (force_exact) manet_profile_record(st, true, 0);
         tl_bank_bytes_hint = (double)BL.T_max * (double)G32.tile_bytes;
         const char *bpack32 = bws + BL.off_pack32;
         switch (G32.steps) {
@@ -2741,6 +2788,7 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
         case 52: launch_rescue_f32_pipe<52>(q32, bpack32, meta, n_ids, nQT32, S32, ML.N_pad, keys2, bcnt, ML.bucket_cap, st); break;
         default: launch_rescue_f32_pipe<64>(q32, bpack32, meta, n_ids, nQT32, S32, ML.N_pad, keys2, bcnt, ML.bucket_cap, st); break;
         }
+        if (force_exact) manet_profile_record(st, false, 0);
     }
     const long total = N * n_ids;
     hipLaunchKernelGGL(global_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, keys2, N, ML.N_pad, n_ids,
@@ -3265,6 +3313,18 @@ int manet_global_match_refine_stats(const void *match_ws, int64_t N, int C, int 
     if (candidates) *candidates = (int64_t)h[0];
     if (list_overflowed) *list_overflowed = (int64_t)h[1];
     return MANET_OK;
+}
+
+int manet_global_match_refine_rescued_async(const void *match_ws, int64_t N, int C, int n_ids, int32_t *out2_device,
+                                            manet_stream_t stream)
+{
+    if (!match_ws || !out2_device) return manet_set_error(MANET_E_INVALID, "null pointer");
+    int rc = check_common(N, 0, C, n_ids, 1, MANET_COMPUTE_BF16_REFINE);
+    if (rc) return rc;
+    MatchLayout ML = match_layout(N, C, n_ids, MANET_COMPUTE_BF16_REFINE, 1);
+    hipLaunchKernelGGL(refine_rescued_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned *)((const char *)match_ws + ML.off_bcnt), (long)(ML.N_pad / QT), (long)ML.bucket_cap, out2_device);
+    return manet_check_launch("manet_global_match_refine_rescued_async");
 }
 
 int manet_global_match_refine_stats2(const void *match_ws, int64_t N, int C, int n_ids, int64_t *stats4)

@@ -187,6 +187,8 @@ class PreparedBank:
         nbytes = ctypes.c_size_t(0)
         _lib.check(lib.manet_bank_workspace_bytes(M0, C, n_ids, self.compute, ctypes.byref(nbytes)),
                    "manet_bank_workspace_bytes")
+        if getattr(reuse, "_adapt", None) is not None:
+            self._adapt = reuse._adapt  # (what the previous bank of this clip learnt about its embeddings carries over)
         old = getattr(reuse, "ws", None)
         if old is not None and old.device == self.device and old.numel() >= nbytes.value:
             self.ws, reuse.ws = old, None
@@ -199,9 +201,17 @@ class PreparedBank:
                                            _stream_ptr(self.device))
         _lib.check(rc, "manet_bank_prepare_ex")
 
-    def match(self, query_embeddings, k_nearest_neighbors=1, normalize=False, mem=None, out=None):
+    # compute="bf16r", adaptive policy: a frame whose filter pass sent more than this share of its query tiles to the rescue
+    # pass (the exact fp32 kernel) cost the filter AND the fp32 kernel; the next ADAPT_FRAMES frames then skip the filter
+    # (MANET_EPI_REFINE_EXACT: the same bits at the fp32 path's cost), after which one frame probes the filter again.
+    ADAPT_SHARE, ADAPT_FRAMES = 0.5, 16
+
+    def match(self, query_embeddings, k_nearest_neighbors=1, normalize=False, mem=None, out=None, adaptive=True):
         """query_embeddings: [..., C] float32 / bfloat16 tensor, or a PackedQuery (operand image made once,
-        e.g. for every frame of a clip right after extract_feature: no per-frame pack pass)"""
+        e.g. for every frame of a clip right after extract_feature: no per-frame pack pass).
+        adaptive (compute="bf16r" only): let the previous frames' rescue share decide whether this frame runs the bf16 filter at
+        all (see ADAPT_SHARE); the result is the fp32 kernel's bit for bit either way.  The share arrives by an asynchronous copy
+        and is read a frame late -- no synchronisation; nothing adapts inside a HIP-graph capture."""
         import ctypes
         lib = _lib.load()
         armed, raw = False, None
@@ -241,6 +251,21 @@ class PreparedBank:
             mem_ptr = mem.data_ptr()
         flags = (_lib.EPI_NORMALIZE if normalize else 0) | (_lib.EPI_KEYS_ARMED if armed else 0)
         self._last = (ws, N)  # (refine_stats)
+        refine = self.compute == _lib.COMPUTE_BF16_REFINE
+        adapt = refine and adaptive and not torch.cuda.is_current_stream_capturing()
+        forced = False
+        if adapt:
+            ad = self.__dict__.setdefault("_adapt", {"host": None, "dev": None, "event": None, "left": 0})
+            if ad["event"] is not None and ad["event"].query():  # the share of a frame or two ago has arrived
+                rescued, tiles = int(ad["host"][0]), int(ad["host"][1])
+                ad["event"] = None
+                if tiles > 0 and rescued > self.ADAPT_SHARE * tiles:
+                    ad["left"] = self.ADAPT_FRAMES
+            forced = ad["left"] > 0
+            if forced:
+                ad["left"] -= 1
+                flags |= _lib.EPI_REFINE_EXACT
+        self.last_match_forced_exact = forced
         with torch.cuda.device(dev):
             if raw is not None:
                 rc = lib.manet_global_match_refine(raw.data_ptr(), _emb_code(raw), raw.stride(0), raw.stride(1), qry.data_ptr(),
@@ -251,6 +276,18 @@ class PreparedBank:
                                                         self.ws.data_ptr(), N, self.M0, C, self.n_ids,
                                                         k_nearest_neighbors, self.compute, out.data_ptr(), mem_ptr,
                                                         flags, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+        if rc == 0 and adapt and not forced and ad["event"] is None:
+            # this frame's rescue share: counted on the device, copied out asynchronously, looked at when it has arrived
+            if ad["dev"] is None or ad["dev"].device != dev:
+                ad["dev"] = torch.zeros(2, dtype=torch.int32, device=dev)
+                ad["host"] = torch.zeros(2, dtype=torch.int32).pin_memory()
+            with torch.cuda.device(dev):
+                rc2 = lib.manet_global_match_refine_rescued_async(ws.data_ptr(), N, C, self.n_ids, ad["dev"].data_ptr(),
+                                                                  _stream_ptr(dev))
+            _lib.check(rc2, "manet_global_match_refine_rescued_async")
+            ad["host"].copy_(ad["dev"], non_blocking=True)
+            ad["event"] = torch.cuda.Event()
+            ad["event"].record()
         if rc != 0 and armed:
             # the armed workspace is only all-0xff again once the finish kernel has run: after a failed call nothing is
             # known about it -- drop it, the next armed call fills a fresh one

@@ -80,6 +80,11 @@ typedef void *manet_stream_t; /* a hipStream_t */
  * holds 0xff bytes throughout (e.g. it filled it once and has only used it for calls with this flag since); the call
  * then skips its fill launch and leaves the workspace in that state again (the epilogue re-arms what it reads). */
 #define MANET_EPI_KEYS_ARMED 2
+/* MANET_COMPUTE_BF16_REFINE only: skip the bf16 filter and let the rescue pass (the exact fp32 kernel) take every query tile --
+ * the same bits at the fp32 path's cost (+ ~0.03 ms), for a caller that knows from the previous frame
+ * (manet_global_match_refine_rescued_async) that the bf16 pass cannot tell these embeddings apart; without it such a frame costs
+ * the filter pass AND the fp32 kernel. */
+#define MANET_EPI_REFINE_EXACT 4
 
 const char *manet_version(void);
 const char *manet_last_error_string(void);
@@ -204,6 +209,10 @@ int manet_global_match_refine_stats(const void *match_ws, int64_t N, int C, int 
  * that went through the rescue pass, [3] = 256-query tiles of the frame -- [2] / [3] is the share of the frame that cost the
  * fp32 kernel's time ON TOP of the filter pass (distribution-dependent: 0 on embeddings the bf16 pass can tell apart). */
 int manet_global_match_refine_stats2(const void *match_ws, int64_t N, int C, int n_ids, int64_t *stats4);
+/* ... and without blocking: a one-workgroup launch on `stream` writes {tiles rescued, tiles} of the last filter pass on `match_ws`
+ * to two int32 of DEVICE memory (copy them out asynchronously, read them a frame later: ops.PreparedBank's adaptive policy). */
+int manet_global_match_refine_rescued_async(const void *match_ws, int64_t N, int C, int n_ids, int32_t *out2_device,
+                                            manet_stream_t stream);
 
 /* Stand-alone normalise / min-merge (IntVOS.py:611-622, :718-723), in place on x[n]
  * (and on mem_inout[n] when not NULL). */

@@ -49,7 +49,7 @@ def test_bf16r_bit_equal_and_rescue_share_at_cfg2_size(kind, scale):
     for qi in (1, 2 * T - 1):  # a frame between two bank frames, and one near the clip's end
         q = emb[qi].permute(1, 2, 0)
         want = ref_bank.match(q)
-        got = bank.match(q)
+        got = bank.match(q, adaptive=False)  # (the filter pass itself: the adaptive policy has its own test below)
         assert torch.equal(got, want), "bf16r must equal the fp32 kernel bit for bit on %s embeddings" % kind
         st = bank.refine_stats_full()
         fracs.append(st["rescued_tile_fraction"])
@@ -81,3 +81,35 @@ def test_plain_bf16_error_on_video_like_embeddings():
     print("plain bf16 vs fp32 on video-like embeddings, normalised maps:", errs)
     assert errs[0.1] < 1e-3
     assert errs[0.3] < 5e-3
+
+
+@pytest.mark.gpu
+def test_bf16r_adaptive_policy_skips_the_filter_on_indistinguishable_embeddings():
+    """ops.PreparedBank.match(adaptive=True): once a frame's rescue share arrives above one half, the next frames skip the bf16
+    filter (MANET_EPI_REFINE_EXACT: the exact fp32 kernel on every tile) -- the worst case costs the fp32 path, not the filter
+    on top of it -- and the result stays the fp32 kernel's bits in both modes.  On distinguishable embeddings nothing is skipped."""
+    from cvpr2020_manet_amd import ops
+    H, W, T, n_ids, C = 120, 214, 3, 2, 100
+    for kind, expect_forced in (("smooth", True), ("video", False)):
+        emb, lab = synth_clip.make_clip(kind, 2 * T + 1, C, H, W, n_ids, scale=0.1, device="cuda", seed=5)
+        bank_idx = list(range(0, 2 * T, 2))
+        rows, labs = emb[bank_idx].permute(0, 2, 3, 1).reshape(-1, C), lab[bank_idx].reshape(-1)
+        ref_bank = ops.PreparedBank(rows, labs, n_ids, compute="f32")
+        bank = ops.PreparedBank(rows, labs, n_ids, compute="bf16r")
+        forced = []
+        for i in range(6):
+            q = emb[1 + 2 * (i % T)].permute(1, 2, 0)
+            got = bank.match(q)
+            forced.append(bank.last_match_forced_exact)
+            torch.cuda.synchronize()  # (lets the asynchronous share of this frame arrive before the next one looks)
+            assert torch.equal(got, ref_bank.match(q)), (kind, i)
+        print(kind, forced)
+        assert forced[0] is False  # the first frame always probes
+        assert any(forced[1:]) == expect_forced
+        # a bank prepared over the old one's workspace inherits what was learnt
+        bank2 = ops.PreparedBank(rows, labs, n_ids, compute="bf16r", reuse=bank)
+        bank2.match(emb[1].permute(1, 2, 0))
+        assert bank2.last_match_forced_exact == expect_forced
+        # adaptive=False always runs the filter
+        bank2.match(emb[1].permute(1, 2, 0), adaptive=False)
+        assert bank2.last_match_forced_exact is False
