@@ -204,7 +204,7 @@ class PreparedBank:
     # compute="bf16r", adaptive policy: a frame whose filter pass sent more than this share of its query tiles to the rescue
     # pass (the exact fp32 kernel) cost the filter AND the fp32 kernel; the next ADAPT_FRAMES frames then skip the filter
     # (MANET_EPI_REFINE_EXACT: the same bits at the fp32 path's cost), after which one frame probes the filter again.
-    ADAPT_SHARE, ADAPT_FRAMES = 0.5, 16
+    ADAPT_SHARE, ADAPT_FRAMES, ADAPT_PROBE_EVERY = 0.5, 16, 4
 
     def match(self, query_embeddings, k_nearest_neighbors=1, normalize=False, mem=None, out=None, adaptive=True):
         """query_embeddings: [..., C] float32 / bfloat16 tensor, or a PackedQuery (operand image made once,
@@ -255,7 +255,7 @@ class PreparedBank:
         adapt = refine and adaptive and not torch.cuda.is_current_stream_capturing()
         forced = False
         if adapt:
-            ad = self.__dict__.setdefault("_adapt", {"host": None, "dev": None, "event": None, "left": 0})
+            ad = self.__dict__.setdefault("_adapt", {"host": None, "event": None, "left": 0, "seen": 0})
             if ad["event"] is not None and ad["event"].query():  # the share of a frame or two ago has arrived
                 rescued, tiles = int(ad["host"][0]), int(ad["host"][1])
                 ad["event"] = None
@@ -276,16 +276,18 @@ class PreparedBank:
                                                         self.ws.data_ptr(), N, self.M0, C, self.n_ids,
                                                         k_nearest_neighbors, self.compute, out.data_ptr(), mem_ptr,
                                                         flags, ws.data_ptr(), ws.numel(), _stream_ptr(dev))
-        if rc == 0 and adapt and not forced and ad["event"] is None:
-            # this frame's rescue share: counted on the device, copied out asynchronously, looked at when it has arrived
-            if ad["dev"] is None or ad["dev"].device != dev:
-                ad["dev"] = torch.zeros(2, dtype=torch.int32, device=dev)
+        if adapt and not forced:
+            ad["seen"] = ad.get("seen", 0) + 1
+        if rc == 0 and adapt and not forced and ad["event"] is None and (ad["seen"] - 1) % self.ADAPT_PROBE_EVERY == 0:
+            # this frame's rescue share: one tiny launch counts it straight into pinned host memory (device-visible), an event
+            # says when it is there -- looked at by a later call, never waited for.  Every ADAPT_PROBE_EVERY-th filtered frame
+            # only: a probe costs ~10 us of stream time, and what the share says changes with the clip, not with the frame.
+            if ad["host"] is None:
                 ad["host"] = torch.zeros(2, dtype=torch.int32).pin_memory()
             with torch.cuda.device(dev):
-                rc2 = lib.manet_global_match_refine_rescued_async(ws.data_ptr(), N, C, self.n_ids, ad["dev"].data_ptr(),
+                rc2 = lib.manet_global_match_refine_rescued_async(ws.data_ptr(), N, C, self.n_ids, ad["host"].data_ptr(),
                                                                   _stream_ptr(dev))
             _lib.check(rc2, "manet_global_match_refine_rescued_async")
-            ad["host"].copy_(ad["dev"], non_blocking=True)
             ad["event"] = torch.cuda.Event()
             ad["event"].record()
         if rc != 0 and armed:

@@ -210,7 +210,8 @@ int manet_global_match_refine_stats(const void *match_ws, int64_t N, int C, int 
  * fp32 kernel's time ON TOP of the filter pass (distribution-dependent: 0 on embeddings the bf16 pass can tell apart). */
 int manet_global_match_refine_stats2(const void *match_ws, int64_t N, int C, int n_ids, int64_t *stats4);
 /* ... and without blocking: a one-workgroup launch on `stream` writes {tiles rescued, tiles} of the last filter pass on `match_ws`
- * to two int32 of DEVICE memory (copy them out asynchronously, read them a frame later: ops.PreparedBank's adaptive policy). */
+ * to two int32 of device-visible memory (device memory, or pinned host memory: then nothing needs copying -- record an event
+ * behind the call and read the two values once it has completed: ops.PreparedBank's adaptive policy). */
 int manet_global_match_refine_rescued_async(const void *match_ws, int64_t N, int C, int n_ids, int32_t *out2_device,
                                             manet_stream_t stream);
 
