@@ -429,7 +429,7 @@ def cpu_baseline(wl, bank_rows, bank_lab, gpu_global=None, gpu_local=None):
     try:
         import torch as _t
         _t.set_num_threads(cores)
-        nb = int(min(N, max(1024, nq // 4)))
+        nb = int(min(N, 2048))
         ref_np, lab_np = bank_rows.float().cpu().numpy(), bank_lab.cpu().numpy()
         q_np = np.ascontiguousarray(qry.reshape(-1, C)[:nb])
         orc.global_match_blas(ref_np, q_np[:256], lab_np, wl.n_ids)  # warm-up

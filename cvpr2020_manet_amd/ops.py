@@ -78,6 +78,23 @@ def _stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(device):
+    """`with _on(dev):` = `with _on(dev):`, minus the guard object when `dev` already is the current device (the
+    usual case: ~4 us of host time per call, 20 calls per propagated frame -- the eager loop is host-bound)"""
+    return _NO_SWITCH if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+
 def _workspace(device, tag, nbytes):
     """Per (device, stream, tag) scratch tensor, grown on demand (torch allocator = plumbing)."""
     key = (device.index, _stream_ptr(device), tag)
@@ -158,7 +175,7 @@ def global_match(reference_embeddings, query_embeddings, reference_labels, n_ids
             raise ValueError("mem must be a contiguous float32 tensor of N*n_ids elements")
         mem_ptr = mem.data_ptr()
     flags = _lib.EPI_NORMALIZE if normalize else 0
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.manet_global_match_ex(qry.data_ptr(), _emb_code(qry), qry.stride(0), qry.stride(1), ref.data_ptr(),
                                        _emb_code(ref), ref.stride(0) if M0 > 0 else C, ref.stride(1) if M0 > 0 else 1,
                                        lab.data_ptr(), N, M0, C, n_ids, k_nearest_neighbors, cmp_,
@@ -194,7 +211,7 @@ class PreparedBank:
             self.ws, reuse.ws = old, None
         else:
             self.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             rc = lib.manet_bank_prepare_ex(ref.data_ptr(), _emb_code(ref), ref.stride(0) if M0 > 0 else C,
                                            ref.stride(1) if M0 > 0 else 1, lab.data_ptr(), M0, C, n_ids,
                                            self.compute, self.ws.data_ptr(), self.ws.numel(),
@@ -266,7 +283,7 @@ class PreparedBank:
                 ad["left"] -= 1
                 flags |= _lib.EPI_REFINE_EXACT
         self.last_match_forced_exact = forced
-        with torch.cuda.device(dev):
+        with _on(dev):
             if raw is not None:
                 rc = lib.manet_global_match_refine(raw.data_ptr(), _emb_code(raw), raw.stride(0), raw.stride(1), qry.data_ptr(),
                                                    self.ws.data_ptr(), N, self.M0, C, self.n_ids, out.data_ptr(), mem_ptr,
@@ -284,7 +301,7 @@ class PreparedBank:
             # only: a probe costs ~10 us of stream time, and what the share says changes with the clip, not with the frame.
             if ad["host"] is None:
                 ad["host"] = torch.zeros(2, dtype=torch.int32).pin_memory()
-            with torch.cuda.device(dev):
+            with _on(dev):
                 rc2 = lib.manet_global_match_refine_rescued_async(ws.data_ptr(), N, C, self.n_ids, ad["host"].data_ptr(),
                                                                   _stream_ptr(dev))
             _lib.check(rc2, "manet_global_match_refine_rescued_async")
@@ -340,7 +357,7 @@ class PackedQuery:
         nbytes = ctypes.c_size_t(0)
         _lib.check(lib.manet_query_pack_bytes(N, C, self.compute, ctypes.byref(nbytes)), "manet_query_pack_bytes")
         self.image = torch.empty(nbytes.value, dtype=torch.uint8, device=qry.device)
-        with torch.cuda.device(qry.device):
+        with _on(qry.device):
             rc = lib.manet_query_pack(qry.data_ptr(), _emb_code(qry), qry.stride(0), qry.stride(1), N, C, self.compute,
                                       self.image.data_ptr(), self.image.numel(), _stream_ptr(qry.device))
         _lib.check(rc, "manet_query_pack")
@@ -399,7 +416,7 @@ def prepare_frames(embeddings, compute="f32", max_distance=-1, preset=None, pres
         import struct
         fill_ptr, fill_words = preset.data_ptr(), preset.numel()
         fill_bits = struct.unpack("<I", struct.pack("<f", float(preset_value)))[0]
-    with torch.cuda.device(emb.device):
+    with _on(emb.device):
         rc = lib.manet_frame_prepare(emb.data_ptr(), _emb_code(emb), emb.stride(0), emb.stride(2), emb.stride(3),
                                      emb.stride(1), B, h, w, C, cmp_, max_distance, ws.data_ptr(), per, fill_ptr,
                                      fill_words, fill_bits, _stream_ptr(emb.device))
@@ -430,7 +447,7 @@ def embed_finish(conv_out, scale, shift, relu=True, emb_dtype=torch.float32, com
         return emb, []
     per = frame_workspace_bytes(h, w, C, compute, max_distance)
     ws = torch.empty((B, per), dtype=torch.uint8, device=conv_out.device)
-    with torch.cuda.device(conv_out.device):
+    with _on(conv_out.device):
         rc = lib.manet_embed_finish(conv_out.data_ptr(), conv_out.stride(0), conv_out.stride(2), conv_out.stride(3),
                                     conv_out.stride(1), scale.data_ptr(), shift.data_ptr(), int(bool(relu)), emb.data_ptr(),
                                     _emb_code(emb), B, h, w, C, cmp_, max_distance, ws.data_ptr(), per, _stream_ptr(conv_out.device))
@@ -458,7 +475,7 @@ def local_match_frames(prev_frame, cur_frame, prev_frame_labels, n_ids, out=None
         out_is_preset = False
     elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != b.h * b.w * n_ids:
         raise ValueError("out must be a contiguous float32 tensor of h*w*n_ids elements")
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.manet_local_match_frames(a.ws.data_ptr(), b.ws.data_ptr(), lab.data_ptr(), b.h, b.w, b.C, b.compute,
                                           n_ids, b.max_distance, out.data_ptr(), int(bool(out_is_preset)),
                                           _stream_ptr(dev))
@@ -480,7 +497,7 @@ def normalize_merge_(x, mem=None, normalize=True):
         if mem.dtype != torch.float32 or not mem.is_contiguous() or mem.numel() != x.numel():
             raise ValueError("mem must be contiguous float32 with x's element count")
         mem_ptr = mem.data_ptr()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.manet_normalize_merge_f32(x.data_ptr(), mem_ptr, x.numel(), int(bool(normalize)),
                                            _stream_ptr(x.device))
     _lib.check(rc, "manet_normalize_merge_f32")
@@ -513,7 +530,7 @@ def local_dist(x, y, max_distance, downsample=True):
                                                ctypes.byref(nbytes)), "manet_local_workspace_bytes")
     ws = _workspace(dev, "local", nbytes.value)
     out = torch.empty((h, w, P * P), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.manet_local_dist_f32(x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), y.data_ptr(),
                                       y.stride(0), y.stride(1), y.stride(2), h, w, C, max_distance,
                                       int(bool(downsample)), out.data_ptr(), ws.data_ptr(), ws.numel(),
@@ -556,7 +573,7 @@ def local_match(prev_frame_embedding, query_embedding, prev_frame_labels, n_ids,
                                                ctypes.byref(nbytes)), "manet_local_workspace_bytes")
     ws = _workspace(dev, "local", nbytes.value)
     out = torch.empty((h, w, n_ids), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.manet_local_match_ex(prev.data_ptr(), prev.stride(0), prev.stride(1), prev.stride(2),
                                       cur.data_ptr(), cur.stride(0), cur.stride(1), cur.stride(2), _emb_code(cur),
                                       lab.data_ptr(), h, w, C, n_ids, max_distance, int(bool(downsample)),
@@ -597,7 +614,7 @@ def correlation_forward(input1, input2, pad_size, kernel_size, max_displacement,
     B, C, H, W = a.shape
     oc, oh, ow = correlation_out_dims(H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
     out = torch.empty((B, oc, oh, ow), dtype=a.dtype, device=a.device)
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         rc = lib.manet_correlation_forward(a.data_ptr(), b.data_ptr(), code, B, C, H, W, pad_size, kernel_size,
                                            max_displacement, stride1, stride2, out.data_ptr(),
                                            _stream_ptr(a.device))
@@ -620,7 +637,7 @@ def upsample_argmax(logits, size, want_small=True):
     H, W = int(size[0]), int(size[1])
     mask = torch.empty((1, H, W), dtype=torch.int64, device=lg.device)
     small = torch.empty((1, 1, h, w), dtype=torch.int32, device=lg.device) if want_small else None
-    with torch.cuda.device(lg.device):
+    with _on(lg.device):
         rc = lib.manet_upsample_argmax(lg.data_ptr(), n_ids, h, w, H, W, mask.data_ptr(),
                                        None if small is None else small.data_ptr(), _stream_ptr(lg.device))
     _lib.check(rc, "manet_upsample_argmax")
@@ -638,7 +655,7 @@ def label_resize_nearest(mask, size):
     H, W = int(m.shape[-2]), int(m.shape[-1])
     h, w = int(size[0]), int(size[1])
     out = torch.empty((1, 1, h, w), dtype=torch.int32, device=m.device)
-    with torch.cuda.device(m.device):
+    with _on(m.device):
         rc = lib.manet_label_resize_nearest(m.data_ptr(), H, W, h, w, out.data_ptr(), _stream_ptr(m.device))
     _lib.check(rc, "manet_label_resize_nearest")
     return out
@@ -657,7 +674,7 @@ def head_inputs(global_map, local_map, labels, n_ids, size):
         raise ValueError("global_map / local_map must hold h*w*n_ids elements as [h, w, n_ids], labels h*w")
     g, l = global_map.float().contiguous(), local_map.float().contiguous()
     out = torch.empty((n_ids, 3, h, w), dtype=torch.float32, device=g.device)
-    with torch.cuda.device(g.device):
+    with _on(g.device):
         rc = lib.manet_head_inputs_f32(g.data_ptr(), l.data_ptr(), lab.data_ptr(), h * w, n_ids, out.data_ptr(),
                                        _stream_ptr(g.device))
     _lib.check(rc, "manet_head_inputs_f32")
@@ -693,7 +710,7 @@ def dwconv7x7_bn_relu(x, weight, bias=None, bn=None, relu=True, scale=None, shif
         scale, shift = scale.float().contiguous(), shift.float().contiguous()
     bz = None if bias is None else bias.detach().float().contiguous()
     out = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.manet_dwconv7x7_bn_relu_ex(x.data_ptr(), B, C, h, w, wt.data_ptr(),
                                             None if bz is None else bz.data_ptr(),
                                             None if scale is None else scale.data_ptr(),
@@ -742,14 +759,14 @@ def conv1x1_mfma(x, w2t, b2, relu_out=False, head_weight=None, head_bias=None):
         hw = head_weight.detach().float().contiguous()
         hb = None if head_bias is None else head_bias.detach().float().contiguous()
         hout = torch.empty((B, 1, h, w), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             rc = lib.manet_conv1x1_head_f32(x.data_ptr(), cin * h * w, B, cin, h * w, w2t.data_ptr(), b2.data_ptr(), PW_COUT,
                                             0, None, hw.data_ptr(), None if hb is None else hb.data_ptr(), hout.data_ptr(),
                                             _stream_ptr(x.device))
         _lib.check(rc, "manet_conv1x1_head_f32")
         return hout
     out = torch.empty((B, PW_COUT, h, w), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.manet_conv1x1_f32(x.data_ptr(), cin * h * w, B, cin, h * w, w2t.data_ptr(), b2.data_ptr(), PW_COUT,
                                    int(bool(relu_out)), out.data_ptr(), _stream_ptr(x.device))
     _lib.check(rc, "manet_conv1x1_f32")
@@ -768,7 +785,7 @@ class SplitWeight:
             raise ValueError("w2t must be [Cin, %d] (ops.fold_pointwise)" % PW_COUT)
         self.cin = int(w2t.shape[0])
         self.packed = torch.empty(int(lib.manet_conv1x1_x3_weight_bytes(self.cin)), dtype=torch.uint8, device=w2t.device)
-        with torch.cuda.device(w2t.device):
+        with _on(w2t.device):
             rc = lib.manet_conv1x1_x3_pack(w2t.data_ptr(), self.cin, PW_COUT, self.packed.data_ptr(), _stream_ptr(w2t.device))
         _lib.check(rc, "manet_conv1x1_x3_pack")
 
@@ -812,7 +829,7 @@ def conv1x1_split(x, weight, b2, relu_out=False, add=None, head_weight=None, hea
     else:
         out = torch.empty((B, PW_COUT, h, w), dtype=torch.float32, device=x.device)
     ptr = lambda t: None if t is None else t.data_ptr()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.manet_conv1x1_x3_f32(x.data_ptr(), cin * h * w, B, cin, h * w, weight.packed.data_ptr(), b2.data_ptr(),
                                       ptr(add), PW_COUT, int(bool(relu_out)), ptr(out), ptr(hw), ptr(hb), ptr(hout),
                                       _stream_ptr(x.device))
@@ -833,7 +850,7 @@ def relu_conv1x1_c1(x, weight, bias=None, relu_in=True):
     wt = weight.detach().float().contiguous()
     bz = None if bias is None else bias.detach().float().contiguous()
     out = torch.empty((B, 1, h, w), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.manet_relu_conv1x1_c1_f32(x.data_ptr(), B, C, h * w, wt.data_ptr(), None if bz is None else bz.data_ptr(),
                                            int(bool(relu_in)), out.data_ptr(), _stream_ptr(x.device))
     _lib.check(rc, "manet_relu_conv1x1_c1_f32")
