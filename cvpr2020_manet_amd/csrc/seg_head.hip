@@ -686,12 +686,16 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
     // weights and 64 accumulators)
     constexpr int FH = RW_KC / 4;  // k-steps per half step
     float F0[FH], F1[FH];
+    // pixel block pb of the tile = the pixels of PARITY pb (MFMA column n <-> pixel 2 n + pb): a lane's two fragments of a
+    // k-step are neighbours in LDS (one ds_read_b64, two k-steps per ds_read2_b64), and its two outputs of a channel are
+    // neighbours in memory (one 8-byte store; 32 lanes = a full 256-byte run)
     {
-        const float *X = &xbuf[0][kk * RW_P + l31];
+        const float *X = &xbuf[0][kk * RW_P + 2 * l31];
 #pragma unroll
         for (int s = 0; s < FH; ++s) {
-            F0[s] = X[2 * s * RW_P];
-            F1[s] = X[2 * s * RW_P + 32];
+            const f32x2 v = *(const f32x2 *)(X + 2 * s * RW_P);
+            F0[s] = v[0];
+            F1[s] = v[1];
         }
     }
     int st = 0;  // step number of (t, c); its stage was read into F during step st - 1, step st reads stage st + 1
@@ -708,7 +712,7 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
         for (int c = 0; c < RW_KMAX / RW_KC; ++c) {
             if (c < nch) {  // (uniform)
                 issue();  // step st + RW_NB - 1 -> the slot of step st - 1 (read during step st - 2: free)
-                const float *Xc = &xbuf[st % RW_NB][kk * RW_P + l31], *Xn = &xbuf[(st + 1) % RW_NB][kk * RW_P + l31];
+                const float *Xc = &xbuf[st % RW_NB][kk * RW_P + 2 * l31], *Xn = &xbuf[(st + 1) % RW_NB][kk * RW_P + 2 * l31];
 #pragma unroll
                 for (int s = 0; s < RW_KC / 2; s += 2) {
                     const int ks = c * (RW_KC / 2) + s, f = s % FH;
@@ -720,13 +724,14 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
                         // k-steps s, s + 1 of this step's second half (s < FH), or of the next stage's first half (a stale
                         // read behind the last step)
                         const float *X = s < FH ? Xc + 2 * (s + FH) * RW_P : Xn + 2 * (s - FH) * RW_P;
-                        F0[f] = X[0];
-                        F1[f] = X[32];
-                        F0[f + 1] = X[2 * RW_P];
-                        F1[f + 1] = X[2 * RW_P + 32];
+                        const f32x2 va = *(const f32x2 *)X, vb = *(const f32x2 *)(X + 2 * RW_P);
+                        F0[f] = va[0];
+                        F1[f] = va[1];
+                        F0[f + 1] = vb[0];
+                        F1[f + 1] = vb[1];
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the refills right behind them
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // the refill (one ds_read2_b64) right behind them
                 }
                 rw_wait_vmcnt(2 * (issued - 1 - (st + 2)));  // step st + 2 has landed: only the steps behind it may be out
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of stages st, st + 1 have returned
@@ -739,17 +744,15 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
         {
             const long p0 = (long)cur_p * RW_P;
             float *dst = out + ((long)cur_b * PW_CO + co0) * HW + p0;
-            const unsigned voff = (unsigned)((long)(4 * kk) * HW + l31);
+            const unsigned voff = (unsigned)((long)(4 * kk) * HW + 2 * l31);
+            if (p0 + 2 * l31 < HW) {  // (HW is a multiple of 4 and p0 of 64: a pixel pair is inside or outside as a whole)
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                if (p0 + pb * 32 + l31 < HW) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2);
-                        float v = (acc[pb][0][r] + acc[pb][1][r]) + bsh[wave * 32 + row + 4 * kk];
-                        if (relu_out) v = fmaxf(v, 0.0f);
-                        if (!(abl & 1)) (dst + (long)row * HW + pb * 32)[voff] = v;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2);
+                    const float bb = bsh[wave * 32 + row + 4 * kk];
+                    f32x2 v = {(acc[0][0][r] + acc[0][1][r]) + bb, (acc[1][0][r] + acc[1][1][r]) + bb};
+                    if (relu_out) v = __builtin_elementwise_max(v, f32x2{0.0f, 0.0f});
+                    if (!(abl & 1)) *(f32x2 *)((dst + (long)row * HW) + voff) = v;
                 }
             }
             if (++cur_p == tpp) {
