@@ -83,6 +83,7 @@ SIGNATURES = {
     "manet_local_match_frames": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "manet_profile_read": (_i, [_i, ctypes.POINTER(ctypes.c_float), _i, _ip]),
     "manet_correlation_backward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "manet_correlation_backward_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
 }
 
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3, COMPUTE_BF16_REFINE = 0, 1, 2, 3

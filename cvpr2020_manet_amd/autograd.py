@@ -161,16 +161,15 @@ class LocalMatchFn(torch.autograd.Function):
 
 class CorrelationFn(torch.autograd.Function):
     """correlation_package's CorrelationFunction (correlation.py:7-45) on the HIP kernels.  The output (and the gradients)
-    have the inputs' dtype, as the reference's op (float / half; the forward computes in that type exactly like the no-grad
-    path).  The backward kernels are fp32: half gradients are computed in fp32 and rounded once; double inputs are refused
-    under grad (the reference dispatches a double backward, correlation_cuda_kernel.cu:495-541 -- not built here)."""
+    have the inputs' dtype, as the reference's op (float / half / double: its dispatch, correlation_cuda_kernel.cu:495-541; the
+    forward computes in that type exactly like the no-grad path).  The backward kernels are fp32 and fp64: half gradients are
+    computed in fp32 and rounded once, double gradients in double."""
 
     @staticmethod
     def forward(ctx, input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2):
         from . import ops
-        if input1.dtype == torch.float64 or input2.dtype == torch.float64:
-            raise RuntimeError("cvpr2020_manet_amd: the correlation backward exists for float32 / float16 inputs; "
-                               "float64 inputs that require grad are not supported (call under torch.no_grad())")
+        if input1.dtype != input2.dtype:
+            raise RuntimeError("cvpr2020_manet_amd: correlation inputs must have the same dtype")
         a = input1.contiguous()
         b = input2.contiguous()
         ctx.save_for_backward(a, b)
@@ -182,14 +181,15 @@ class CorrelationFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         lib = _lib.load()
         a0, b0 = ctx.saved_tensors
-        a, b = a0.float(), b0.float()
+        wide = torch.float64 if a0.dtype == torch.float64 else torch.float32
+        a, b = a0.to(wide), b0.to(wide)
         B, C, H, W = a.shape
         pad_size, kernel_size, max_displacement, stride1, stride2 = ctx.params
-        g = grad_out.contiguous().float()
+        g = grad_out.contiguous().to(wide)
         ga, gb = torch.empty_like(a), torch.empty_like(b)
+        fn = lib.manet_correlation_backward_f64 if wide == torch.float64 else lib.manet_correlation_backward_f32
         with torch.cuda.device(a.device):
-            rc = lib.manet_correlation_backward_f32(a.data_ptr(), b.data_ptr(), g.data_ptr(), B, C, H, W, pad_size,
-                                                    kernel_size, max_displacement, stride1, stride2, ga.data_ptr(),
-                                                    gb.data_ptr(), _stream_ptr(a.device))
-        _lib.check(rc, "manet_correlation_backward_f32")
+            rc = fn(a.data_ptr(), b.data_ptr(), g.data_ptr(), B, C, H, W, pad_size, kernel_size, max_displacement, stride1,
+                    stride2, ga.data_ptr(), gb.data_ptr(), _stream_ptr(a.device))
+        _lib.check(rc, "manet_correlation_backward")
         return ga.to(a0.dtype), gb.to(b0.dtype), None, None, None, None, None

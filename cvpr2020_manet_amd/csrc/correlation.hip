@@ -177,10 +177,12 @@ static bool launch_corr_tiled(hipStream_t st, const T *in1, const T *in2, int B,
 //      with oy*s1 = ya + pad - max_disp - j,  ox*s1 = xa + pad - max_disp - i   (integral, inside the output)
 //   gin2[n][c][yb][xb] = the same with in1 sampled at (yb - tj*s2, xb - ti*s2) and
 //      oy*s1 = yb + pad - max_disp - j - tj*s2
-template <bool SECOND>
+// T = float (half inputs are widened by the caller: fp32 gradients rounded once) or double (the reference dispatches a double
+// backward as well, correlation_cuda_kernel.cu:495-541; arithmetic in the tensor's type like its scalar_t kernels)
+template <bool SECOND, typename T>
 __global__ __launch_bounds__(256) void correlation_backward_kernel(
-    const float *__restrict__ other, const float *__restrict__ gout, int B, int C, int H, int W, int pad, int kr,
-    int max_disp, int s1, int s2, int r, int oh, int ow, float nelems, float *__restrict__ gin)
+    const T *__restrict__ other, const T *__restrict__ gout, int B, int C, int H, int W, int pad, int kr,
+    int max_disp, int s1, int s2, int r, int oh, int ow, T nelems, T *__restrict__ gin)
 {
     const int D = 2 * r + 1;
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,9 +192,9 @@ __global__ __launch_bounds__(256) void correlation_backward_kernel(
     const int y = (int)((idx / W) % H);
     const int c = (int)((idx / plane) % C);
     const int n = (int)(idx / (plane * C));
-    const float *oth = other + ((long)n * C + c) * plane;
-    const float *go = gout + (long)n * D * D * oh * ow;
-    float acc = 0.0f;
+    const T *oth = other + ((long)n * C + c) * plane;
+    const T *go = gout + (long)n * D * D * oh * ow;
+    T acc = (T)0;
     for (int tj = -r; tj <= r; ++tj)
         for (int ti = -r; ti <= r; ++ti) {
             const int tc = (tj + r) * D + (ti + r);
@@ -200,10 +202,10 @@ __global__ __launch_bounds__(256) void correlation_backward_kernel(
             const int yo = SECOND ? y - tj * s2 : y + tj * s2;
             const int xo = SECOND ? x - ti * s2 : x + ti * s2;
             if (yo < 0 || yo >= H || xo < 0 || xo >= W) continue;
-            const float ov = oth[(long)yo * W + xo];
+            const T ov = oth[(long)yo * W + xo];
             // first-input position of the product: (y, x) itself, or (yo, xo) when this is the second input
             const int y1p = (SECOND ? yo : y) + pad - max_disp, x1p = (SECOND ? xo : x) + pad - max_disp;
-            float gs = 0.0f;
+            T gs = (T)0;
             for (int j = -kr; j <= kr; ++j) {
                 const int ys = y1p - j;
                 if (ys < 0 || ys % s1) continue;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void correlation_backward_kernel(
                     gs += go[((long)tc * oh + oy) * ow + ox];
                 }
             }
-            acc = fmaf(gs, ov, acc);
+            acc = fma(gs, ov, acc);
         }
     gin[idx] = acc / nelems;
 }
@@ -293,9 +295,12 @@ int manet_correlation_forward(const void *in1, const void *in2, int dtype, int B
     return manet_check_launch("manet_correlation_forward");
 }
 
-int manet_correlation_backward_f32(const float *in1, const float *in2, const float *grad_out, int B, int C, int H, int W,
-                                   int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
-                                   float *grad_in1, float *grad_in2, manet_stream_t stream)
+}  // extern "C"
+
+template <typename T>
+static int correlation_backward_t(const T *in1, const T *in2, const T *grad_out, int B, int C, int H, int W, int pad_size,
+                                  int kernel_size, int max_displacement, int stride1, int stride2, T *grad_in1, T *grad_in2,
+                                  manet_stream_t stream)
 {
     int oc, oh, ow;
     int rc = manet_correlation_out_dims(H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &oc, &oh, &ow);
@@ -305,13 +310,31 @@ int manet_correlation_backward_f32(const float *in1, const float *in2, const flo
     int kr = (kernel_size - 1) / 2;
     int r = max_displacement / stride2;
     long total = (long)B * C * H * W;
-    float nelems = (float)(kernel_size * kernel_size * C);
+    T nelems = (T)(kernel_size * kernel_size * C);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(correlation_backward_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in2,
+    hipLaunchKernelGGL((correlation_backward_kernel<false, T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in2,
                        grad_out, B, C, H, W, pad_size, kr, max_displacement, stride1, stride2, r, oh, ow, nelems, grad_in1);
-    hipLaunchKernelGGL(correlation_backward_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in1,
+    hipLaunchKernelGGL((correlation_backward_kernel<true, T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in1,
                        grad_out, B, C, H, W, pad_size, kr, max_displacement, stride1, stride2, r, oh, ow, nelems, grad_in2);
-    return manet_check_launch("manet_correlation_backward_f32");
+    return manet_check_launch("manet_correlation_backward");
+}
+
+extern "C" {
+
+int manet_correlation_backward_f32(const float *in1, const float *in2, const float *grad_out, int B, int C, int H, int W,
+                                   int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                   float *grad_in1, float *grad_in2, manet_stream_t stream)
+{
+    return correlation_backward_t<float>(in1, in2, grad_out, B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2,
+                                         grad_in1, grad_in2, stream);
+}
+
+int manet_correlation_backward_f64(const double *in1, const double *in2, const double *grad_out, int B, int C, int H, int W,
+                                   int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+                                   double *grad_in1, double *grad_in2, manet_stream_t stream)
+{
+    return correlation_backward_t<double>(in1, in2, grad_out, B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2,
+                                          grad_in1, grad_in2, stream);
 }
 
 }  // extern "C"

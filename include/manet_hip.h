@@ -426,6 +426,12 @@ int manet_correlation_backward_f32(const float *in1, const float *in2, const flo
                                    int C, int H, int W, int pad_size, int kernel_size,
                                    int max_displacement, int stride1, int stride2, float *grad_in1,
                                    float *grad_in2, manet_stream_t stream);
+/* ... and for double tensors (the reference dispatches float, double and half backwards, correlation_cuda_kernel.cu:495-541;
+ * half gradients are this library's fp32 kernel on widened inputs, rounded once by the caller). */
+int manet_correlation_backward_f64(const double *in1, const double *in2, const double *grad_out, int B,
+                                   int C, int H, int W, int pad_size, int kernel_size,
+                                   int max_displacement, int stride1, int stride2, double *grad_in1,
+                                   double *grad_in2, manet_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Opt-in measurement hook (not part of the data path, used by bench.py): between _begin and _end
