@@ -722,9 +722,27 @@ class IntVOS(nn.Module):
             if inference and (bank is not None or fused_local):
                 # this frame's operands: ONE read of its embedding (cache hit when the driver prepared the clip, or on
                 # later interaction rounds); wide windows want the local map pre-set to 1.0 -- it rides in that launch
-                if fused_local and self._local_radius() >= 11:
+                lslot = None
+                if fused_local and local_map_dics is not None:
+                    # the local map is written straight into its slot of the local-map memory (IntVOS.py:645-647 stores it
+                    # there anyway: one device copy per frame less); the tables are created as the reference creates them
+                    local_map_tmp_dic, local_map_dist_dic = local_map_dics
+                    dev_ = current_frame_embedding.device
+                    if seq_names[n] not in local_map_dist_dic:
+                        local_map_dist_dic[seq_names[n]] = torch.zeros(MAX_CLIP_FRAMES, MAX_INTERACTIONS, device=dev_)
+                    if seq_names[n] not in local_map_tmp_dic:
+                        local_map_tmp_dic[seq_names[n]] = torch.zeros((MAX_CLIP_FRAMES, MAX_INTERACTIONS, h, w, n_ids, 1),
+                                                                     dtype=torch.float32, device=dev_)
+                    tab_ = local_map_tmp_dic[seq_names[n]]
+                    if (tab_.dtype == torch.float32 and tab_.is_contiguous()
+                            and tuple(tab_.shape[2:]) == (h, w, n_ids, 1) and 0 < interaction_num <= tab_.shape[1]):
+                        lslot = tab_[frame_num[n]][interaction_num - 1].view(h, w, n_ids)
+                if lslot is not None:
+                    lpre = lslot
+                elif fused_local and self._local_radius() >= 11:
                     lpre = torch.empty((h, w, n_ids), dtype=torch.float32, device=current_frame_embedding.device)
-                fcur, preset_done = self._prepared_frame(current_frame_embedding[n], preset=lpre)
+                fcur, preset_done = self._prepared_frame(current_frame_embedding[n],
+                                                         preset=lpre if self._local_radius() >= 11 else None)
             if pre is not None:  # computed ahead of the chain (global_maps): out == mem after the fused min-merge
                 mem.view(-1).copy_(pre.reshape(-1))
                 nn_features_n = mem.view(1, h, w, n_ids, 1).clone()
@@ -769,7 +787,9 @@ class IntVOS(nn.Module):
                 # python arithmetic first, as the reference: frame == annotated frame raises ZeroDivisionError
                 weight = 1.0 / (abs(frame_num[n] - start_annotated_frame))
                 dist_tab[frame_num[n]][interaction_num - 1] = weight
-                map_tab[frame_num[n]][interaction_num - 1] = prev_frame_nn_features_n.squeeze(0).detach()
+                slot_ = map_tab[frame_num[n]][interaction_num - 1]
+                if prev_frame_nn_features_n.data_ptr() != slot_.data_ptr():  # (not written in place above)
+                    slot_.copy_(prev_frame_nn_features_n.squeeze(0).detach())
                 if interaction_num == 1:
                     prev_frame_nn_features_n = map_tab[frame_num[n]][interaction_num - 1].unsqueeze(0)
                 elif dist_tab[frame_num[n]][interaction_num - 1] > dist_tab[frame_num[n]][interaction_num - 2]:
