@@ -46,11 +46,14 @@ __global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *
                                                                    const float *__restrict__ bias,
                                                                    const float *__restrict__ scale,
                                                                    const float *__restrict__ shift, int relu,
-                                                                   int relu_in, float *__restrict__ out)
+                                                                   int relu_in, float *__restrict__ out, int per_item)
 {
     // E: element (r, col) at ((r >> 1) * LW + col) * 2 + (r & 1), r = row - (y0 - 3); O: the same for r - 1
     __shared__ __attribute__((aligned(16))) float tile[2 * DW_IMG];
-    const int c = blockIdx.z;
+    // per_item (r4): few channels (layer 1's 3 per-object ones: 24 workgroups walking 3 items each = 3 serial round trips on a
+    // tenth of the chip) -- a workgroup per (tile, channel, batch item) instead of the batch walk
+    const int c = per_item ? (int)(blockIdx.z % (unsigned)C) : (int)blockIdx.z;
+    const int b_first = per_item ? (int)(blockIdx.z / (unsigned)C) : 0, b_end = per_item ? b_first + 1 : B;
     const int x0 = blockIdx.x * DW_TX, y0 = blockIdx.y * DW_TY;
     const long plane = (long)h * w;
     const int tid = threadIdx.x;
@@ -96,8 +99,8 @@ __global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *
     const float *wk = weight + (long)c * DW_K * DW_K;
     const float bc = bias ? bias[c] : 0.0f, sc = scale ? scale[c] : 1.0f, sh = shift ? shift[c] : 0.0f;
     const int t = tid >> 3, tg = tid & 7;  // output row pair (2t, 2t+1), group of 8 columns
-    issue_loads(0);
-    for (int b = 0; b < B; ++b) {
+    issue_loads(b_first);
+    for (int b = b_first; b < b_end; ++b) {
 #pragma unroll
         for (int k = 0; k < KI; ++k) asm volatile("" : "+v"(ld[k][0]), "+v"(ld[k][1]), "+v"(ld[k][2]));
 #pragma unroll
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (b + 1 < B) issue_loads(b + 1);  // in flight under this item's arithmetic
+        if (b + 1 < b_end) issue_loads(b + 1);  // in flight under this item's arithmetic
         if (t < DW_TY / 2) {
             f32x2 acc[8];
 #pragma unroll
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(PW_NT, 3) void conv1x1_mfma_kernel(const float *__r
                                                                 const float *__restrict__ b2, int relu_out,
                                                                 float *__restrict__ out, const float *__restrict__ head_w,
                                                                 const float *__restrict__ head_b,
-                                                                float *__restrict__ head_out)
+                                                                float *__restrict__ head_out, const float *__restrict__ add)
 {
     __shared__ __attribute__((aligned(1024))) float wbuf[2][PW_KC * PW_CO];
     __shared__ __attribute__((aligned(1024))) float xbuf[2][PW_KC * PW_P];
@@ -286,22 +289,26 @@ __global__ __launch_bounds__(PW_NT, 3) void conv1x1_mfma_kernel(const float *__r
     const long p0 = (long)blockIdx.x * PW_P;
     const int b = blockIdx.y;
     const float *src = in + (long)b * in_bs;
-    const int n = (Cin + PW_KC - 1) / PW_KC;  // Cin % 4 == 0: the last chunk may hold 4, 8 or 12 channels
+    const int n = (Cin + PW_KC - 1) / PW_KC;  // any Cin >= 1 (r4): the last chunk may hold 1 .. 16 channels
     const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&wbuf[0][0]);
     const unsigned xbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&xbuf[0][0]);
     // in-slice piece of this wave: channels 4 wave .. 4 wave + 3 of the chunk, lane -> (channel lane / 16, pixels 4 (lane % 16) ..)
     long pix = p0 + 4 * (lane & 15);
     if (pix > HW - 4) pix = HW - 4;  // the plane's last tile: clamped columns are computed and never stored
     auto dma = [&](int c, int buf) __attribute__((always_inline)) {
-        const int k0 = c * PW_KC, kn = (Cin - k0) < PW_KC ? (Cin - k0) : PW_KC;  // channels of this chunk (multiple of 4)
+        const int k0 = c * PW_KC, kn = (Cin - k0) < PW_KC ? (Cin - k0) : PW_KC;  // channels of this chunk
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wave * 4 + i;  // weight row = 1 KiB piece
             if (row < kn)
                 lds_dma16(w2t + (long)(k0 + row) * PW_CO + lane * 4, wbase + (unsigned)buf * (unsigned)(PW_KC * PW_CO * 4) + (unsigned)row * 1024u);
         }
-        if (wave * 4 < kn)
-            lds_dma16(src + (long)(k0 + wave * 4 + (lane >> 4)) * HW + pix, xbase + (unsigned)buf * (unsigned)(PW_KC * PW_P * 4) + (unsigned)wave * 1024u);
+        if (wave * 4 < kn) {
+            // (rows past Cin inside a piece re-read row Cin - 1: their weight rows are zero -- layer 1's per-object half has 3)
+            int ch = k0 + wave * 4 + (lane >> 4);
+            ch = ch < Cin ? ch : Cin - 1;
+            lds_dma16(src + (long)ch * HW + pix, xbase + (unsigned)buf * (unsigned)(PW_KC * PW_P * 4) + (unsigned)wave * 1024u);
+        }
     };
     f32x16 acc[2][2];
 #pragma unroll
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(PW_NT, 3) void conv1x1_mfma_kernel(const float *__r
     const int co0 = wave * 64;
     __shared__ float bsh[PW_CO];
     bsh[tid] = b2[tid];  // the folded bias, read back in the epilogue (a global load per output would serialise it)
-    const int tail = Cin - (n - 1) * PW_KC;  // channels of the last chunk: 4, 8, 12 or 16
+    const int tail = Cin - (n - 1) * PW_KC;  // channels of the last chunk: 1 .. 16
     // A partial last chunk multiplies all 16 rows like the others (no branch in the MFMA loop: a branch per k-step keeps
     // hipcc from overlapping a k-step's LDS reads with the previous k-step's MFMAs): its missing weight rows are ZERO in LDS,
     // so whatever finite in-slice rows an earlier chunk left there contribute nothing.  (n == 1: the in-slice rows were
@@ -387,6 +394,7 @@ __global__ __launch_bounds__(PW_NT, 3) void conv1x1_mfma_kernel(const float *__r
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 float v = acc[cb][pb][r] + bsh[co];
+                if (add) v += add[(long)co * HW + p];  // layer 1's shared-embedding half, the same for every batch item
                 if (relu_out) v = fmaxf(v, 0.0f);
                 dst[(long)co * HW + p] = v;
             }
@@ -794,9 +802,12 @@ extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, 
         return manet_set_error(MANET_E_INVALID, "bad arguments (B*C must be <= 65535)");
     if (C > 65535) return manet_set_error(MANET_E_INVALID, "C must be <= 65535");
     dim3 grid((unsigned)((w + DW_TX - 1) / DW_TX), (unsigned)((h + DW_TY - 1) / DW_TY), (unsigned)C);
+    // the batch walk pays when every CU has workgroups to overlap; below two workgroups per CU the items go into the grid
+    const int per_item = (B > 1 && (long)grid.x * grid.y * C < 512) ? 1 : 0;
+    if (per_item) grid.z = (unsigned)(B * C);
 #define DW_LAUNCH(F_, A_)                                                                                              \
     hipLaunchKernelGGL((dwconv7x7_bn_relu_kernel<F_, A_>), grid, dim3(256), 0, (hipStream_t)stream, in, B, C, h, w, weight, bias, \
-                       bn_scale, bn_shift, relu, relu_in, out)
+                       bn_scale, bn_shift, relu, relu_in, out, per_item)
     if (w % 2 == 0 && w >= 2 && ((size_t)in & 7) == 0 && ((size_t)out & 7) == 0) {
 #ifdef MANET_ABLATION
         switch (manet_tune_get(MANET_TUNE_ABLATION, 0)) {  // timing experiments only (tools/pw_bench.py --dw)
@@ -814,6 +825,10 @@ extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, 
     return manet_check_launch("manet_dwconv7x7_bn_relu_f32");
 }
 
+static int conv1x1_f32_impl(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const float *w2t,
+                            const float *b2, int Cout, int relu_out, float *out, const float *head_w, const float *head_b,
+                            float *head_out, const float *add, manet_stream_t stream);
+
 // 1x1 convolution with 256 output channels as an fp32-MFMA contraction (conv1x1_mfma_kernel)
 extern "C" int manet_conv1x1_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const float *w2t,
                                  const float *b2, int Cout, int relu_out, float *out, manet_stream_t stream)
@@ -822,19 +837,37 @@ extern "C" int manet_conv1x1_f32(const float *in, int64_t in_batch_stride, int B
 }
 
 // ... optionally with DynamicSegHead's output layer fused into the epilogue (head_w != NULL: `out` is not written)
+extern "C" int manet_conv1x1_add_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const float *w2t,
+                                     const float *b2, const float *add, int Cout, int relu_out, float *out, manet_stream_t stream);
+
 extern "C" int manet_conv1x1_head_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const float *w2t,
                                       const float *b2, int Cout, int relu_out, float *out, const float *head_w,
                                       const float *head_b, float *head_out, manet_stream_t stream)
 {
+    return conv1x1_f32_impl(in, in_batch_stride, B, Cin, HW, w2t, b2, Cout, relu_out, out, head_w, head_b, head_out, nullptr, stream);
+}
+
+// ... or with an optional [256][HW] term shared by every batch entry added in the epilogue (layer 1's shared-embedding half)
+extern "C" int manet_conv1x1_add_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const float *w2t,
+                                     const float *b2, const float *add, int Cout, int relu_out, float *out, manet_stream_t stream)
+{
+    return conv1x1_f32_impl(in, in_batch_stride, B, Cin, HW, w2t, b2, Cout, relu_out, out, nullptr, nullptr, nullptr, add, stream);
+}
+
+static int conv1x1_f32_impl(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const float *w2t,
+                            const float *b2, int Cout, int relu_out, float *out, const float *head_w, const float *head_b,
+                            float *head_out, const float *add, manet_stream_t stream)
+{
     if (!in || !w2t || !b2 || (!out && !head_w) || (head_w && !head_out) || B <= 0 || B > 65535 || Cin <= 0 || HW <= 0)
         return manet_set_error(MANET_E_INVALID, "bad arguments");
     if (Cout != PW_CO) return manet_set_error(MANET_E_INVALID, "Cout=%d (this kernel is built for %d output channels)", Cout, PW_CO);
-    if (Cin % 4 != 0 || HW % 4 != 0 || HW < 4)
-        return manet_set_error(MANET_E_INVALID, "Cin=%d and HW=%lld must be multiples of 4 (16-byte LDS-DMA rows)", Cin, (long long)HW);
+    if (HW % 4 != 0 || HW < 4)
+        return manet_set_error(MANET_E_INVALID, "HW=%lld must be a multiple of 4 (16-byte LDS-DMA rows)", (long long)HW);
     if (((size_t)w2t & 15) != 0 || ((size_t)in & 15) != 0 || (in_batch_stride & 3) != 0)
         return manet_set_error(MANET_E_INVALID, "in / w2t must be 16-byte aligned, the batch stride a multiple of 4 elements");
     // weights resident in registers (conv1x1_rw_kernel) when the layer allows: whole 32-channel stages, no fused output layer
-    if (!head_w && Cin % RW_KC == 0 && Cin <= RW_KMAX && manet_tune_get(MANET_TUNE_CONV1X1, 0) != 1) {
+    if (head_w && add) return manet_set_error(MANET_E_INVALID, "add and the fused output layer are exclusive");
+    if (!head_w && !add && Cin % RW_KC == 0 && Cin <= RW_KMAX && manet_tune_get(MANET_TUNE_CONV1X1, 0) != 1) {
         const int tpp = (int)((HW + RW_P - 1) / RW_P);
         const long total = (long)tpp * B;
         int G = 256;  // pixel-range groups: one per CU; each is served by two workgroups (the output-channel halves)
@@ -851,7 +884,7 @@ extern "C" int manet_conv1x1_head_f32(const float *in, int64_t in_batch_stride, 
     }
     dim3 grid((unsigned)((HW + PW_P - 1) / PW_P), (unsigned)B);
     hipLaunchKernelGGL(conv1x1_mfma_kernel, grid, dim3(PW_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin, (long)HW,
-                       w2t, b2, relu_out, out, head_w, head_b, head_out);
+                       w2t, b2, relu_out, out, head_w, head_b, head_out, add);
     return manet_check_launch("manet_conv1x1_f32");
 }
 

@@ -265,7 +265,7 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
 
     def _pointwise(self, y, k, which, bias, relu):
         """bn2(conv2(y)) [+ relu2] on the depthwise stage's output: the fp32-MFMA 1x1 kernel when the shapes allow (256 output
-        channels, Cin and h*w multiples of 4), else the framework's convolution with the same folded weights"""
+        channels, h*w a multiple of 4), else the framework's convolution with the same folded weights"""
         skey = {"all": "sw", "shared": "sw_shared", "object": "sw_object"}[which]
         if skey in k and ops.conv1x1_split_ok(y, self.conv2.out_channels):
             b2 = k["b2"] if bias else k.setdefault("b2_zero", torch.zeros_like(k["b2"]))
@@ -315,6 +315,10 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
             zero = k.setdefault("b2_zero", torch.zeros_like(k["b2"]))
             return ops.conv1x1_split(p1, k["sw_object"], k["b2"], relu_out=not defer_relu,
                                      add=ops.conv1x1_split(s1, k["sw_shared"], zero))
+        if "w2t_object" in k and ops.conv1x1_mfma_ok(p1, self.conv2.out_channels):  # the same form on the fp32 matrix pipe
+            zero = k.setdefault("b2_zero", torch.zeros_like(k["b2"]))
+            return ops.conv1x1_mfma(p1, k["w2t_object"], k["b2"], relu_out=not defer_relu,
+                                    add=ops.conv1x1_mfma(s1, k["w2t_shared"], zero))
         y = self._pointwise(p1, k, "object", True, False)
         y += self._pointwise(s1, k, "shared", False, False)  # broadcast over the objects
         return y if defer_relu else y.relu_()

@@ -733,17 +733,18 @@ def fold_pointwise(conv2, bn2):
 
 
 def conv1x1_mfma_ok(x, cout):
-    """shapes the MFMA 1x1 kernel takes: 256 output channels, Cin and h*w multiples of 4 (16-byte LDS-DMA rows)"""
-    return (cout == PW_COUT and x.dim() == 4 and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0
+    """shapes the MFMA 1x1 kernel takes: 256 output channels, any Cin, h*w a multiple of 4 (16-byte LDS-DMA rows)"""
+    return (cout == PW_COUT and x.dim() == 4 and x.shape[1] >= 1 and (x.shape[2] * x.shape[3]) % 4 == 0
             and x.shape[2] * x.shape[3] >= 4)
 
 
-def conv1x1_mfma(x, w2t, b2, relu_out=False, head_weight=None, head_bias=None):
+def conv1x1_mfma(x, w2t, b2, relu_out=False, head_weight=None, head_bias=None, add=None):
     """conv2 -> bn2 [-> relu2] of a _split_separable_conv2d block (IntVOS.py:494,503-505) as an fp32-MFMA contraction fed by
     LDS-DMA (manet_conv1x1_f32).  x [B, Cin, h, w] fp32; w2t [Cin, 256], b2 [256] from fold_pointwise -> [B, 256, h, w].
     head_weight [1, 256, 1, 1] (+ head_bias [1]): DynamicSegHead's output layer Conv2d(256, 1, 1)(relu(.)) (IntVOS.py:519,525)
-    fused into the epilogue -- returns [B, 1, h, w], the 256-channel activation is never written."""
-    _refuse_autograd("conv1x1_mfma", x, w2t, b2, head_weight, head_bias)
+    fused into the epilogue -- returns [B, 1, h, w], the 256-channel activation is never written.
+    add [256, h, w] / [1, 256, h, w] fp32: added to every batch entry before relu_out (layer1's shared-embedding half)."""
+    _refuse_autograd("conv1x1_mfma", x, w2t, b2, head_weight, head_bias, add)
     lib = _lib.load()
     _need_gpu(x, "x")
     x = x.float().contiguous()
@@ -751,8 +752,20 @@ def conv1x1_mfma(x, w2t, b2, relu_out=False, head_weight=None, head_bias=None):
     if tuple(w2t.shape) != (cin, PW_COUT) or b2.numel() != PW_COUT:
         raise ValueError("w2t must be [%d, %d] (ops.fold_pointwise), b2 [%d]" % (cin, PW_COUT, PW_COUT))
     if not conv1x1_mfma_ok(x, PW_COUT):
-        raise ValueError("conv1x1_mfma needs Cin and h*w to be multiples of 4")
+        raise ValueError("conv1x1_mfma needs h*w to be a multiple of 4")
     w2t, b2 = w2t.detach().float().contiguous(), b2.detach().float().contiguous()
+    if add is not None:
+        if head_weight is not None:
+            raise ValueError("add and the fused output layer are exclusive")
+        if add.numel() != PW_COUT * h * w or add.dtype != torch.float32 or add.device != x.device:
+            raise ValueError("add must be [%d, h, w] fp32 on x's device" % PW_COUT)
+        add = add.contiguous()
+        out = torch.empty((B, PW_COUT, h, w), dtype=torch.float32, device=x.device)
+        with _on(x.device):
+            rc = lib.manet_conv1x1_add_f32(x.data_ptr(), cin * h * w, B, cin, h * w, w2t.data_ptr(), b2.data_ptr(),
+                                           add.data_ptr(), PW_COUT, int(bool(relu_out)), out.data_ptr(), _stream_ptr(x.device))
+        _lib.check(rc, "manet_conv1x1_add_f32")
+        return out
     if head_weight is not None:
         if head_weight.numel() != PW_COUT:
             raise ValueError("head_weight must be [1, %d, 1, 1]" % PW_COUT)

@@ -336,8 +336,8 @@ int manet_relu_conv1x1_c1_f32(const float *in, int B, int C, long HW, const floa
 /* The 1x1 convolution of a _split_separable_conv2d block (networks/IntVOS.py:494,503-505: conv2 -> bn2 [-> relu2]) as an
  * fp32-MFMA contraction, operands fed by LDS-DMA:
  *     out[b][co][p] = b2[co] + sum_ci w2t[ci][co] * in[b][ci][p]      [max(., 0) if relu_out]
- *   in   [B][Cin][HW] fp32, batch stride in_batch_stride elements (0 = one tensor for every batch item), 16-byte aligned;
- *        Cin and HW multiples of 4
+ *   in   [B][Cin][HW] fp32, batch stride in_batch_stride elements (0 = one tensor for every batch item; a multiple of 4),
+ *        16-byte aligned; any Cin >= 1, HW a multiple of 4
  *   w2t  [Cin][Cout] fp32, 16-byte aligned: the 1x1 weight TRANSPOSED with eval-mode bn2 folded in
  *        (w2t[ci][co] = conv2.weight[co][ci] * bn2_scale[co]);  b2 [Cout] = conv2.bias * bn2_scale + bn2_shift;  Cout = 256
  *   out  [B][Cout][HW] fp32 contiguous.
@@ -351,6 +351,11 @@ int manet_conv1x1_f32(const float *in, int64_t in_batch_stride, int B, int Cin, 
 int manet_conv1x1_head_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const float *w2t,
                            const float *b2, int Cout, int relu_out, float *out, const float *head_w,
                            const float *head_b, float *head_out, manet_stream_t stream);
+/* ... or with add [Cout][HW] fp32 (NULL = none) added to every batch entry's output before relu_out: layer1 of the
+ * shared-embedding form (the embedding half of the contraction is computed once per frame and added here, instead of a
+ * broadcast-add pass over the [n_objects,256,h,w] activation). */
+int manet_conv1x1_add_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const float *w2t,
+                          const float *b2, const float *add, int Cout, int relu_out, float *out, manet_stream_t stream);
 
 /* The same layer in SPLIT-bf16 arithmetic: each fp32 factor = hi + lo (two bf16 pieces, 16 significand bits), a product =
  * hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (<= 2^-16 relative per product; the reference's

@@ -79,10 +79,13 @@ def test_gpu_full_size_vs_framework_conv():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(1, 3, 61, 65), (3, 5, 9, 13), (2, 4, 130, 71), (4, 2, 7, 7), (2, 3, 60, 64), (3, 2, 121, 130)])
+@pytest.mark.parametrize("shape", [(1, 3, 61, 65), (3, 5, 9, 13), (2, 4, 130, 71), (4, 2, 7, 7), (2, 3, 60, 64), (3, 2, 121, 130),
+                                   (2, 520, 9, 13), (3, 130, 61, 66), (3, 3, 120, 214)])
 def test_depthwise_batch_walk_odd_widths_and_tile_edges(shape):
-    """the depthwise kernel walks the batch items of a (tile, channel) with the next item's loads in flight: every item,
-    odd and even widths (the 4-byte and the 8-byte load path), one / several tiles per axis, against torch's conv + BN (+ReLU)"""
+    """the depthwise kernel walks the batch items of a (tile, channel) with the next item's loads in flight (>= 512 workgroups:
+    the two wide shapes) or takes a workgroup per (tile, channel, item) (fewer: the others, layer 1's 3 per-object channels):
+    every item, odd and even widths (the 4-byte and the 8-byte load path), one / several tiles per axis, against torch's
+    conv + BN (+ReLU)"""
     from cvpr2020_manet_amd import ops
     B, C, h, w = shape
     torch.manual_seed(B * 1000 + w)
@@ -217,7 +220,7 @@ def test_split_bf16_pointwise_error_bound_and_forms():
 def test_mfma_pointwise_vs_framework_conv_and_literal_module(mode):
     """ops.conv1x1_mfma (fp32-MFMA contraction fed by LDS-DMA) against the framework's 1x1 convolution with the same folded
     weights, and the blocks that use it against their literal form relu2(bn2(conv2(relu1(bn1(conv1(x)))))): full chunks,
-    partial last chunks (Cin % 16 = 4, 8, 12), a partial last pixel tile, the full [3,256,120,214] size, the shared-embedding
+    partial last chunks (Cin % 16 = 4, 8, 12; r4: any Cin), a partial last pixel tile, the full [3,256,120,214] size, the shared-embedding
     route of layer 1 (K = 100 on one batch item)."""
     import torch
     from cvpr2020_manet_amd import ops
@@ -249,14 +252,29 @@ def _pointwise_module_cases(M, ops, torch):
         # fp64 spot check of the chain on the large case
         ref64 = torch.nn.functional.conv2d(x.double(), w2t.t().reshape(256, cin, 1, 1).double(), b2.double())
         assert float((got.double() - ref64).abs().max()) < 2e-4
-        # layer 1's shared route: K = 100 over one batch item + K = 3 per object (framework conv: 3 % 4 != 0)
+        # layer 1's shared route: K = 100 over one batch item, then K = 3 per object with that added in the epilogue
         head = M.DynamicSegHead(in_dim=103, embed_dim=256).cuda().eval()
         xs = torch.randn(3, 103, 24, 30, device="cuda")
         shared = head.forward_shared(xs[:1, :100].contiguous(), xs[:, 100:].contiguous())
         lit = head(torch.cat((xs[:1, :100].repeat(3, 1, 1, 1), xs[:, 100:]), 1))
         torch.testing.assert_close(shared, lit, rtol=1e-3, atol=1e-3)
+        # r4: any Cin (rows past Cin inside a 4-row DMA piece re-read row Cin - 1 against zero weight rows), and the `add` term
+        for (B, cin, h, w) in ((3, 3, 24, 30), (1, 1, 4, 4), (2, 6, 5, 12), (2, 18, 9, 12), (3, 103, 6, 10), (3, 3, 120, 214)):
+            x = torch.randn(B, cin, h, w, device="cuda")
+            w2t = torch.randn(cin, 256, device="cuda") * 0.2
+            bb = torch.randn(256, device="cuda")
+            addt = torch.randn(256, h, w, device="cuda")
+            want = torch.nn.functional.conv2d(x, w2t.t().reshape(256, cin, 1, 1).contiguous(), bb)
+            torch.testing.assert_close(ops.conv1x1_mfma(x, w2t, bb), want, rtol=2e-4, atol=2e-4)
+            got = ops.conv1x1_mfma(x, w2t, bb, relu_out=True, add=addt)
+            torch.testing.assert_close(got, (want + addt).relu(), rtol=2e-4, atol=2e-4)
+            assert torch.equal(ops.conv1x1_mfma(x, w2t, bb, add=addt.unsqueeze(0)).relu(), got)
         with pytest.raises(ValueError):
-            ops.conv1x1_mfma(torch.randn(1, 6, 4, 4, device="cuda"), torch.zeros(6, 256, device="cuda"), b2)
+            ops.conv1x1_mfma(x, w2t, bb, add=addt[:, :4])
+        with pytest.raises(ValueError):
+            ops.conv1x1_mfma(x, w2t, bb, add=addt, head_weight=torch.zeros(1, 256, 1, 1, device="cuda"))
+        with pytest.raises(ValueError):
+            ops.conv1x1_mfma(torch.randn(1, 6, 3, 3, device="cuda"), torch.zeros(6, 256, device="cuda"), b2)  # h*w % 4
         # the head's output layer fused into layer4's pointwise kernel: Conv2d(256, 1, 1)(relu(z)) without z in memory
         x = torch.randn(3, 256, 27, 36, device="cuda")
         w2t = torch.randn(256, 256, device="cuda") * 0.05
