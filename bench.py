@@ -43,6 +43,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# dmabuf IPC only on these hosts: RCCL's device-buffer exchange between the ranks of a node fails without it
+# (hipIpcGetMemHandle: invalid argument).  Set before the HIP runtime loads, also when a launcher started this rank.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -306,7 +306,7 @@ class PreparedBank:
                                                                   _stream_ptr(dev))
             _lib.check(rc2, "manet_global_match_refine_rescued_async")
             ad["event"] = torch.cuda.Event()
-            ad["event"].record()
+            ad["event"].record(torch.cuda.current_stream(dev))  # (the stream the launches above went to: _stream_ptr(dev))
         if rc != 0 and armed:
             # the armed workspace is only all-0xff again once the finish kernel has run: after a failed call nothing is
             # known about it -- drop it, the next armed call fills a fresh one
