@@ -571,7 +571,7 @@ def exact_leg(cfg, device, lib, args):
 
 def robustness_block(device, lib, args):
     """every distribution-dependent claim bracketed in the driver-run line.  cfg2 shape (480p, T=5,
-    2 ids, d=12), fp32-stored embeddings, data in {iid, video, smooth} (tools/synth_clip.py) x scale in {0.1, 0.3} x
+    2 ids, d=12), fp32-stored embeddings, data in {iid, video, smooth, flat} (tools/synth_clip.py) x scale in {0.1, 0.3} x
     compute in {f32, bf16, bf16r}: ms per step of the same step the headline times (K steps over non-bank frames),
     error of the normalised global map of one non-bank frame against the fp32 result (the f32 kernel, itself checked
     against the CPU oracle on a pixel sample right here) and, for bf16r, the candidate rows per (query, object) pair and
@@ -580,8 +580,8 @@ def robustness_block(device, lib, args):
     from oracle import oracle as orc
     K, Wm = args.robust_steps, 3
     legs = []
-    for data in ("iid", "video", "smooth"):
-        for scale in (0.1, 0.3):
+    for data in ("iid", "video", "smooth", "flat"):
+        for scale in ((0.1, 0.3) if data != "flat" else (0.1,)):
             ref_norm, oracle_ok = None, None
             for compute in ("f32", "bf16", "bf16r"):
                 wl = Workload(2, compute, "f32", device, n_local=CONFIGS[2]["T"] + 2, data=data, scale=scale)
@@ -621,15 +621,16 @@ def robustness_block(device, lib, args):
 
     def pick(data, compute, key, scale=0.1):
         return next(l[key] for l in legs if l["data"] == data and l["compute"] == compute and l["scale"] == scale)
-    summary = {"bf16r_frames_per_s_best_typical_worst": [pick("iid", "bf16r", "frames_per_s"), pick("video", "bf16r", "frames_per_s"),
-                                                         pick("smooth", "bf16r", "frames_per_s")],
+    summary = {"bf16r_frames_per_s_iid_video_smooth_flat": [pick(d, "bf16r", "frames_per_s") for d in ("iid", "video", "smooth", "flat")],
                "f32_frames_per_s": pick("iid", "f32", "frames_per_s"),
-               "bf16_max_err_scale_0.1": max(pick(d, "bf16", "err_vs_fp32_oracle_normalised_max") for d in ("iid", "video", "smooth")),
+               "bf16_max_err_scale_0.1": max(pick(d, "bf16", "err_vs_fp32_oracle_normalised_max") for d in ("iid", "video", "smooth", "flat")),
                "bf16_max_err_scale_0.3": max(pick(d, "bf16", "err_vs_fp32_oracle_normalised_max", 0.3) for d in ("iid", "video", "smooth"))}
     return {"shape": "cfg2 (480p grid 120x214, T=5, 2 ids, d=12), fp32-stored embeddings, %d steps per leg over non-bank frames" % K,
             "data_kinds": "iid = relu(randn) + uniform labels (best case); video = smooth field + per-pixel detail + object "
                           "clusters, temporally adjacent bank frames, blob labels (typical); smooth = 32-pixel bilinear "
-                          "fields, near-identical frames (worst case) -- tools/synth_clip.py",
+                          "fields, near-identical frames (hard: whole blocks of the bf16 filter qualify -- dense entries of the "
+                          "re-rank); flat = every pixel of an object carries the same vector (the floor: every tile goes to the "
+                          "exact fp32 kernel, the adaptive policy then skips the filter) -- tools/synth_clip.py",
             "reference": "normalised global map of a non-bank frame from the fp32 kernel (checked against the CPU oracle on "
                          "a 512-pixel sample per data kind, raw distances bit for bit: f32_kernel_equals_cpu_oracle_on_sample)",
             "summary": summary, "legs": legs}
@@ -740,7 +741,7 @@ def main():
     ap.add_argument("--scaling", type=str, default="weak", choices=["weak", "strong"],
                     help="weak: K frames per rank (the driver's contract); strong: a fixed 64-frame clip (BASELINE "
                          "configs[3]) cut into 64 / N frames per rank (--steps is ignored)")
-    ap.add_argument("--data", type=str, default="iid", choices=["iid", "video", "smooth"],
+    ap.add_argument("--data", type=str, default="iid", choices=["iid", "video", "smooth", "flat"],
                     help="embedding distribution of the main leg (tools/synth_clip.py): iid = SURVEY 8d's relu(randn) with "
                          "uniform labels (the headline); video / smooth = spatially smooth, temporally redundant, "
                          "label-coherent clips (N = 1 only).  The default line brackets all three in `robustness`.")

@@ -59,8 +59,27 @@ int refine_sub(long T_max)
 #define MANET_REFINE_XCHG_MASK 3
 #endif
 constexpr int REFINE_XCHG_MASK = MANET_REFINE_XCHG_MASK;  // threshold exchange every (mask + 1) steps
-constexpr int REFINE_CAP = 64;  // capacity of a candidate bucket (one per 32-query block), in rows per (query, object) pair ON AVERAGE
-constexpr int REFINE_LDS_LIST = 2048;  // candidate entries a filter workgroup collects in LDS before it appends them in bulk
+#ifndef MANET_REFINE_CAP
+#define MANET_REFINE_CAP 128
+#endif
+#ifndef MANET_REFINE_LDS_LIST
+#define MANET_REFINE_LDS_LIST 2048
+#endif
+constexpr int REFINE_CAP = MANET_REFINE_CAP;  // capacity of a candidate bucket (one per 32-query block), in rows per (query, object) pair ON AVERAGE
+constexpr int REFINE_LDS_LIST = MANET_REFINE_LDS_LIST;  // candidate entries a filter workgroup collects in LDS before it appends them in bulk
+// A 32-query x 32-row block with more qualifying distances than a sub-list holds is listed as ONE "dense" entry {block's
+// first pair, 0x80000000 | first bank slot of the pass}: the re-rank evaluates all of its 1 024 distances exactly.  At most
+// REFINE_DENSE_CAP of them per 32-query bucket (counted in bcnt's second half); one more marks the bucket incomplete and
+// the rescue pass (the exact fp32 kernel on the 256-query tile) takes over.  A dense entry is one 32 x 32 x C tile on the fp32
+// matrix pipe for ONE wave (1.4 us at C = 100, operands from global memory / LDS per entry): 1 024 of them in every bucket of a
+// 480p frame are ~1.1 ms of the chip, a quarter of the fp32 kernel -- beyond that the fp32 kernel's operand reuse wins.
+#ifndef MANET_REFINE_DENSE_CAP
+#define MANET_REFINE_DENSE_CAP 1024
+#endif
+constexpr int REFINE_DENSE_CAP = MANET_REFINE_DENSE_CAP;
+constexpr unsigned REFINE_DENSE_BIT = 0x80000000u;
+constexpr int REFINE_RZ = 4;  // workgroups of the re-rank launch per bucket: each takes every 4th entry (the longest bucket is the launch's time)
+constexpr int RESCUE_LISTED = 1 << 30;  // block_map flag of the rescue launch: deal the workgroups to the LISTED tiles
 
 // Packed operand image of one row block: `units` 16-byte units per row, stored [unit][row][16 B].
 //   f32    unit u = 2g+h holds k = 8g + 2j + h, j = 0..3 (4 floats)      -> v_mfma_f32_32x32x2_f32
@@ -220,7 +239,9 @@ MatchLayout match_layout(int64_t N, int C, int n_ids, int compute, int k_nn = 1,
         L.bucket_cap = (long)n_ids * QB * REFINE_CAP;
         L.off_stats = manet_align_up(L.off_list + (size_t)L.list_cap * sizeof(uint2), 256);
         L.off_bcnt = L.off_stats + 256;
-        L.off_q32 = manet_align_up(L.off_bcnt + (size_t)(L.N_pad / QB) * sizeof(unsigned), 1024);  // fp32 query image (rescue)
+        // (bcnt: [N_pad / 32] entries appended | bit 31 incomplete, then [N_pad / 32] dense entries appended)
+        // then {number of 256-query tiles to rescue, their ids} (written by the re-rank launch, read by the rescue launch)
+        L.off_q32 = manet_align_up(L.off_bcnt + ((size_t)2 * (L.N_pad / QB) + 1 + (size_t)(L.N_pad / QT)) * sizeof(unsigned), 1024);  // fp32 query image (rescue)
         L.total = manet_align_up(L.off_q32 + (size_t)(L.N_pad / QB) * geom_of(C, MANET_COMPUTE_F32).qblk_bytes, 1024);
     }
     return L;
@@ -1155,14 +1176,50 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_pipe_kernel(const cha
 
     int qt, s, t0, t1;
     const int T = meta[META_T];
-    if (!split_of_block(blockIdx.x, nQT, S, T, block_map, qt, s, t0, t1)) return;
-    if (RESCUE) {
-        bool need = false;
-        for (int i = 0; i < QT / QB; ++i) {
-            const unsigned raw = bcnt[(long)qt * (QT / QB) + i];
-            need = need || (raw >> 31) || (long)raw > bucket_cap;
+    if (RESCUE && (block_map & RESCUE_LISTED)) {
+        // the tiles to rescue were listed by the re-rank launch (rs = {count, tile ids}, behind bcnt's two halves): the
+        // launch's workgroups are dealt to THOSE tiles, with as many bank splits each as the grid allows -- a frame with a
+        // handful of incomplete tiles spreads them over the whole chip instead of leaving each to 16 workgroups (r4: 1.5 ms
+        // for 4 of 102 tiles at cfg2 size, the time one workgroup needs for a 16th of the bank)
+        const unsigned *rs = bcnt + 2 * (N_pad >> 5);
+        const int nr = (int)rs[0];
+        if (nr <= 0) return;
+        // splits per tile: whole rounds of the chip's 512 workgroup slots (a workgroup's fixed cost -- its 106 KB query
+        // operand, the pipeline fill, the closing atomics -- is worth ~6 tiles of matrix work: few long workgroups beat many
+        // short ones; 4 tiles of 102 at cfg2 size: 390 us with 404 splits of 5 tiles, 3.2 rounds)
+        int Sd = (block_map >> 8) & 0x3fffff;  // (experiments: MANET_TUNE_RESCUE_SPLITS)
+        if (Sd > 0) {
+            const int most_grid = (int)gridDim.x / nr;
+            Sd = Sd > most_grid ? most_grid : Sd;
+            Sd = Sd < 1 ? 1 : Sd;
+        } else {
+            const int most_grid = (int)gridDim.x / nr, most_t = T / 8 > 1 ? T / 8 : 1;
+            const int most = most_grid < most_t ? most_grid : most_t;
+            long best = -1;
+            for (int r = 1; r <= 4; ++r) {
+                int c = (512 * r) / nr;
+                c = c < 1 ? 1 : (c > most ? most : c);
+                const long rounds = ((long)nr * c + 511) / 512;
+                const long cost = rounds * ((long)(T + c - 1) / c + 6);
+                if (best < 0 || cost < best) { best = cost; Sd = c; }
+            }
         }
-        if (!need) return;  // (wave-uniform: every lane read the same eight counters)
+        if ((int)blockIdx.x >= nr * Sd) return;
+        s = (int)blockIdx.x / nr;
+        qt = (int)rs[1 + ((int)blockIdx.x - s * nr)];
+        t0 = (int)((long)s * T / Sd);
+        t1 = (int)((long)(s + 1) * T / Sd);
+        if (t0 >= t1) return;
+    } else {
+        if (!split_of_block(blockIdx.x, nQT, S, T, block_map, qt, s, t0, t1)) return;
+        if (RESCUE) {
+            bool need = false;
+            for (int i = 0; i < QT / QB; ++i) {
+                const unsigned raw = bcnt[(long)qt * (QT / QB) + i];
+                need = need || (raw >> 31) || (long)raw > bucket_cap;
+            }
+            if (!need) return;  // (wave-uniform: every lane read the same eight counters)
+        }
     }
 
     const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
@@ -1885,8 +1942,10 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     // The hits of one 32 x 32 block go to sub-list j optimistically (the fast path is the loop above and one scalar compare).
     // If they did not fit behind what the sub-list held, nothing is lost: the sub-list is rolled back to its old fill,
     // flushed to its bucket, and the block is listed again into the empty sub-list.  A block with more hits than a whole
-    // sub-list (> 128 of its 1 024 distances inside the threshold: embeddings the bf16 pass cannot tell apart) is not
-    // listed at all -- its bucket is marked incomplete and the rescue pass (the exact fp32 kernel) takes that query tile.
+    // sub-list (> 128 of its 1 024 distances inside the threshold: embeddings the bf16 pass cannot tell apart) is listed as
+    // ONE dense entry (r4; REFINE_DENSE_CAP per bucket, beyond that the bucket is marked incomplete and the rescue pass --
+    // the exact fp32 kernel -- takes that query tile; through r4's first captures every such block went to the rescue pass:
+    // 99 % of the tiles of a spatially smooth clip).
     auto emit = [&](const f32x16 &c, float t, int j, int row0) __attribute__((always_inline)) {
         const int before = wl_n[j];
         emit_regs(c, t, j, row0);
@@ -1895,7 +1954,16 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
             wl_n[j] = before;
             flush_sub(j);
             if (total > WL) {
-                if (lane == 0) atomicOr(&bcnt[(long)qt * (QTB / QB) + wave * NQB + j], 0x80000000u);  // (bit 31: incomplete)
+                // a DENSE block (embeddings the bf16 pass cannot tell apart over this neighbourhood): one entry for its 1 024
+                // distances, into the sub-list that was just emptied; the bucket's dense count lives behind the fill counts
+                int b32 = qt * (QTB / QB) + wave * NQB + j, nb32 = (int)(N_pad >> 5);
+                asm volatile("" : "+s"(b32), "+s"(nb32));
+                if (lane == 0) {
+                    if (atomicAdd(&bcnt[(long)nb32 + b32], 1u) >= (unsigned)REFINE_DENSE_CAP)
+                        atomicOr(&bcnt[b32], 0x80000000u);  // (bit 31: incomplete -- the rescue pass takes this query tile)
+                    fl[j * WL] = make_uint2(((unsigned)o << 16) | (unsigned)(wave * (NQB * QB) + 32 * j), REFINE_DENSE_BIT | (unsigned)row0);
+                }
+                wl_n[j] = 1;
                 wl_total += total;  // (statistics: qualifying rows SEEN)
             } else
                 emit_regs(c, t, j, row0);
@@ -2191,7 +2259,7 @@ __global__ void refine_threshold_kernel(const unsigned *__restrict__ keys, const
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) stats[0] = stats[1] = 0ull;
-    if (i < N_pad / QB) bcnt[i] = 0u;
+    if (i <= 2 * (N_pad / QB)) bcnt[i] = 0u;  // (entries appended, dense entries appended, number of tiles to rescue)
     if (i >= (long)n_ids * N_pad) return;
     const long n = i % N_pad;
     const int o = (int)(i / N_pad);
@@ -2232,6 +2300,7 @@ __global__ void refine_force_kernel(long N_pad, int n_ids, unsigned *__restrict_
         stats[1] = 1ull;
     }
     if (i < N_pad / QB) bcnt[i] = 0x80000000u;
+    if (i == 0) bcnt[2 * (N_pad / QB)] = 0u;  // (the re-rank launch lists the tiles to rescue: all of them)
     if (i < (long)n_ids * N_pad) keys2[i] = 0xffffffffu;
 }
 
@@ -2270,7 +2339,7 @@ __global__ void refine_rescued_kernel(const unsigned *__restrict__ bcnt, long ti
 template <typename SRC>
 __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restrict__ q, long q_sn, long q_sc,
                                                             const float *__restrict__ rows, const float *__restrict__ norms,
-                                                            const uint2 *__restrict__ list, const unsigned *__restrict__ bcnt,
+                                                            const uint2 *__restrict__ list, unsigned *__restrict__ bcnt,
                                                             long bucket_cap, long N, long N_pad, int C,
                                                             unsigned *__restrict__ keys2, unsigned long long *__restrict__ stats,
                                                             char *__restrict__ q32, int units32, long qblk_bytes32)
@@ -2293,14 +2362,23 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restric
             rescue = rescue || (r2 >> 31) || (long)r2 > bucket_cap;
         }
     }
+    const int z = blockIdx.y;  // this workgroup's share of the bucket: entries z, z + REFINE_RZ, ...
+    if (rescue && tid == 0 && z == 0 && b % (QT / QB) == 0) {  // the tile's first block lists it for the rescue launch
+        unsigned *rs = bcnt + 2 * (N_pad / QB);
+        rs[1 + atomicAdd(&rs[0], 1u)] = (unsigned)(b / (QT / QB));
+    }
+    if (z > 0 && (rescue || cnt <= z)) return;  // (a rescued tile's candidates are moot; its image is written by z == 0)
     if (cnt == 0 && !rescue) return;
+    __shared__ int dense_n;
+    __shared__ int dense_at[REFINE_DENSE_CAP];
+    if (tid == 0) dense_n = 0;
     for (int idx = tid; idx < QB * C; idx += 256) {
         long n = b * QB + (idx & (QB - 1));
         n = n < N ? n : N - 1;  // (padding queries have no candidates)
         qs[idx] = emb_load(q + n * q_sn, (long)(idx / QB) * q_sc);
     }
     __syncthreads();
-    if (rescue) {  // (block-uniform) the block's image as pack_rows_kernel<32,32> writes it for MANET_COMPUTE_F32
+    if (rescue) {  // (block-uniform; z == 0) the block's image as pack_rows_kernel<32,32> writes it for MANET_COMPUTE_F32
         char *out0 = q32 + b * qblk_bytes32;
         for (int item = tid; item < units32 * QB; item += 256) {
             const int r = item & (QB - 1), u = item / QB;
@@ -2315,9 +2393,17 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restric
             for (int k = 0; k < C; ++k) nrm = fmaf(qs[k * QB + tid], qs[k * QB + tid], nrm);
             *(float *)(out0 + (long)units32 * QB * 16 + tid * 4) = nrm;
         }
+        return;  // (the rescue pass evaluates every pair of this tile: its candidates are moot)
     }
-    for (int i = tid; i < cnt; i += 256) {
+    for (int i = z + REFINE_RZ * tid; i < cnt; i += REFINE_RZ * 256) {
         const uint2 e = list[b * bucket_cap + i];
+        if (e.y & REFINE_DENSE_BIT) {  // a dense block: the whole workgroup evaluates it below
+            if (!rescue) {             // (a tile that is rescued anyway gets every distance from the fp32 kernel)
+                const int at = atomicAdd(&dense_n, 1);
+                if (at < REFINE_DENSE_CAP) dense_at[at] = i;  // (more than the cap: the filter pass marked the bucket incomplete)
+            }
+            continue;
+        }
         const float *x = qs + (int)((e.x % (unsigned long)N_pad) & (QB - 1));
         const float *kr = rows + (long)e.y * C;
         float xs = 0.0f, mm = 0.0f;
@@ -2339,6 +2425,59 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restric
             mm = fmaf(xv, kr[k], mm);
         }
         atomicMin(keys2 + e.x, key_of(fmaf(-2.0f, mm, xs + norms[e.y])));  // IntVOS.py:39
+    }
+    __syncthreads();
+    // dense entries: 32 bank rows x this block's 32 queries each -- exactly one 32 x 32 tile of the fp32 matrix pipe: a WAVE
+    // per entry, A = the 32 bank rows (lane = row, read from the fp32 copy of the bank), B = the block's queries from LDS,
+    // ceil(C / 2) v_mfma_f32_32x32x2_f32 in k order -- the fp32 kernel's own chain for these pairs, hence its bits.  (First
+    // form: VALU, a thread per (query, 4 rows): 1.4 us per entry per workgroup, a quarter of the CU's rate.)
+    const int nd = dense_n < REFINE_DENSE_CAP ? dense_n : REFINE_DENSE_CAP;
+    if (nd > 0) {
+        const int lane = tid & 63, w = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+        const float *x = qs + l31;
+        float xs = 0.0f;
+        for (int k = 0; k < C; ++k) xs = fmaf(x[k * QB], x[k * QB], xs);
+        for (int d = w; d < nd; d += 4) {
+            const uint2 e = list[b * bucket_cap + dense_at[d]];
+            const long slot0 = (long)(e.y & ~REFINE_DENSE_BIT);
+            const float *kr = rows + (slot0 + l31) * C;
+            f32x16 acc = {0};
+            if ((C & 3) == 0) {
+                for (int k0 = 0; k0 < C; k0 += 20) {  // five 16-byte loads in flight = ten k-steps
+                    f32x4 y[5];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) y[j] = (k0 + 4 * j < C) ? *(const f32x4 *)(kr + k0 + 4 * j) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        if (k0 + 4 * j < C) {  // (wave-uniform)
+                            const int k = k0 + 4 * j + hh;  // this half's k of the step: even lanes' half 2s, the other 2s + 1
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? y[j][1] : y[j][0], x[k * QB], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? y[j][3] : y[j][2], x[(k + 2) * QB], acc, 0, 0, 0);
+                        }
+                    }
+                }
+            } else {
+                for (int k0 = 0; k0 < C; k0 += 2) {
+                    const int k = k0 + hh;
+                    const bool ok = k < C;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? kr[k] : 0.0f, ok ? x[k * QB] : 0.0f, acc, 0, 0, 0);
+                }
+            }
+            // C/D layout: column = lane & 31 (query), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (bank row of the pass)
+            unsigned best = 0xffffffffu;
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                const f32x4 nv = *(const f32x4 *)(norms + slot0 + 8 * tq + 4 * hh);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned kd = key_of(fmaf(-2.0f, acc[4 * tq + i], xs + nv[i]));  // IntVOS.py:39
+                    best = kd < best ? kd : best;
+                }
+            }
+            const unsigned other = (unsigned)__shfl_xor((int)best, 32);
+            best = other < best ? other : best;
+            if (hh == 0) atomicMin(keys2 + e.x + l31, best);  // (e.x = the pair of the block's first query)
+        }
     }
 }
 
@@ -2580,13 +2719,17 @@ void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int 
 // the exact fp32 kernel as MANET_COMPUTE_BF16_REFINE's rescue pass (workgroups of complete query tiles return at once)
 template <int KS>
 void launch_rescue_f32_pipe(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S, long N_pad,
-                            unsigned *keys, const unsigned *bcnt, long bucket_cap, hipStream_t st)
+                            unsigned *keys, const unsigned *bcnt, long bucket_cap, bool listed, hipStream_t st)
 {
     size_t lds = 2 * bank_tile_bytes((KS + 3) / 4);
     (void)hipFuncSetAttribute((const void *)global_match_f32_pipe_kernel<KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
+    // listed: the workgroups are dealt to the tiles the re-rank launch listed (few, usually none); else (every tile is
+    // matched: MANET_EPI_REFINE_EXACT) the fp32 kernel's own block map
     hipLaunchKernelGGL((global_match_f32_pipe_kernel<KS, true>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack, bpack, meta,
-                       n_ids, nQT, S, N_pad, keys, block_map_arg(nQT, 512, S), bcnt, bucket_cap);
+                       n_ids, nQT, S, N_pad, keys,
+                       listed ? (RESCUE_LISTED | ((manet_tune_get(MANET_TUNE_RESCUE_SPLITS, 0) & 0x3fffff) << 8)) : block_map_arg(nQT, 512, S),
+                       bcnt, bucket_cap);
 }
 
 template <int KS>
@@ -2757,17 +2900,17 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
     }  // (!force_exact)
     // 4. exact re-rank of the candidates
     const float *rows = (const float *)(bws + BL.off_rows), *norms = (const float *)(bws + BL.off_norms);
-    const dim3 rgrid((unsigned)(ML.N_pad / QB));
+    const dim3 rgrid((unsigned)(ML.N_pad / QB), REFINE_RZ);
     const size_t rlds = (size_t)QB * C * sizeof(float);
     const Geom G32 = BL.G32;
     char *q32 = mws + ML.off_q32;
     if (q_dtype == MANET_EMB_F32)
         hipLaunchKernelGGL(refine_rerank_kernel<float>, rgrid, dim3(256), rlds, st, (const float *)qraw, q_sn, q_sc, rows, norms,
-                           (const uint2 *)list, (const unsigned *)bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2, stats, q32, G32.units,
+                           (const uint2 *)list, bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2, stats, q32, G32.units,
                            (long)G32.qblk_bytes);
     else
         hipLaunchKernelGGL(refine_rerank_kernel<unsigned short>, rgrid, dim3(256), rlds, st, (const unsigned short *)qraw, q_sn, q_sc,
-                           rows, norms, (const uint2 *)list, (const unsigned *)bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2, stats, q32,
+                           rows, norms, (const uint2 *)list, bcnt, ML.bucket_cap, N, ML.N_pad, C, keys2, stats, q32,
                            G32.units, (long)G32.qblk_bytes);
     // 5. rescue: the 256-query tiles that hold a 32-query block whose bucket is incomplete (a block's hits were not listed,
     //    or the bucket overflowed) go through the exact fp32 kernel against the whole bank -- their fp32 operand image was
@@ -2783,10 +2926,10 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
         tl_bank_bytes_hint = (double)BL.T_max * (double)G32.tile_bytes;
         const char *bpack32 = bws + BL.off_pack32;
         switch (G32.steps) {
-        case 16: launch_rescue_f32_pipe<16>(q32, bpack32, meta, n_ids, nQT32, S32, ML.N_pad, keys2, bcnt, ML.bucket_cap, st); break;
-        case 50: launch_rescue_f32_pipe<50>(q32, bpack32, meta, n_ids, nQT32, S32, ML.N_pad, keys2, bcnt, ML.bucket_cap, st); break;
-        case 52: launch_rescue_f32_pipe<52>(q32, bpack32, meta, n_ids, nQT32, S32, ML.N_pad, keys2, bcnt, ML.bucket_cap, st); break;
-        default: launch_rescue_f32_pipe<64>(q32, bpack32, meta, n_ids, nQT32, S32, ML.N_pad, keys2, bcnt, ML.bucket_cap, st); break;
+        case 16: launch_rescue_f32_pipe<16>(q32, bpack32, meta, n_ids, nQT32, S32, ML.N_pad, keys2, bcnt, ML.bucket_cap, !force_exact, st); break;
+        case 50: launch_rescue_f32_pipe<50>(q32, bpack32, meta, n_ids, nQT32, S32, ML.N_pad, keys2, bcnt, ML.bucket_cap, !force_exact, st); break;
+        case 52: launch_rescue_f32_pipe<52>(q32, bpack32, meta, n_ids, nQT32, S32, ML.N_pad, keys2, bcnt, ML.bucket_cap, !force_exact, st); break;
+        default: launch_rescue_f32_pipe<64>(q32, bpack32, meta, n_ids, nQT32, S32, ML.N_pad, keys2, bcnt, ML.bucket_cap, !force_exact, st); break;
         }
         if (force_exact) manet_profile_record(st, false, 0);
     }

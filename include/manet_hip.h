@@ -63,8 +63,12 @@ typedef void *manet_stream_t; /* a hipStream_t */
  * arg-min row may drop every other one.  A bf16 pre-pass over every 8th bank tile bounds the minimum, a bf16 pass over
  * the whole bank keeps the rows whose bf16 distance is within the rounding bound of that, and those few are re-evaluated in
  * the reference's fp32 arithmetic (the fmaf chains of MANET_COMPUTE_F32): the result EQUALS MANET_COMPUTE_F32's bit for bit
- * at about 1.4x the cost of MANET_COMPUTE_BF16 on embeddings the bf16 pass can tell apart (blocks of queries it cannot are
- * re-done by the exact fp32 kernel: the worst case costs the fp32 path's time plus the filter's; manet_global_match_refine_stats2).
+ * at about 1.4x the cost of MANET_COMPUTE_BF16 on embeddings the bf16 pass can tell apart.  Where it cannot -- a 32-query x
+ * 32-row block of which more than an eighth qualifies -- the block is listed whole and its 1 024 distances are re-evaluated on
+ * the fp32 matrix pipe by the re-rank (spatially smooth embeddings: ~1.8x the cost of MANET_COMPUTE_BF16); a 32-query block with
+ * more than 1 024 such blocks, or more than 128 listed rows per pair on average, sends its 256-query tile through the exact
+ * fp32 kernel instead (dealt to the listed tiles only; if that is every tile -- e.g. all rows of an object identical -- the
+ * frame costs the fp32 path's time plus the filter's: manet_global_match_refine_stats2, MANET_EPI_REFINE_EXACT).
  * NaN embeddings propagate as in MANET_COMPUTE_F32: a NaN bank row makes its own object's minimum NaN for every query, a NaN
  * query row its own pixel's, every other pair keeps the fp32 bits. */
 #define MANET_COMPUTE_BF16_REFINE 3
@@ -195,8 +199,8 @@ int manet_embed_finish(const float *conv_out, int64_t s_f, int64_t s_y, int64_t 
  * manet_query_pack with MANET_COMPUTE_BF16 or _BF16_REFINE): the fp32 re-rank also needs the query as stored, so this entry
  * point takes both.  query_image == NULL: same as manet_global_match_prepared_ex(..., MANET_COMPUTE_BF16_REFINE, ...).
  * manet_global_match_refine_stats reads back (blocking copy -- tests / benchmarks) what the last call on `match_ws` did:
- * qualifying bank rows seen by the filter pass, and whether some 32-query block's candidate bucket (64 rows per pair on
- * average) was incomplete -- 1: the 256-query tiles of those blocks also went through the exact fp32 kernel (the bank
+ * qualifying bank rows seen by the filter pass, and whether some 32-query block's candidate bucket (128 rows per pair on
+ * average, 1 024 whole 32 x 32 blocks) was incomplete -- 1: the 256-query tiles of those blocks also went through the exact fp32 kernel (the bank
  * workspace of this mode carries the fp32 operand image beside the bf16 one for that), which bounds the cost of any input at
  * about the fp32 path's; 0: the usual case. */
 int manet_global_match_refine(const void *query, int emb_dtype, int64_t q_stride_n, int64_t q_stride_c,

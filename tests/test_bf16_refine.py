@@ -77,21 +77,53 @@ def test_prepared_bank_frames_and_2_byte_storage(ops):
         assert over == 0 and h * w <= cands < 16 * h * w * n_ids
 
 
-def test_adversarial_duplicate_rows_overflow_every_list(ops):
-    """a bank that is 40 copies of a handful of rows: 120 equally good rows per pair overflow the candidate list (16 per pair
-    on average), every pair falls back to scanning its object's rows -- still the fp32 kernel's bits"""
+def test_adversarial_duplicate_rows_dense_blocks_and_beyond(ops):
+    """banks that are many copies of a handful of rows: whole 32-query x 32-row blocks qualify.  (a) 40 copies: every block
+    is listed as ONE dense entry and re-ranked exactly (r4; before, such a block sent its 256-query tile to the rescue pass);
+    (b) 11 000 copies: more dense blocks per 32-query bucket than REFINE_DENSE_CAP (1 024) -- the buckets are marked incomplete
+    and the rescue pass (the exact fp32 kernel) takes every tile.  Either way the fp32 kernel's bits."""
     N, C, n_ids = 300, 100, 2
     g = torch.Generator(device="cuda").manual_seed(21)
     q = torch.relu(torch.randn(N, C, generator=g, device="cuda")) * 0.2
     base = torch.relu(torch.randn(6, C, generator=g, device="cuda")) * 0.2
-    k = base.repeat(40, 1)
-    lab = (torch.arange(240, device="cuda") % 6 < 3).to(torch.int32)
-    want = ops.global_match(k, q, lab, n_ids, compute="f32")
-    bank = ops.PreparedBank(k, lab, n_ids, compute="bf16r")
-    got = bank.match(q)
-    assert torch.equal(got, want)
-    cands, over = bank.refine_stats()
-    assert over == 1 and cands >= 16 * N * n_ids  # every bucket overflowed, the rescue scan ran, the result is still exact
+    for copies, rescued in ((40, False), (2200, False), (11000, True)):
+        k = base.repeat(copies, 1)
+        lab = (torch.arange(6 * copies, device="cuda") % 6 < 3).to(torch.int32)
+        want = ops.global_match(k, q, lab, n_ids, compute="f32")
+        bank = ops.PreparedBank(k, lab, n_ids, compute="bf16r")
+        got = bank.match(q, adaptive=False)
+        assert torch.equal(got, want)
+        st = bank.refine_stats_full()
+        assert st["candidate_rows"] >= 16 * N * n_ids  # (rows SEEN: the dense blocks' hits count in full)
+        if rescued:
+            assert st["list_overflowed"] == 1 and st["rescued_tiles"] == st["query_tiles"] > 0
+        else:
+            assert st["list_overflowed"] == 0 and st["rescued_tiles"] == 0
+
+
+def test_dense_blocks_with_nan_and_2_byte_storage(ops):
+    """dense entries take the same chains as listed rows: NaN rows / queries propagate as in the fp32 kernel, bf16-stored
+    embeddings re-rank from the stored values"""
+    N, C, n_ids = 200, 100, 3
+    g = torch.Generator(device="cuda").manual_seed(5)
+    base = torch.relu(torch.randn(4, C, generator=g, device="cuda")) * 0.2
+    k = (base.repeat(100, 1) + 1e-4 * torch.randn(400, C, generator=g, device="cuda")).contiguous()
+    lab = (torch.arange(400, device="cuda") % 3).to(torch.int32)
+    q = (base[torch.randint(0, 4, (N,), generator=g, device="cuda")] + 1e-4 * torch.randn(N, C, generator=g, device="cuda")).contiguous()
+    for storage in (torch.float32, torch.bfloat16):
+        ks, qs = k.to(storage), q.to(storage)
+        want = ops.global_match(ks, qs, lab, n_ids, compute="f32")
+        bank = ops.PreparedBank(ks, lab, n_ids, compute="bf16r")
+        assert torch.equal(bank.match(qs, adaptive=False), want)
+        assert bank.refine_stats_full()["rescued_tiles"] == 0
+    kn = k.clone()
+    kn[7, 3] = float("nan")  # object 7 % 3 == 1
+    qn = q.clone()
+    qn[11, 0] = float("nan")
+    want = ops.global_match(kn, qn, lab, n_ids, compute="f32")
+    got = ops.PreparedBank(kn, lab, n_ids, compute="bf16r").match(qn, adaptive=False)
+    assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(want, nan=-1.0))
+    assert bool(torch.isnan(got[:, 1]).all()) and bool(torch.isnan(got[11]).all())
 
 
 @pytest.mark.parametrize("cfg", [3, 5])
@@ -147,22 +179,29 @@ def test_spatially_smooth_embeddings_do_not_overflow(ops):
 
 def test_partly_degenerate_embeddings_rescue_only_their_blocks(ops):
     """a band of the image where every embedding is the SAME vector (nothing for the bf16 pass to tell apart: hundreds of
-    bank rows tie for every query of the band): those 32-query blocks are marked incomplete and re-evaluated exactly by
-    the rescue pass (the exact fp32 kernel on their query tiles), the rest of the frame goes through the candidate lists; the result is the fp32 kernel's, bit for bit"""
+    bank rows tie for every query of the band).  (a) a band of 25 bank rows x 64 columns: 50 dense 32 x 32 blocks per
+    bucket -- re-ranked exactly, no rescue (r4); (b) the same vector in every row of 15 more bank frames: more dense blocks than a
+    bucket takes (1 024) -- the band's query tiles, and only those, go through the rescue pass (the exact fp32 kernel, dealt to
+    the listed tiles); the rest of the frame goes through the candidate lists.  The result is the fp32 kernel's, bit for bit."""
     H, W, n_ids = 40, 64, 2
     g = torch.Generator(device="cuda").manual_seed(9)
     q = torch.relu(torch.randn(100, H, W, generator=g, device="cuda")) * 0.2
-    ref = torch.relu(torch.randn(100, H, W, generator=g, device="cuda")) * 0.2
     const = torch.relu(torch.randn(100, generator=g, device="cuda")) * 0.2
     q[:, 10:20, :] = const[:, None, None]
-    ref[:, 5:30, :] = (const * 1.001)[:, None, None]
-    lab = torch.randint(0, n_ids, (H * W,), generator=g, device="cuda", dtype=torch.int32)
-    bank_rows = ref.permute(1, 2, 0).reshape(-1, 100)
-    want = ops.global_match(bank_rows, q.permute(1, 2, 0), lab, n_ids, compute="f32")
-    bank = ops.PreparedBank(bank_rows, lab, n_ids, compute="bf16r")
-    assert torch.equal(bank.match(q.permute(1, 2, 0)), want)
-    _, over = bank.refine_stats()
-    assert over == 1  # (the band's blocks were rescued)
+    for frames, rescued in ((1, False), (16, True)):
+        ref = torch.relu(torch.randn(frames, 100, H, W, generator=g, device="cuda")) * 0.2
+        ref[0, :, 5:30, :] = (const * 1.001)[:, None, None]
+        ref[1:] = (const * 1.001)[None, :, None, None]  # (the other queries find their nearest rows in frame 0's random part)
+        lab = torch.randint(0, n_ids, (frames * H * W,), generator=g, device="cuda", dtype=torch.int32)
+        bank_rows = ref.permute(0, 2, 3, 1).reshape(-1, 100)
+        want = ops.global_match(bank_rows, q.permute(1, 2, 0), lab, n_ids, compute="f32")
+        bank = ops.PreparedBank(bank_rows, lab, n_ids, compute="bf16r")
+        assert torch.equal(bank.match(q.permute(1, 2, 0), adaptive=False), want)
+        st = bank.refine_stats_full()
+        if rescued:  # queries 640 .. 1279 are the band: tiles 2, 3, 4 of the 10
+            assert st["list_overflowed"] == 1 and 0 < st["rescued_tiles"] <= 4 and st["query_tiles"] == 10
+        else:
+            assert st["list_overflowed"] == 0 and st["rescued_tiles"] == 0
 
 
 def _same_with_nans(a, b):

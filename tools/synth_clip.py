@@ -12,15 +12,19 @@ spatially smooth, temporally redundant and label-coherent (test.py:142-154 extra
           object's blob; frame t is the SAME scene shifted by `motion` pixels per frame with a little fresh noise (bank
           frames = temporally adjacent perturbations of the query frame); labels = the blobs    -- typical
   smooth  bilinear fields from a 1/32-resolution grid, no detail, frames nearly identical: rows indistinguishable over
-          32-pixel patches and across frames; labels = blobs                -- worst case (every query tile of bf16r is
+          32-pixel patches and across frames; labels = blobs                -- hard case (whole 32 x 32 blocks of the bf16
+          filter qualify: listed as dense entries since r4; through r4's first captures every query tile of bf16r was
           rescued by the exact fp32 kernel)
+  flat    every pixel of an object carries the object's vector + 1e-4 of jitter, in every frame: NOTHING distinguishes the
+          rows of an object                                                  -- the floor (more dense blocks per bucket than
+          the re-rank takes: every tile is rescued by the exact fp32 kernel, and the adaptive policy then skips the filter)
 """
 import math
 
 import torch
 import torch.nn.functional as F
 
-KINDS = ("iid", "video", "smooth")
+KINDS = ("iid", "video", "smooth", "flat")
 
 
 def _blob_labels(n_frames, H, W, n_ids, motion, device):
@@ -55,6 +59,9 @@ def make_clip(kind, n_frames, C, H, W, n_ids, scale=0.1, device="cpu", seed=0, m
         return emb, lab
     lab = _blob_labels(n_frames, H, W, n_ids, motion, device)
     cluster = randn(n_ids, C) * 0.6  # object-specific feature offset (what makes the labels embedding-coherent)
+    if kind == "flat":
+        frames = [torch.relu(cluster[lab[t].long()].permute(2, 0, 1) + 0.5 + 1e-4 * randn(C, H, W)) * scale for t in range(n_frames)]
+        return torch.stack(frames).contiguous(), lab
     if kind == "video":
         coarse, detail_amp, fresh_amp, temporal = 4, 0.45, 0.10, 0.04
     else:  # smooth
