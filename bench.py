@@ -744,7 +744,8 @@ def main():
     ap.add_argument("--data", type=str, default="iid", choices=["iid", "video", "smooth", "flat"],
                     help="embedding distribution of the main leg (tools/synth_clip.py): iid = SURVEY 8d's relu(randn) with "
                          "uniform labels (the headline); video / smooth = spatially smooth, temporally redundant, "
-                         "label-coherent clips (N = 1 only).  The default line brackets all three in `robustness`.")
+                         "label-coherent clips; flat = all rows of an object identical, the floor (N = 1 only).  The default line "
+                         "brackets all of them in `robustness`.")
     ap.add_argument("--scale", type=float, default=0.1, help="embedding scale (SURVEY 8d: 0.1)")
     ap.add_argument("--no-robustness", action="store_true", help="skip the `robustness` legs of the N=1 line")
     ap.add_argument("--robust-steps", type=int, default=10)
