@@ -304,10 +304,11 @@ __global__ __launch_bounds__(PW_NT, 3) void conv1x1_mfma_kernel(const float *__r
                 lds_dma16(w2t + (long)(k0 + row) * PW_CO + lane * 4, wbase + (unsigned)buf * (unsigned)(PW_KC * PW_CO * 4) + (unsigned)row * 1024u);
         }
         if (wave * 4 < kn) {
-            // (rows past Cin inside a piece re-read row Cin - 1: their weight rows are zero -- layer 1's per-object half has 3)
-            int ch = k0 + wave * 4 + (lane >> 4);
-            ch = ch < Cin ? ch : Cin - 1;
-            lds_dma16(src + (long)ch * HW + pix, xbase + (unsigned)buf * (unsigned)(PW_KC * PW_P * 4) + (unsigned)wave * 1024u);
+            // (rows past Cin inside a piece -- layer 1's per-object half has 3 channels -- are not fetched: their lanes sit the
+            // DMA out, the LDS rows keep zero_tail's zeros (one chunk) or an earlier chunk's values, against zero weight rows)
+            const int ch = k0 + wave * 4 + (lane >> 4);
+            if (ch < Cin)
+                lds_dma16(src + (long)ch * HW + pix, xbase + (unsigned)buf * (unsigned)(PW_KC * PW_P * 4) + (unsigned)wave * 1024u);
         }
     };
     f32x16 acc[2][2];

@@ -126,6 +126,27 @@ def test_dense_blocks_with_nan_and_2_byte_storage(ops):
     assert bool(torch.isnan(got[:, 1]).all()) and bool(torch.isnan(got[11]).all())
 
 
+@pytest.mark.parametrize("C", [4, 7, 16, 26, 30, 50, 99, 101, 106])
+@pytest.mark.parametrize("storage", [torch.float32, torch.bfloat16])
+def test_dense_blocks_over_channel_counts_and_ragged_sizes(ops, C, storage):
+    """the dense re-rank's 32 x 32 x C matrix tile: C a multiple of 4 (16-byte row reads) or not (the generic k loop), the
+    small-C filter kernel (C <= 26) and the C = 100-class one, query counts that are not multiples of 32 / 256, a bank whose
+    last tile is partly padding; near-duplicate rows so that whole blocks qualify"""
+    N, n_ids = 333, 3
+    g = torch.Generator(device="cuda").manual_seed(1000 + C)
+    base = torch.relu(torch.randn(5, C, generator=g, device="cuda")) * 0.3 + 0.05
+    M = 5 * 131  # 655 rows: objects end inside tiles
+    k = (base.repeat(131, 1) + 2e-4 * torch.randn(M, C, generator=g, device="cuda")).to(storage)
+    lab = (torch.arange(M, device="cuda") % n_ids).to(torch.int32)
+    q = (base[torch.randint(0, 5, (N,), generator=g, device="cuda")] + 2e-4 * torch.randn(N, C, generator=g, device="cuda")).to(storage)
+    want = ops.global_match(k, q, lab, n_ids, compute="f32")
+    bank = ops.PreparedBank(k, lab, n_ids, compute="bf16r")
+    got = bank.match(q, adaptive=False)
+    assert torch.equal(got, want), (C, storage)
+    st = bank.refine_stats_full()
+    assert st["rescued_tiles"] == 0 and st["candidate_rows_per_pair"] > 20.0  # (whole blocks qualified: dense entries)
+
+
 @pytest.mark.parametrize("cfg", [3, 5])
 def test_full_size_bit_equal_and_candidate_count(ops, cfg):
     H, W, T, n_ids = {3: (120, 214, 5, 4), 5: (180, 320, 10, 6)}[cfg]

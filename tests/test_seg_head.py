@@ -269,6 +269,13 @@ def _pointwise_module_cases(M, ops, torch):
             got = ops.conv1x1_mfma(x, w2t, bb, relu_out=True, add=addt)
             torch.testing.assert_close(got, (want + addt).relu(), rtol=2e-4, atol=2e-4)
             assert torch.equal(ops.conv1x1_mfma(x, w2t, bb, add=addt.unsqueeze(0)).relu(), got)
+        # an infinite activation in the LAST channel stays what the contraction makes of it (+-inf by the weight's sign, no NaN
+        # from a zero weight row meeting a copy of it): the rows past Cin are not fetched
+        xi = torch.randn(2, 3, 8, 12, device="cuda")
+        xi[1, 2, 3, 5] = float("inf")
+        wi = torch.randn(3, 256, device="cuda").abs() + 0.1
+        yi = ops.conv1x1_mfma(xi, wi, torch.zeros(256, device="cuda"))
+        assert bool(torch.isinf(yi[1, :, 3, 5]).all()) and bool((yi[1, :, 3, 5] > 0).all()) and not bool(torch.isnan(yi).any())
         with pytest.raises(ValueError):
             ops.conv1x1_mfma(x, w2t, bb, add=addt[:, :4])
         with pytest.raises(ValueError):
