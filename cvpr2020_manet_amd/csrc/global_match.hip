@@ -1904,6 +1904,7 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         asm volatile("" : "+s"(b32), "+s"(sub_off));
         const long b = (long)b32;
         unsigned base = 0u;
+        if (!(ABL & 64))
         if (lane == 0) base = atomicAdd(&bcnt[b], (unsigned)cnt) & 0x7fffffffu;  // (bit 31 = the bucket's "incomplete" mark)
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
         uint2 *dst = list + b * bucket_cap + base;  // (wave-uniform)
@@ -1918,6 +1919,10 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         wl_total += cnt;
     };
     auto emit_regs = [&](const f32x16 &c, float t, int j, int row0) __attribute__((always_inline)) {
+        if (ABL & 128) {  // (timing: the tests without the listing)
+            wl_n[j] += (int)(__popcll(__ballot(c[0] <= t)) & 1);
+            return;
+        }
         const unsigned lq = (unsigned)(wave * (NQB * QB) + l31 + 32 * j);  // query inside the workgroup's 512
         // (four registers at a time first: a block usually has its one or two hits in one group -- 8 tests instead of 16)
 #pragma unroll
@@ -2878,6 +2883,9 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
             if (fabl == 16) fn = (const void *)global_match_bf16_wide_kernel<7, 16, true>;
             if (fabl == 32) fn = (const void *)global_match_bf16_wide_kernel<7, 32, true>;
             if (fabl == 48) fn = (const void *)global_match_bf16_wide_kernel<7, 48, true>;
+            if (fabl == 64) fn = (const void *)global_match_bf16_wide_kernel<7, 64, true>;    // no returning atomic in flush_sub
+            if (fabl == 128) fn = (const void *)global_match_bf16_wide_kernel<7, 128, true>;  // no listing behind the tests
+            if (fabl == 192) fn = (const void *)global_match_bf16_wide_kernel<7, 192, true>;
         }
 #endif
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
