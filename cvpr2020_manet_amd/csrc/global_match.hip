@@ -78,6 +78,14 @@ constexpr int REFINE_LDS_LIST = MANET_REFINE_LDS_LIST;  // candidate entries a f
 #endif
 constexpr int REFINE_DENSE_CAP = MANET_REFINE_DENSE_CAP;
 constexpr unsigned REFINE_DENSE_BIT = 0x80000000u;
+// ... and a block is listed whole as soon as more than REFINE_DENSE_MIN of its 1 024 distances qualify: a listed row costs the
+// re-rank a 400-byte gather of its bank row (C = 100) per (query, row) pair, a dense entry 12.8 KB of coalesced rows per 1 024
+// pairs and 1.4 us of one wave's matrix pipe -- they meet at ~32 rows (cfg5 shape, smooth embeddings: re-rank 1.12 ms of
+// gathers with the threshold at a full sub-list, 128).
+#ifndef MANET_REFINE_DENSE_MIN
+#define MANET_REFINE_DENSE_MIN 32
+#endif
+constexpr int REFINE_DENSE_MIN = MANET_REFINE_DENSE_MIN;
 constexpr int REFINE_RZ = 4;  // workgroups of the re-rank launch per bucket: each takes every 4th entry (the longest bucket is the launch's time)
 constexpr int RESCUE_LISTED = 1 << 30;  // block_map flag of the rescue launch: deal the workgroups to the LISTED tiles
 
@@ -1954,11 +1962,11 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     auto emit = [&](const f32x16 &c, float t, int j, int row0) __attribute__((always_inline)) {
         const int before = wl_n[j];
         emit_regs(c, t, j, row0);
-        if (wl_n[j] > WL) {  // (wave-uniform, rare)
+        if (wl_n[j] > WL || wl_n[j] - before > REFINE_DENSE_MIN) {  // (wave-uniform, rare)
             const int total = wl_n[j] - before;
             wl_n[j] = before;
-            flush_sub(j);
-            if (total > WL) {
+            if (before >= WL || total <= REFINE_DENSE_MIN) flush_sub(j);  // (room for the dense entry / for the block's rows)
+            if (total > REFINE_DENSE_MIN) {
                 // a DENSE block (embeddings the bf16 pass cannot tell apart over this neighbourhood): one entry for its 1 024
                 // distances, into the sub-list that was just emptied; the bucket's dense count lives behind the fill counts
                 int b32 = qt * (QTB / QB) + wave * NQB + j, nb32 = (int)(N_pad >> 5);
@@ -1966,9 +1974,9 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
                 if (lane == 0) {
                     if (atomicAdd(&bcnt[(long)nb32 + b32], 1u) >= (unsigned)REFINE_DENSE_CAP)
                         atomicOr(&bcnt[b32], 0x80000000u);  // (bit 31: incomplete -- the rescue pass takes this query tile)
-                    fl[j * WL] = make_uint2(((unsigned)o << 16) | (unsigned)(wave * (NQB * QB) + 32 * j), REFINE_DENSE_BIT | (unsigned)row0);
+                    fl[j * WL + wl_n[j]] = make_uint2(((unsigned)o << 16) | (unsigned)(wave * (NQB * QB) + 32 * j), REFINE_DENSE_BIT | (unsigned)row0);
                 }
-                wl_n[j] = 1;
+                wl_n[j] += 1;
                 wl_total += total;  // (statistics: qualifying rows SEEN)
             } else
                 emit_regs(c, t, j, row0);

@@ -16,7 +16,7 @@ from cvpr2020_manet_amd import ops  # noqa: E402
 from tools import synth_clip  # noqa: E402
 
 dev = torch.device("cuda", 0)
-H, W, C, T, n_ids = 120, 214, 100, 5, 2
+H, W, C, T, n_ids = (180, 320, 100, 10, 6) if os.environ.get("SHAPE") == "cfg5" else (120, 214, 100, 5, 2)
 kinds = sys.argv[1:] or ["iid", "video", "smooth"]
 for kind in kinds:
     # 2 T + 1 frames, bank = the even ones, query = an odd one in the middle (temporally adjacent to its bank frames)
