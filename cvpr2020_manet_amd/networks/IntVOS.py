@@ -26,6 +26,7 @@ What differs, deliberately:
 """
 from collections import OrderedDict
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -443,6 +444,7 @@ class IntVOS(nn.Module):
         for m in self.semantic_embedding:
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self._dist_mirror = {}             # seq_name -> (data_ptr of its local_map_dist table, {(frame, round): weight})
         self._bank_cache = OrderedDict()   # seq_name -> (identity key, ops.PreparedBank, keyed tensors): _prepared_bank
         self._frame_cache = OrderedDict()  # identity key of a [C,h,w] embedding -> ops.PreparedFrame: _prepared_frame
         self.dynamic_seghead = DynamicSegHead()  # propagation head
@@ -554,6 +556,7 @@ class IntVOS(nn.Module):
         the identity keys can see."""
         self._bank_cache.clear()
         self._frame_cache.clear()
+        self._dist_mirror.clear()
         self._frame_cache_cap = DEFAULT_CACHED_FRAMES
         for m in self.modules():
             if hasattr(m, "_fold_cache"):
@@ -791,15 +794,25 @@ class IntVOS(nn.Module):
                 # python arithmetic first, as the reference: frame == annotated frame raises ZeroDivisionError
                 weight = 1.0 / (abs(frame_num[n] - start_annotated_frame))
                 dist_tab[frame_num[n]][interaction_num - 1] = weight
+                # (host mirror of the weights this module wrote into THIS table: the comparison two lines down then needs no
+                # device read -- in the reference it is a device-to-host synchronisation per frame from the second round on)
+                mirror = self._dist_mirror.get(seq_names[n])
+                if mirror is None or mirror[0] != dist_tab.data_ptr():
+                    mirror = self._dist_mirror[seq_names[n]] = (dist_tab.data_ptr(), {})
+                fkey = int(frame_num[n])
+                # (as the table holds it: rounded to float32)
+                mirror[1][(fkey, interaction_num - 1)] = float(np.float32(weight)) if dist_tab.dtype == torch.float32 else None
                 slot_ = map_tab[frame_num[n]][interaction_num - 1]
                 if prev_frame_nn_features_n.data_ptr() != slot_.data_ptr():  # (not written in place above)
                     slot_.copy_(prev_frame_nn_features_n.squeeze(0).detach())
-                if interaction_num == 1:
-                    prev_frame_nn_features_n = map_tab[frame_num[n]][interaction_num - 1].unsqueeze(0)
-                elif dist_tab[frame_num[n]][interaction_num - 1] > dist_tab[frame_num[n]][interaction_num - 2]:
-                    prev_frame_nn_features_n = map_tab[frame_num[n]][interaction_num - 1].unsqueeze(0)
-                else:
-                    prev_frame_nn_features_n = map_tab[frame_num[n]][interaction_num - 2].unsqueeze(0)
+                newer_wins = True  # (first round: there is nothing older)
+                if interaction_num > 1:
+                    now_, before_ = mirror[1][(fkey, interaction_num - 1)], mirror[1].get((fkey, interaction_num - 2))
+                    if now_ is not None and before_ is not None:
+                        newer_wins = now_ > before_
+                    else:  # a table this module did not fill (or not in this process): ask the device, as the reference does
+                        newer_wins = bool(dist_tab[frame_num[n]][interaction_num - 1] > dist_tab[frame_num[n]][interaction_num - 2])
+                prev_frame_nn_features_n = map_tab[frame_num[n]][interaction_num - (1 if newer_wins else 2)].unsqueeze(0)
                 local_map_dics = (local_map_tmp_dic, local_map_dist_dic)
 
             # ---- head input [n_ids, C+3, h, w] (:663-673)
