@@ -79,14 +79,22 @@ constexpr int REFINE_LDS_LIST = MANET_REFINE_LDS_LIST;  // candidate entries a f
 constexpr int REFINE_DENSE_CAP = MANET_REFINE_DENSE_CAP;
 constexpr unsigned REFINE_DENSE_BIT = 0x80000000u;
 // ... and a block is listed whole as soon as more than REFINE_DENSE_MIN of its 1 024 distances qualify: a listed row costs the
-// re-rank a 400-byte gather of its bank row (C = 100) per (query, row) pair, a dense entry 12.8 KB of coalesced rows per 1 024
-// pairs and 1.4 us of one wave's matrix pipe -- they meet at ~32 rows (cfg5 shape, smooth embeddings: re-rank 1.12 ms of
-// gathers with the threshold at a full sub-list, 128).
+// re-rank a 400-byte gather of its bank row (C = 100) per (query, row) pair, a dense entry 12.8 KB of rows per 1 024 pairs and
+// 1.4 us of one wave's matrix pipe (more when the wave has nothing else to hide the row loads behind).  Measured on one box,
+// ms per step on video-like / smooth embeddings at cfg2 size for (REFINE_DENSE_MIN, REFINE_DENSE_LANES): (128, off) 0.798 /
+// 0.963, (64, 24) 0.799 / 0.866, (64, 16) 0.803 / 0.856, (32, 16) 0.806 / 0.858, (32, 8) 0.813 / 0.854.
 #ifndef MANET_REFINE_DENSE_MIN
-#define MANET_REFINE_DENSE_MIN 32
+#define MANET_REFINE_DENSE_MIN 64
 #endif
 constexpr int REFINE_DENSE_MIN = MANET_REFINE_DENSE_MIN;
-constexpr int REFINE_RZ = 4;  // workgroups of the re-rank launch per bucket: each takes every 4th entry (the longest bucket is the launch's time)
+#ifndef MANET_REFINE_DENSE_LANES
+#define MANET_REFINE_DENSE_LANES 16
+#endif
+constexpr int REFINE_DENSE_LANES = MANET_REFINE_DENSE_LANES;  // (64: off; smooth embeddings at cfg2 size: filter 0.66 -> 0.56 ms)
+#ifndef MANET_REFINE_RZ
+#define MANET_REFINE_RZ 4
+#endif
+constexpr int REFINE_RZ = MANET_REFINE_RZ;  // workgroups of the re-rank launch per bucket: each takes every 4th entry (the longest bucket is the launch's time)
 constexpr int RESCUE_LISTED = 1 << 30;  // block_map flag of the rescue launch: deal the workgroups to the LISTED tiles
 
 // Packed operand image of one row block: `units` 16-byte units per row, stored [unit][row][16 B].
@@ -1959,14 +1967,18 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
     // ONE dense entry (r4; REFINE_DENSE_CAP per bucket, beyond that the bucket is marked incomplete and the rescue pass --
     // the exact fp32 kernel -- takes that query tile; through r4's first captures every such block went to the rescue pass:
     // 99 % of the tiles of a spatially smooth clip).
-    auto emit = [&](const f32x16 &c, float t, int j, int row0) __attribute__((always_inline)) {
+    auto emit = [&](const f32x16 &c, float t, int j, int row0, unsigned long long hm) __attribute__((always_inline)) {
         const int before = wl_n[j];
-        emit_regs(c, t, j, row0);
-        if (wl_n[j] > WL || wl_n[j] - before > REFINE_DENSE_MIN) {  // (wave-uniform, rare)
-            const int total = wl_n[j] - before;
+        // hm = the lanes (query, half of the pass's rows) whose 16 distances hold a qualifying one: more than
+        // REFINE_DENSE_LANES of the 64 and the block goes dense without looking at single registers (video-like data:
+        // neighbouring queries find their rows in the same pass -- the listing of such blocks was the filter pass's tail)
+        const bool many = REFINE_DENSE_LANES < 64 && __popcll(hm) > REFINE_DENSE_LANES;
+        if (!many) emit_regs(c, t, j, row0);
+        if (many || wl_n[j] > WL || wl_n[j] - before > REFINE_DENSE_MIN) {  // (wave-uniform, rare)
+            const int total = many ? __popcll(hm) : wl_n[j] - before;
             wl_n[j] = before;
-            if (before >= WL || total <= REFINE_DENSE_MIN) flush_sub(j);  // (room for the dense entry / for the block's rows)
-            if (total > REFINE_DENSE_MIN) {
+            if (before >= WL || !(many || total > REFINE_DENSE_MIN)) flush_sub(j);  // (room for the dense entry / for the block's rows)
+            if (many || total > REFINE_DENSE_MIN) {
                 // a DENSE block (embeddings the bf16 pass cannot tell apart over this neighbourhood): one entry for its 1 024
                 // distances, into the sub-list that was just emptied; the bucket's dense count lives behind the fill counts
                 int b32 = qt * (QTB / QB) + wave * NQB + j, nb32 = (int)(N_pad >> 5);
@@ -2034,8 +2046,9 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         tq[jb_] = fminf(tq[jb_], pb + sq[jb_]);                                                    \
         const bool ha = pa <= tq[ja_], hb = pb <= tq[jb_];                                         \
         if (!(ABL & 16) && __ballot(ha | hb)) { /* wave-uniform */                                 \
-            if (__ballot(ha)) emit(ca_, tq[ja_], ja_, (row0_));                                    \
-            if (__ballot(hb)) emit(cb_, tq[jb_], jb_, (row0_));                                    \
+            const unsigned long long ma_ = __ballot(ha), mb_ = __ballot(hb);                       \
+            if (ma_) emit(ca_, tq[ja_], ja_, (row0_), ma_);                                        \
+            if (mb_) emit(cb_, tq[jb_], jb_, (row0_), mb_);                                        \
         }                                                                                          \
     }
 #define MANET_PASS_F(next_base_, row0_)                                                            \
@@ -2375,12 +2388,18 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restric
             rescue = rescue || (r2 >> 31) || (long)r2 > bucket_cap;
         }
     }
-    const int z = blockIdx.y;  // this workgroup's share of the bucket: entries z, z + REFINE_RZ, ...
+    // this workgroup's share of the bucket: entries z, z + zn, ... -- zn of the launch's REFINE_RZ workgroups per bucket take
+    // part: one per 512 entries, a dense entry (a 32 x 32 x C matrix tile for one wave) counted as 64 listed rows.  (All four on
+    // every bucket: 4 x the query-block loads and a quarter of the work each -- +8 us of the re-rank on video-like data, where a
+    // bucket holds ~320 rows; one: -45 us on smooth data, where the longest bucket is the launch's time.)
+    const int z = blockIdx.y;
+    int zn = (int)(((long)cnt + 64l * (long)bcnt[N_pad / QB + b] + 511) / 512);
+    zn = zn < 1 ? 1 : (zn > REFINE_RZ ? REFINE_RZ : zn);
     if (rescue && tid == 0 && z == 0 && b % (QT / QB) == 0) {  // the tile's first block lists it for the rescue launch
         unsigned *rs = bcnt + 2 * (N_pad / QB);
         rs[1 + atomicAdd(&rs[0], 1u)] = (unsigned)(b / (QT / QB));
     }
-    if (z > 0 && (rescue || cnt <= z)) return;  // (a rescued tile's candidates are moot; its image is written by z == 0)
+    if (z > 0 && (rescue || z >= zn)) return;  // (a rescued tile's candidates are moot; its image is written by z == 0)
     if (cnt == 0 && !rescue) return;
     __shared__ int dense_n;
     __shared__ int dense_at[REFINE_DENSE_CAP];
@@ -2408,7 +2427,7 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restric
         }
         return;  // (the rescue pass evaluates every pair of this tile: its candidates are moot)
     }
-    for (int i = z + REFINE_RZ * tid; i < cnt; i += REFINE_RZ * 256) {
+    for (int i = z + zn * tid; i < cnt; i += zn * 256) {
         const uint2 e = list[b * bucket_cap + i];
         if (e.y & REFINE_DENSE_BIT) {  // a dense block: the whole workgroup evaluates it below
             if (!rescue) {             // (a tile that is rescued anyway gets every distance from the fp32 kernel)

@@ -199,7 +199,8 @@ int manet_embed_finish(const float *conv_out, int64_t s_f, int64_t s_y, int64_t 
  * manet_query_pack with MANET_COMPUTE_BF16 or _BF16_REFINE): the fp32 re-rank also needs the query as stored, so this entry
  * point takes both.  query_image == NULL: same as manet_global_match_prepared_ex(..., MANET_COMPUTE_BF16_REFINE, ...).
  * manet_global_match_refine_stats reads back (blocking copy -- tests / benchmarks) what the last call on `match_ws` did:
- * qualifying bank rows seen by the filter pass, and whether some 32-query block's candidate bucket (128 rows per pair on
+ * candidate rows the filter pass listed (+, per 32 x 32 block it listed whole, the number of (query, half pass) lanes that held
+ * a qualifying row: a lower bound of that block's qualifying rows), and whether some 32-query block's candidate bucket (128 rows per pair on
  * average, 1 024 whole 32 x 32 blocks) was incomplete -- 1: the 256-query tiles of those blocks also went through the exact fp32 kernel (the bank
  * workspace of this mode carries the fp32 operand image beside the bf16 one for that), which bounds the cost of any input at
  * about the fp32 path's; 0: the usual case. */
@@ -209,7 +210,7 @@ int manet_global_match_refine(const void *query, int emb_dtype, int64_t q_stride
                               manet_stream_t stream);
 int manet_global_match_refine_stats(const void *match_ws, int64_t N, int C, int n_ids, int64_t *candidates,
                                     int64_t *list_overflowed);
-/* ... and in full (blocking copies; benchmarks): stats4[0] = qualifying rows, [1] = the flag above, [2] = 256-query tiles
+/* ... and in full (blocking copies; benchmarks): stats4[0] = candidate rows (as above), [1] = the flag above, [2] = 256-query tiles
  * that went through the rescue pass, [3] = 256-query tiles of the frame -- [2] / [3] is the share of the frame that cost the
  * fp32 kernel's time ON TOP of the filter pass (distribution-dependent: 0 on embeddings the bf16 pass can tell apart). */
 int manet_global_match_refine_stats2(const void *match_ws, int64_t N, int C, int n_ids, int64_t *stats4);

@@ -1,0 +1,18 @@
+#!/bin/bash
+# as tools/kstats.sh, on a variant library: usage: tools/kstats_variant.sh TAG variant.so <bench.py arguments...>
+TAG=$1; V=$2; shift; shift
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+export MANET_LIB_VARIANT=$REPO/$V
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python3 $REPO/tools/bench_variant.py "$@" > $OUT/log.txt 2>&1
+cd $REPO
+python3 - $OUT <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: -float(r["TotalDurationNs"]))
+for r in rows[:12]:
+    print("%-100s %5s calls  avg %8.1f us" % (r["Name"].replace("(anonymous namespace)::", "")[:100], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
+rm -f $OUT/*kernel_trace.csv
