@@ -894,6 +894,10 @@ __device__ __forceinline__ float min3p(float m, float a, float b)
 // block -> (tile, split) map (such a bank fits every XCD's L2 anyway).  The minimum is order-independent: same bits.
 // `block_map`: bits 0-7 = tuning (0: XCD-aware, 1: tile fastest, 2: split fastest, 4..7: XCD-aware with 2..5 splits
 // fastest), bits 8.. = small_S.
+#ifndef MANET_FILTER_TAIL_CUTS
+#define MANET_FILTER_TAIL_CUTS 4
+#endif
+constexpr int FILTER_TAIL_CUTS = MANET_FILTER_TAIL_CUTS;  // (1: bm == 3's map)
 __device__ __forceinline__ bool split_of_block(int b, int nQT, int S, int T, int block_map, int &qt, int &s, int &t0,
                                                int &t1)
 {
@@ -940,6 +944,34 @@ __device__ __forceinline__ bool split_of_block(int b, int nQT, int S, int T, int
     t1 = (int)((long)(s + 1) * T / S);
     return t0 < t1;
 }
+
+// bm == 3's map with a TAPERED tail (the FILTER pass only): each XCD's LAST split is cut into FILTER_TAIL_CUTS pieces.  The
+// listing behind the filter's tests is a few per cent of all wave cycles but sits in a few workgroups -- on video-like data a
+// (query tile, split) that holds the tile's image region of a bank frame lists thousands of rows and runs twice as long as its
+// neighbours (measured: listing 3.9 % of the wave cycles, up to 45 % of one wave's) -- and whatever such a workgroup adds in
+// the launch's LAST round is the launch's tail: shorter last workgroups, a shorter tail.
+__device__ __forceinline__ bool tapered_split_of_block(int b, int nQT, int S, int T, int &qt, int &s, int &t0, int &t1)
+{
+    const int xcd = b & 7, idx = b >> 3, S8 = S >> 3;
+    const int full = nQT * (S8 - 1);
+    int cut = 0, cuts = 1;
+    if (idx < full) {
+        qt = idx % nQT;
+        s = xcd * S8 + idx / nQT;
+    } else {
+        const int r = idx - full;
+        cut = r / nQT;
+        cuts = FILTER_TAIL_CUTS;
+        if (cut >= FILTER_TAIL_CUTS) return false;
+        qt = r - cut * nQT;
+        s = xcd * S8 + S8 - 1;
+    }
+    const int a = (int)((long)s * T / S), e = (int)((long)(s + 1) * T / S);
+    t0 = a + (int)((long)cut * (e - a) / cuts);
+    t1 = a + (int)((long)(cut + 1) * (e - a) / cuts);
+    return t0 < t1;
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // main kernel, fp32: one workgroup = 256 queries x one bank split
@@ -1799,7 +1831,10 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
 
     int qt, s, t0, t1;
     const int T = meta[META_T];
-    if (!split_of_block(blockIdx.x, nQT, S, T, block_map, qt, s, t0, t1)) return;
+    if (FILTER && (block_map & 0xff) == 8) {
+        if (!tapered_split_of_block(blockIdx.x, nQT, S, T, qt, s, t0, t1)) return;
+    } else if (!split_of_block(blockIdx.x, nQT, S, T, block_map, qt, s, t0, t1))
+        return;
 
     constexpr int PIECES = UNITS * TPS;  // 1 KiB pieces per step
     const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
@@ -2046,9 +2081,14 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         tq[jb_] = fminf(tq[jb_], pb + sq[jb_]);                                                    \
         const bool ha = pa <= tq[ja_], hb = pb <= tq[jb_];                                         \
         if (!(ABL & 16) && __ballot(ha | hb)) { /* wave-uniform */                                 \
+            const unsigned long long tk0_ = (ABL & 256) ? __builtin_readcyclecounter() : 0ull;     \
             const unsigned long long ma_ = __ballot(ha), mb_ = __ballot(hb);                       \
             if (ma_) emit(ca_, tq[ja_], ja_, (row0_), ma_);                                        \
             if (mb_) emit(cb_, tq[jb_], jb_, (row0_), mb_);                                        \
+            if (ABL & 256) {                                                                       \
+                dbg_cycles += __builtin_readcyclecounter() - tk0_;                                 \
+                dbg_events += 1;                                                                   \
+            }                                                                                      \
         }                                                                                          \
     }
 #define MANET_PASS_F(next_base_, row0_)                                                            \
@@ -2076,6 +2116,8 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
         MANET_TEST2(c0, c1, 0, 1, (row0_));                                                        \
         pend_row0 = (row0_);                                                                       \
     }
+    unsigned long long dbg_cycles = 0ull, dbg_events = 0ull;  // (ABL & 256: cycles this wave spent behind the tests, and how often)
+    const unsigned long long dbg_t0 = (ABL & 256) ? __builtin_readcyclecounter() : 0ull;
     unsigned xk[NQB] = {0u, 0u, 0u, 0u};  // FILTER: threshold keys asked for in the previous exchange step, of object xo
     int xo = -1;
     f32x16 pc2, pc3;  // FILTER: the pending half (nothing pending: distances no threshold admits)
@@ -2182,6 +2224,14 @@ __global__ __launch_bounds__(256, 2) void global_match_bf16_wide_kernel(const ch
 #pragma unroll
         for (int j = 0; j < NQB; ++j) flush_sub(j);
         if (lane == 0 && wl_total) atomicAdd(&stats[0], (unsigned long long)wl_total);  // (statistics only)
+        if ((ABL & 256) && lane == 0) {  // timing experiments: stats[4..7] = listing cycles, listing events, wave cycles, waves
+            atomicAdd(&stats[4], dbg_cycles);
+            atomicAdd(&stats[5], dbg_events);
+            atomicAdd(&stats[6], __builtin_readcyclecounter() - dbg_t0);
+            atomicAdd(&stats[7], 1ull);
+            atomicMax(&stats[8], dbg_cycles);
+            atomicMax(&stats[9], __builtin_readcyclecounter() - dbg_t0);
+        }
     }
 }
 
@@ -2285,6 +2335,7 @@ __global__ void refine_threshold_kernel(const unsigned *__restrict__ keys, const
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) stats[0] = stats[1] = 0ull;
+    if (i >= 4 && i < 10) stats[i] = 0ull;  // (ablation builds: cycle counters of the filter pass)
     if (i <= 2 * (N_pad / QB)) bcnt[i] = 0u;  // (entries appended, dense entries appended, number of tiles to rescue)
     if (i >= (long)n_ids * N_pad) return;
     const long n = i % N_pad;
@@ -2329,6 +2380,16 @@ __global__ void refine_force_kernel(long N_pad, int n_ids, unsigned *__restrict_
     if (i == 0) bcnt[2 * (N_pad / QB)] = 0u;  // (the re-rank launch lists the tiles to rescue: all of them)
     if (i < (long)n_ids * N_pad) keys2[i] = 0xffffffffu;
 }
+
+#ifdef MANET_ABLATION
+// timing experiments (manet_tune_set(MANET_TUNE_ABLATION, 256)): what the filter pass's waves spent behind their threshold tests
+__global__ void refine_debug_kernel(const unsigned long long *stats)
+{
+    printf("filter pass: %llu waves, %.0f cycles each (longest %llu); listing path: %llu events, %.0f cycles each, %.1f %% of the wave "
+           "cycles (most in one wave: %llu cycles)\n", stats[7], (double)stats[6] / (double)(stats[7] ? stats[7] : 1), stats[9], stats[5],
+           (double)stats[4] / (double)(stats[5] ? stats[5] : 1), 100.0 * (double)stats[4] / (double)(stats[6] ? stats[6] : 1), stats[8]);
+}
+#endif
 
 // how many 256-query tiles of the last filter pass went through the rescue pass -> out2 = {rescued, tiles} (device memory: the
 // caller copies it out asynchronously and reads it a frame later)
@@ -2913,6 +2974,7 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
             if (fabl == 64) fn = (const void *)global_match_bf16_wide_kernel<7, 64, true>;    // no returning atomic in flush_sub
             if (fabl == 128) fn = (const void *)global_match_bf16_wide_kernel<7, 128, true>;  // no listing behind the tests
             if (fabl == 192) fn = (const void *)global_match_bf16_wide_kernel<7, 192, true>;
+            if (fabl == 256) fn = (const void *)global_match_bf16_wide_kernel<7, 256, true>;  // cycle counts of the listing path -> stats[4..9]
         }
 #endif
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2921,7 +2983,14 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
         // (see split_of_block) the spread map.  (PB splits fastest on top of it, as the plain kernels have it: fabric fetch
         // of this pass 301 -> 176 MB at cfg3 shape, but concurrent splits of one object share thresholds later --
         // 4.3 -> 5.05 candidate rows per pair -- and the step got 1 % slower: not taken.)
-        if ((bm & 0xff) == 0) bm |= 3;
+        unsigned fgrid = (unsigned)(nQT * S);
+        if ((bm & 0xff) == 0) {
+            bm |= 3;
+            if (FILTER_TAIL_CUTS > 1 && (S & 7) == 0) {  // (tapered tail: see split_of_block)
+                bm = (bm & ~0xff) | 8;
+                fgrid = (unsigned)(nQT * (S + 8 * (FILTER_TAIL_CUTS - 1)));
+            }
+        }
         long N_pad = ML.N_pad, cap = ML.bucket_cap;
         unsigned *thr_c = thr;
         const float *slack_c = slack;
@@ -2929,8 +2998,11 @@ int run_refine(const char *qimg, const void *qraw, int q_dtype, long q_sn, long 
                         (void *)&N_pad, (void *)&keys, (void *)&bm, (void *)&prio, (void *)&thr_c, (void *)&slack_c, (void *)&stats,
                         (void *)&list, (void *)&cap, (void *)&bcnt};
         manet_profile_record(st, true, 0);
-        (void)hipLaunchKernel(fn, dim3((unsigned)(nQT * S)), dim3(256), args, lds, st);
+        (void)hipLaunchKernel(fn, dim3(fgrid), dim3(256), args, lds, st);
         manet_profile_record(st, false, 0);
+#ifdef MANET_ABLATION
+        if (manet_tune_get(MANET_TUNE_ABLATION, 0) == 256) hipLaunchKernelGGL(refine_debug_kernel, dim3(1), dim3(1), 0, st, stats);
+#endif
     }
     }  // (!force_exact)
     // 4. exact re-rank of the candidates
