@@ -458,7 +458,13 @@ int manet_profile_begin(int max_launches);
  *         2..5 splits fastest),
  * key 1 = forced number of bank splits (0 = automatic),
  * key 2 = form of the bf16 kernels (bit field, see launch_main_bf16 in csrc/global_match.hip),
- * key 3 = timing ablations (results are garbage), key 4 = 1: the r1 three-launch local match.
+ * key 3 = timing ablations (results are garbage; -DMANET_ABLATION builds only; for MANET_COMPUTE_BF16_REFINE's filter pass:
+ *         16 no listing path, 32 no threshold exchange, 64 no bucket reservations, 64 + 128 no per-register listing, 256 cycle
+ *         counters of the listing path printed after each filter launch),
+ * key 4 = 1: the r1 three-launch local match, key 5 = un-pipelined fp32 kernel, key 6 = frame-prepare channel block,
+ * key 7 = pre-pass sampling of MANET_COMPUTE_BF16_REFINE (every value-th bank tile), key 8 = 1: the LDS-weights fp32 1x1
+ * kernel everywhere, key 9 = bank splits per listed tile of MANET_COMPUTE_BF16_REFINE's rescue launch.
+ * Keys 2, 3, 5, 6 select kernels that only -DMANET_ABLATION builds contain and are refused otherwise.
  * No knob changes a workspace layout. */
 int manet_tune_set(int key, int value);
 int manet_profile_end(float *ms_out, int capacity, int *n_launches);
