@@ -2536,10 +2536,15 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restric
             const float *kr = rows + (slot0 + l31) * C;
             f32x16 acc = {0};
             if ((C & 3) == 0) {
-                for (int k0 = 0; k0 < C; k0 += 20) {  // five 16-byte loads in flight = ten k-steps
-                    f32x4 y[5];
+                // batches of five 16-byte loads = ten k-steps, two batches in flight: the loads of batch i + 1 are issued before
+                // the MFMAs of batch i (a lone wave has nothing else to hide a row load behind: the first form -- load, wait,
+                // ten MFMAs, five times per entry -- spent most of an entry waiting)
+                f32x4 ya[5], yb[5];
+                auto load5 = [&](f32x4 (&y)[5], int k0) __attribute__((always_inline)) {
 #pragma unroll
                     for (int j = 0; j < 5; ++j) y[j] = (k0 + 4 * j < C) ? *(const f32x4 *)(kr + k0 + 4 * j) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                };
+                auto mfma5 = [&](const f32x4 (&y)[5], int k0) __attribute__((always_inline)) {
 #pragma unroll
                     for (int j = 0; j < 5; ++j) {
                         if (k0 + 4 * j < C) {  // (wave-uniform)
@@ -2548,6 +2553,13 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const SRC *__restric
                             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? y[j][3] : y[j][2], x[(k + 2) * QB], acc, 0, 0, 0);
                         }
                     }
+                };
+                load5(ya, 0);
+                for (int k0 = 0; k0 < C; k0 += 40) {
+                    if (k0 + 20 < C) load5(yb, k0 + 20);
+                    mfma5(ya, k0);
+                    if (k0 + 40 < C) load5(ya, k0 + 40);
+                    if (k0 + 20 < C) mfma5(yb, k0 + 20);
                 }
             } else {
                 for (int k0 = 0; k0 < C; k0 += 2) {
