@@ -673,8 +673,9 @@ def e2e_block(device, args):
 
 def e2e_parallel_main(args, device, rank, world, backend):
     """`bench.py --e2e [--gpus N]`: the clip-parallel real propagation as a bench line: a fixed
-    `--e2e-frames` clip (strong scaling), N ranks compute the global maps of their frame blocks, ONE gather per round to the
-    chain rank, which runs local match + head + mask sequentially (examples/propagate_clip.py)."""
+    `--e2e-frames` clip (strong scaling), N ranks compute the global maps of their frame blocks, ONE collective per round to the
+    chain ranks (0: forwards from the annotated frame, 1: backwards), which run local match + head + mask frame by frame
+    (examples/propagate_clip.py)."""
     from examples import propagate_clip as pc
     eargs = pc.parse_args(["--frames", str(args.e2e_frames), "--fused-mask-step", "--gpus", str(world)])
     if world > 1:
@@ -691,7 +692,8 @@ def e2e_parallel_main(args, device, rank, world, backend):
             "warmup": res["frames"] - 1, "ms_per_step": res["parallel_ms_per_round"] / (res["frames"] - 1),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "examples/propagate_clip.py: %d-frame 480p clip, 2 objects, 1-frame scribble bank, exact fp32 "
-                                   "head; ranks compute the global maps of their frame blocks, rank 0 runs the sequential chain"
+                                   "head; ranks compute the global maps of their frame blocks, rank 0 runs the forward half of the sequential "
+                                   "chain, rank 1 the backward half"
                                    % res["frames"], "clip_frames": res["frames"]},
             "collective": res.get("collective"), "e2e_parallel": res}
 

@@ -218,7 +218,8 @@ def all_gather_clip(local_embeddings, num_frames, group=None):
 
 
 def gather_frame_rows(local_rows, num_frames, dst=0, group=None, timing=False):
-    """ONE gather to rank `dst` of per-frame float32 rows: `local_rows` [f_local, L] belong to this rank's contiguous
+    """ONE gather to rank `dst` (dst=None: an all-gather, every rank gets them) of per-frame float32 rows: `local_rows`
+    [f_local, L] belong to this rank's contiguous
     frame block (shard_frames); returns [num_frames, L] on `dst` (frames in clip order), None elsewhere.  The
     clip-parallel propagation ships the normalised + merged global maps of a round this way ([h*w*n_ids] = 205 KB per
     480p frame and 2 ids: 13 MB for a 64-frame clip -- 0.09 ms on one xGMI link)."""
@@ -237,10 +238,14 @@ def gather_frame_rows(local_rows, num_frames, dst=0, group=None, timing=False):
         torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     send = slab.cpu() if staged else slab
-    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, bufs, dst=dst, group=group)
+    if dst is None:  # every rank gets the rows (two chain ranks: propagate_clip.py's forward / backward directions)
+        bufs = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(bufs, send, group=group)
+    else:
+        bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        dist.gather(send, bufs, dst=dst, group=group)
     out = None
-    if rank == dst:
+    if dst is None or rank == dst:
         parts = []
         for r in range(world):
             a, b = shard_frames(num_frames, world, r)
@@ -253,3 +258,17 @@ def gather_frame_rows(local_rows, num_frames, dst=0, group=None, timing=False):
     LAST_GATHER.update({"backend": dist.get_backend(group), "world": world, "dst": dst, "slab_bytes": int(per * L * 4),
                         "gathered_bytes": int(world * per * L * 4), "gather_ms": (time.perf_counter() - t0) * 1e3 if timing else None})
     return out
+
+
+def send_tensor(t, dst, group=None):
+    """point-to-point send of a device tensor (gloo: staged through the host); pairs with recv_tensor"""
+    staged = dist.get_backend(group) == "gloo" and t.is_cuda
+    dist.send(t.contiguous().cpu() if staged else t.contiguous(), dst=dst, group=group)
+
+
+def recv_tensor(shape, dtype, device, src, group=None):
+    """-> the tensor send_tensor(...) shipped from rank `src`"""
+    staged = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
+    buf = torch.empty(shape, dtype=dtype, device="cpu" if staged else device)
+    dist.recv(buf, src=src, group=group)
+    return buf.to(device) if staged else buf

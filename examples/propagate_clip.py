@@ -21,9 +21,12 @@ label-INDEPENDENT half of a propagated frame -- the global match against the ann
 frame at a 5-frame fp32 bank) -- while local match -> head -> argmax -> next frame's previous mask is a sequential
 chain.  So every rank extracts the embeddings of its contiguous frame block (ONE all-gather assembles the clip, once
 per clip), computes the normalised + merged global maps of its block (`IntVOS.global_maps`), ONE gather per round
-ships them ([h*w*n_ids] floats per frame) to the chain rank, and rank 0 runs the chain with
-`prop_seghead(..., global_map_precomputed=...)`.  Rank 0 also runs the plain 1-rank loop on the same embeddings and
-asserts the masks are bit-equal.
+ships them ([h*w*n_ids] floats per frame) to the chain rank(s), which run the chain with
+`prop_seghead(..., global_map_precomputed=...)`.  The chain itself has TWO independent halves -- forwards and backwards
+from the annotated frame (test.py:237-259 and :276-295) -- so with two or more ranks rank 0 runs the forward half and
+rank 1 the backward half at the same time (each also runs the annotated frame's interaction head), and rank 1 ships
+its masks to rank 0: up to 2x on the sequential part, whatever the number of ranks.  Rank 0 also runs the plain 1-rank
+loop on the same embeddings and asserts the masks are bit-equal.
 """
 import argparse
 import hashlib
@@ -191,9 +194,11 @@ class Clip:
     def propagation_order(self):
         return (range(self.start + 1, self.F), range(self.start - 1, -1, -1))
 
-    def one_round(self, precomputed=None, keep_logits=None):
+    def one_round(self, precomputed=None, keep_logits=None, directions=(0, 1), as_dict=False):
         """test.py:208-295 for one interaction: int_seghead on the annotated frame, then the chain.  precomputed: dict
-        frame -> merged global map (IntVOS.global_maps) -- the clip-parallel form"""
+        frame -> merged global map (IntVOS.global_maps) -- the clip-parallel form.  directions: which of the two
+        independent chains to run (0 = forwards from the annotated frame, test.py:237-259; 1 = backwards, :276-295);
+        as_dict: return {frame: mask} of the frames this call produced instead of the whole clip's masks"""
         model, cfg, start = self.model, self.cfg, self.start
         gmap, lmaps = {}, ({}, {})
         ref = self.emb[start:start + 1]
@@ -203,7 +208,9 @@ class Clip:
         ref_label = self.mask_step(tmp[SEQ]).unsqueeze(0)
         masks = {start: ref_label}
         pre = None if precomputed is None else {SEQ: precomputed}
-        for order in self.propagation_order():
+        for di, order in enumerate(self.propagation_order()):
+            if di not in directions:
+                continue
             prev_label, prev_emb = ref_label, ref
             for ii in order:
                 cur = self.emb[ii:ii + 1]
@@ -220,6 +227,8 @@ class Clip:
                 prev_label = self.mask_step(tmp[SEQ]).unsqueeze(0)
                 prev_emb = cur
                 masks[ii] = prev_label
+        if as_dict:
+            return masks
         return torch.cat([masks[i][0] for i in range(self.F)], 0)
 
     def timed_round(self, precomputed_fn=None, rounds=1):
@@ -344,8 +353,12 @@ def run_parallel(args, dev, rank, world):
         L = clip.eh * clip.ew * (args.objects + 1)
         timing = {}
 
+        # the two directions of the propagation (forwards / backwards from the annotated frame) are independent chains:
+        # rank 0 runs the forward one, rank 1 -- when there is one -- the backward one, then ships its masks to rank 0
+        chain_ranks = (0, 1) if world > 1 and start > 0 else (0,)
+
         def maps_for_round():
-            """this rank's block -> normalised + merged global maps; ONE gather ships every rank's to rank 0"""
+            """this rank's block -> normalised + merged global maps; ONE collective ships every rank's to the chain rank(s)"""
             t1 = time.perf_counter()
             if my_frames:
                 rows = model.global_maps(ref, clip.scribble, emb[s0:e0], my_frames, SEQ, clip.gt)
@@ -353,15 +366,26 @@ def run_parallel(args, dev, rank, world):
                 rows = torch.empty((0, L), dtype=torch.float32, device=dev)
             torch.cuda.synchronize()
             timing["global_maps_ms"] = (time.perf_counter() - t1) * 1e3
-            allrows = cp.gather_frame_rows(rows, F_, dst=0, timing=True)
+            allrows = cp.gather_frame_rows(rows, F_, dst=0 if len(chain_ranks) == 1 else None, timing=True)
             timing["gather"] = dict(cp.LAST_GATHER)
-            if rank != 0:
+            if rank not in chain_ranks:
                 return None
             return {f: allrows[f] for f in range(F_) if f != start}
 
         def one_parallel_round():
             pre = maps_for_round()
-            return clip.one_round(pre) if rank == 0 else None
+            if rank not in chain_ranks:
+                return None
+            if len(chain_ranks) == 1:
+                return clip.one_round(pre)
+            mine_ = clip.one_round(pre, directions=(rank,), as_dict=True)
+            if rank == 1:  # the backward chain's masks (frames start - 1 .. 0) -> rank 0, as int16
+                back = torch.cat([mine_[i][0] for i in range(start)], 0)
+                cp.send_tensor(back.to(torch.int16), dst=0)
+                return None
+            back = cp.recv_tensor((start, args.height, args.width), torch.int16, dev, src=1)
+            fwd = torch.cat([mine_[i][0] for i in range(start, F_)], 0)
+            return torch.cat([back.to(fwd.dtype), fwd], 0)
 
         one_parallel_round()  # warm-up
         torch.cuda.synchronize()
@@ -380,6 +404,7 @@ def run_parallel(args, dev, rank, world):
                 "compute": model.compute, "parallel_ms_per_round": dt * 1e3, "parallel_frames_per_s": (F_ - 1) / dt,
                 "single_rank_ms_per_round": dt1 * 1e3, "single_rank_frames_per_s": (F_ - 1) / dt1,
                 "masks_bit_equal_to_single_rank": same, "mask_digest": mask_digest(final),
+                "chain_ranks": list(chain_ranks),
                 "clip_all_gather_ms": clip_gather_ms, "rank0_global_maps_ms": timing.get("global_maps_ms"),
                 "collective": timing.get("gather")}
 

@@ -84,8 +84,9 @@ def _run_json(cmd, env, timeout=900):
 def test_clip_parallel_propagation_masks_bit_equal_to_one_rank(world, frames):
     """the multi-GPU split that speeds up what test.py does.  N ranks (sharing the one GPU here, gloo)
     extract the embeddings of their frame blocks (one all-gather assembles the clip), compute the normalised + merged global
-    maps of their blocks, ONE gather ships them to rank 0, rank 0 runs local match -> head -> mask sequentially; rank 0 also
-    runs the plain 1-rank loop on the same embeddings: the masks must be the same bits."""
+    maps of their blocks, ONE collective ships them to the chain ranks: rank 0 runs the forward half of the propagation
+    (local match -> head -> mask, frame by frame), rank 1 the backward half at the same time and ships its masks to rank 0;
+    rank 0 also runs the plain 1-rank loop on the same embeddings: the masks must be the same bits."""
     env = dict(os.environ, MANET_BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
@@ -95,7 +96,8 @@ def test_clip_parallel_propagation_masks_bit_equal_to_one_rank(world, frames):
     assert res["masks_bit_equal_to_single_rank"] is True
     col = res["collective"]
     L = 120 * 214 * 3
-    assert col["world"] == world and col["dst"] == 0 and col["slab_bytes"] == -(-frames // world) * L * 4
+    assert res["chain_ranks"] == [0, 1]
+    assert col["world"] == world and col["dst"] is None and col["slab_bytes"] == -(-frames // world) * L * 4
     assert res["parallel_frames_per_s"] > 0 and res["single_rank_frames_per_s"] > 0
 
 

@@ -144,6 +144,16 @@ def _worker_gather(rank, world, port, F, bf16, q):
             ok = False
         except ValueError:
             pass
+        # dst=None: every rank gets the rows (two chain ranks: the forward / backward halves of the propagation)
+        every = cp.gather_frame_rows(rows[s:e].clone(), F, dst=None)
+        ok = ok and every is not None and torch.equal(every, rows) and cp.LAST_GATHER["dst"] is None
+        # ... and the backward chain's masks go from rank 1 to rank 0 point to point
+        if world > 1:
+            m = (torch.arange(3 * 4 * 5).view(3, 4, 5) % 7).to(torch.int16)
+            if rank == 1:
+                cp.send_tensor(m, dst=0)
+            elif rank == 0:
+                ok = ok and torch.equal(cp.recv_tensor((3, 4, 5), torch.int16, "cpu", src=1), m)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
