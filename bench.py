@@ -642,7 +642,7 @@ def e2e_block(device, args):
     region (test.py:143-154 extracts a clip's embeddings up front).  Headline = the exact-fp32 head (`pointwise: f32`, the
     module's default); the split-bf16 1x1 kernel beside it with its max |logit| deviation from the fp32 head."""
     from examples import propagate_clip as pc
-    eargs = pc.parse_args(["--frames", str(args.e2e_frames), "--fused-mask-step"])
+    eargs = pc.parse_args(["--frames", str(args.e2e_frames), "--fused-mask-step", "--two-streams"])
     out = {"workload": "examples/propagate_clip.py: %d-frame synthetic clip at 480x854 (grid 120x214), 2 objects (3 ids), "
                        "1-frame scribble bank, fp32 match, d=12, int_seghead on the annotated frame + prop_seghead + "
                        "upsample/argmax per frame; encoder outside the timed region" % args.e2e_frames,
@@ -659,6 +659,10 @@ def e2e_block(device, args):
         torch.cuda.empty_cache()
     out["value"] = out["modes"]["f32"]["eager_frames_per_s"]
     out["value_graph"] = out["modes"]["f32"]["graph_frames_per_s"]
+    # the round's two independent halves (forwards / backwards from the annotated frame) on two HIP streams of the one GPU
+    out["value_two_streams"] = out["modes"]["f32"]["two_streams_frames_per_s"]
+    out["two_streams_masks_equal_eager"] = bool(out["modes"]["f32"]["two_streams_masks_equal_eager"]
+                                                and out["modes"]["split"]["two_streams_masks_equal_eager"])
     # split vs f32 head on the first propagated frame (same inputs: later frames see different previous masks)
     first = min(k for k in logits["f32"] if k > args.e2e_frames // 2)
     out["split_vs_f32_head_max_abs_logit_diff"] = float((logits["split"][first] - logits["f32"][first]).abs().max().item())

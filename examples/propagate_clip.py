@@ -231,6 +231,54 @@ class Clip:
             return masks
         return torch.cat([masks[i][0] for i in range(self.F)], 0)
 
+    def one_round_two_streams(self):
+        """The same round with the two independent halves of the chain -- forwards and backwards from the annotated frame -- on
+        TWO HIP streams of this one GPU, issued alternately frame by frame: a propagated frame is ~20 launches of which a
+        dozen are small (a few microseconds on a few CUs) -- while one direction runs those, the other direction's wide
+        kernels have the chip.  Same kernels, same order inside a direction, disjoint frames of the memories: same masks."""
+        model, cfg, start = self.model, self.cfg, self.start
+        gmap, lmaps = {}, ({}, {})
+        ref = self.emb[start:start + 1]
+        tmp, lmaps = model.int_seghead(ref_frame_embedding=ref, ref_scribble_label=self.scribble, prev_round_label=None,
+                                       global_map_tmp_dic=gmap, local_map_dics=lmaps, interaction_num=1,
+                                       seq_names=[SEQ], gt_ids=self.gt, frame_num=[start], first_inter=True)
+        ref_label = self.mask_step(tmp[SEQ]).unsqueeze(0)
+        masks = {start: ref_label}
+        n_ids = self.nobj + 1
+        # the memories both directions write into (disjoint frames) exist before the streams fork
+        if SEQ not in gmap:
+            gmap[SEQ] = torch.ones((104, self.eh, self.ew, n_ids, 1), dtype=torch.float32, device=self.dev)
+        if SEQ not in lmaps[0]:
+            lmaps[0][SEQ] = torch.zeros((104, 9, self.eh, self.ew, n_ids, 1), dtype=torch.float32, device=self.dev)
+        if SEQ not in lmaps[1]:
+            lmaps[1][SEQ] = torch.zeros(104, 9, device=self.dev)
+        if not hasattr(self, "_streams"):
+            self._streams = (torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev))
+        main = torch.cuda.current_stream(self.dev)
+        orders = [list(o) for o in self.propagation_order()]
+        state = [[ref_label, ref], [ref_label, ref]]
+        for st_ in self._streams:
+            st_.wait_stream(main)
+        for i in range(max(len(o) for o in orders)):
+            for di in (0, 1):
+                if i >= len(orders[di]):
+                    continue
+                ii = orders[di][i]
+                with torch.cuda.stream(self._streams[di]):
+                    cur = self.emb[ii:ii + 1]
+                    tmp, _, _ = model.prop_seghead(ref, state[di][1], cur, self.scribble, state[di][0],
+                                                   normalize_nearest_neighbor_distances=True, use_local_map=True,
+                                                   seq_names=[SEQ], gt_ids=self.gt, k_nearest_neighbors=cfg.KNNS,
+                                                   global_map_tmp_dic=gmap, local_map_dics=lmaps, interaction_num=1,
+                                                   start_annotated_frame=start, frame_num=[ii],
+                                                   dynamic_seghead=model.dynamic_seghead)
+                    state[di][0] = self.mask_step(tmp[SEQ]).unsqueeze(0)
+                    state[di][1] = cur
+                    masks[ii] = state[di][0]
+        for st_ in self._streams:
+            main.wait_stream(st_)
+        return torch.cat([masks[i][0] for i in range(self.F)], 0)
+
     def timed_round(self, precomputed_fn=None, rounds=1):
         """warm-up round + `rounds` timed ones -> (masks, seconds per round)"""
         self.one_round(precomputed_fn() if precomputed_fn else None)  # warm-up (MIOpen find, workspace growth)
@@ -316,6 +364,16 @@ def run_single(args, dev, pointwise=None, want_graph=False, want_stages=False):
             with StageTimer() as st:
                 clip.one_round()
             res["per_frame_stages_us"] = st.per_frame_us(args.frames - 1)
+        if getattr(args, "two_streams", False):
+            clip.one_round_two_streams()  # warm-up: per-stream workspaces
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.rounds):
+                tfinal = clip.one_round_two_streams()
+            torch.cuda.synchronize()
+            tdt = (time.perf_counter() - t0) / args.rounds
+            res.update({"two_streams_ms_per_round": tdt * 1e3, "two_streams_frames_per_s": (args.frames - 1) / tdt,
+                        "two_streams_masks_equal_eager": bool(torch.equal(tfinal, final))})
         if want_graph:
             ground = clip.graph_round_fn()
             ground()
@@ -443,6 +501,8 @@ def parse_args(argv=None):
                     help="extract the embeddings through the stock module chain (bn2, relu2, cast as separate passes; frames "
                          "prepared on first use) instead of the fused embedding epilogue (extract_feature(packed=True))")
     ap.add_argument("--rounds", type=int, default=1, help="timed interaction rounds (after one warm-up round)")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="also time the round with the forward and the backward half of the chain on two HIP streams")
     ap.add_argument("--stages", action="store_true", help="per-stage microseconds of a propagated frame (HIP events)")
     ap.add_argument("--gpus", type=int, default=1, help="clip-parallel propagation over N ranks (module docstring)")
     ap.add_argument("--json", action="store_true", help="print the result as one JSON line")
@@ -496,8 +556,15 @@ def main():
                   "eager loop's; host work per frame: 1 graph launch + 5 small copies instead of one launch per kernel"
                   % (res["graph_ms_per_round"], res["graph_frames_per_s"], res["eager_frames_per_s"],
                      "identical to" if res["graph_masks_equal_eager"] else "DIFFER from"))
+        if args.two_streams:
+            print("forward and backward halves of the chain on two HIP streams: %.1f ms per round, %.1f frames/s (one stream %.1f); "
+                  "masks %s the one-stream loop's" % (res["two_streams_ms_per_round"], res["two_streams_frames_per_s"],
+                                                      res["eager_frames_per_s"],
+                                                      "identical to" if res["two_streams_masks_equal_eager"] else "DIFFER from"))
     if args.graph:
         assert res["graph_masks_equal_eager"], "graph replay changed the masks"
+    if args.two_streams:
+        assert res["two_streams_masks_equal_eager"], "the two-stream round changed the masks"
 
 
 if __name__ == "__main__":

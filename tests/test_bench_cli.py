@@ -102,6 +102,19 @@ def test_clip_parallel_propagation_masks_bit_equal_to_one_rank(world, frames):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("frames", [9, 4])
+def test_two_stream_round_masks_equal_the_one_stream_loop(frames):
+    """examples/propagate_clip.py --two-streams: the forward and the backward half of the chain issued alternately on two HIP
+    streams of the one GPU (per-stream workspaces, disjoint frames of the shared memories): the same masks"""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    res = _run_json([sys.executable, os.path.join(ROOT, "examples", "propagate_clip.py"), "--frames", str(frames),
+                     "--fused-mask-step", "--two-streams", "--rounds", "2", "--json"], env)
+    assert res["two_streams_masks_equal_eager"] is True and res["two_streams_frames_per_s"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_e2e_line_two_ranks_on_one_gpu():
     """`bench.py --e2e --gpus 2`: the clip-parallel propagation as a bench line (strong scaling over a fixed clip), with the
     `collective` echo of the round's gather"""
