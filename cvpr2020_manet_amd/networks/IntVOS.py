@@ -633,6 +633,23 @@ class IntVOS(nn.Module):
             x = self.prepare_clip(x, batch=max(1, x.shape[0]))
         return x
 
+    def prepare_bank(self, ref_frame_embedding, ref_scribble_label, seq_name, gt_id):
+        """Sort / pack the annotated frame's memory bank NOW, on the current stream (this implementation only): what the first
+        `prop_seghead` of an interaction round does on its way (`_prepared_bank`; the following frames then find it cached).
+        A driver that issues the round's two directions on two HIP streams calls this before the streams fork -- otherwise
+        the bank is built on one stream while the other may already match against it.  `ref_frame_embedding` [1, C, h, w],
+        `ref_scribble_label` [1, 1, h', w'] as passed to `prop_seghead`.  Returns the ops.PreparedBank."""
+        _, _, h, w = ref_frame_embedding.shape
+        if not ref_frame_embedding.is_cuda:
+            raise RuntimeError("prepare_bank: embeddings must be on a HIP device (no CPU fallback)")
+        if self.cfg.TEST_MODE:  # as prop_seghead (IntVOS.py:591-595)
+            lab = ref_scribble_label.float()
+        else:
+            lab = F.interpolate(ref_scribble_label.float(), size=(h, w), mode="nearest")
+        ref_lab = lab.int()[0].permute(1, 2, 0).reshape(-1)
+        return self._prepared_bank(seq_name, ref_frame_embedding[0], ref_scribble_label[0],
+                                   ref_frame_embedding[0].permute(1, 2, 0), ref_lab, _n_ids_from(gt_id, None))
+
     def global_maps(self, ref_frame_embedding, ref_scribble_label, embeddings, frame_nums, seq_name, gt_id,
                     stored_maps=None):
         """The label-INDEPENDENT half of `prop_seghead` for a block of frames (this implementation only): the global
@@ -647,13 +664,7 @@ class IntVOS(nn.Module):
         n_ids = _n_ids_from(gt_id, None)
         if not embeddings.is_cuda:
             raise RuntimeError("global_maps: embeddings must be on a HIP device (no CPU fallback)")
-        if self.cfg.TEST_MODE:  # as prop_seghead (IntVOS.py:591-595)
-            lab = ref_scribble_label.float()
-        else:
-            lab = F.interpolate(ref_scribble_label.float(), size=(h, w), mode="nearest")
-        ref_lab = lab.int()[0].permute(1, 2, 0).reshape(-1)
-        bank = self._prepared_bank(seq_name, ref_frame_embedding[0], ref_scribble_label[0],
-                                   ref_frame_embedding[0].permute(1, 2, 0), ref_lab, n_ids)
+        bank = self.prepare_bank(ref_frame_embedding, ref_scribble_label, seq_name, gt_id)
         out = torch.empty((f, h * w * n_ids), dtype=torch.float32, device=embeddings.device)
         if stored_maps is None:
             mem = torch.ones_like(out)

@@ -252,6 +252,8 @@ class Clip:
             lmaps[0][SEQ] = torch.zeros((104, 9, self.eh, self.ew, n_ids, 1), dtype=torch.float32, device=self.dev)
         if SEQ not in lmaps[1]:
             lmaps[1][SEQ] = torch.zeros(104, 9, device=self.dev)
+        # ... and so does the annotated frame's memory bank (the first propagated frame would otherwise build it on ITS stream)
+        model.prepare_bank(ref, self.scribble, SEQ, self.gt)
         if not hasattr(self, "_streams"):
             self._streams = (torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev))
         main = torch.cuda.current_stream(self.dev)

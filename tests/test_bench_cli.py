@@ -115,6 +115,26 @@ def test_two_stream_round_masks_equal_the_one_stream_loop(frames):
 
 
 @pytest.mark.gpu
+def test_two_stream_round_on_a_cold_model():
+    """the two-stream round FIRST (nothing cached: the bank is built by IntVOS.prepare_bank before the streams fork, the
+    memories exist before the fork), then the plain loop: the same masks; prepare_bank returns what prop_seghead then finds"""
+    import torch
+    from examples import propagate_clip as pc
+    dev = torch.device("cuda", 0)
+    args = pc.parse_args(["--frames", "7", "--fused-mask-step", "--height", "240", "--width", "428"])
+    cfg, model = pc.build_model(dev, None, None, None)
+    with torch.no_grad():
+        emb = pc.synthetic_clip(model, dev, args.frames, args.height, args.width, args.objects, packed=True)
+        clip = pc.Clip(cfg, model, emb, args.height, args.width, args.objects, fused_mask_step=True)
+        two = clip.one_round_two_streams()
+        torch.cuda.synchronize()
+        bank = model.prepare_bank(emb[clip.start:clip.start + 1], clip.scribble, pc.SEQ, clip.gt)
+        assert bank is model.prepare_bank(emb[clip.start:clip.start + 1], clip.scribble, pc.SEQ, clip.gt)  # cached
+        one = clip.one_round()
+        assert torch.equal(two, one)
+
+
+@pytest.mark.gpu
 def test_bench_e2e_line_two_ranks_on_one_gpu():
     """`bench.py --e2e --gpus 2`: the clip-parallel propagation as a bench line (strong scaling over a fixed clip), with the
     `collective` echo of the round's gather"""
