@@ -647,8 +647,10 @@ class IntVOS(nn.Module):
         else:
             lab = F.interpolate(ref_scribble_label.float(), size=(h, w), mode="nearest")
         ref_lab = lab.int()[0].permute(1, 2, 0).reshape(-1)
+        n_ids = _n_ids_from(gt_id, None)
+        _obj_ids(n_ids, ref_frame_embedding.device)  # (the cached id vector, too, exists before any fork)
         return self._prepared_bank(seq_name, ref_frame_embedding[0], ref_scribble_label[0],
-                                   ref_frame_embedding[0].permute(1, 2, 0), ref_lab, _n_ids_from(gt_id, None))
+                                   ref_frame_embedding[0].permute(1, 2, 0), ref_lab, n_ids)
 
     def global_maps(self, ref_frame_embedding, ref_scribble_label, embeddings, frame_nums, seq_name, gt_id,
                     stored_maps=None):
