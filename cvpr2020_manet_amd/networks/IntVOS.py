@@ -637,7 +637,8 @@ class IntVOS(nn.Module):
         """Sort / pack the annotated frame's memory bank NOW, on the current stream (this implementation only): what the first
         `prop_seghead` of an interaction round does on its way (`_prepared_bank`; the following frames then find it cached).
         A driver that issues the round's two directions on two HIP streams calls this before the streams fork -- otherwise
-        the bank is built on one stream while the other may already match against it.  `ref_frame_embedding` [1, C, h, w],
+        the bank is built on one stream while the other may already match against it (the same goes for the heads' folded
+        BatchNorm constants and the cached id vector: all made here).  `ref_frame_embedding` [1, C, h, w],
         `ref_scribble_label` [1, 1, h', w'] as passed to `prop_seghead`.  Returns the ops.PreparedBank."""
         _, _, h, w = ref_frame_embedding.shape
         if not ref_frame_embedding.is_cuda:
@@ -648,7 +649,13 @@ class IntVOS(nn.Module):
             lab = F.interpolate(ref_scribble_label.float(), size=(h, w), mode="nearest")
         ref_lab = lab.int()[0].permute(1, 2, 0).reshape(-1)
         n_ids = _n_ids_from(gt_id, None)
-        _obj_ids(n_ids, ref_frame_embedding.device)  # (the cached id vector, too, exists before any fork)
+        _obj_ids(n_ids, ref_frame_embedding.device)  # (the cached id vector, too, exists before any fork ...
+        if not self.training and not torch.is_grad_enabled():  # ... and so do the heads' folded BatchNorm constants)
+            for head in (self.dynamic_seghead, self.inter_seghead):
+                if isinstance(head, DynamicSegHead):
+                    head.layer1._folded(ref_frame_embedding.shape[1])
+                    for layer in (head.layer2, head.layer3, head.layer4):
+                        layer._folded()
         return self._prepared_bank(seq_name, ref_frame_embedding[0], ref_scribble_label[0],
                                    ref_frame_embedding[0].permute(1, 2, 0), ref_lab, n_ids)
 
