@@ -46,6 +46,10 @@ if ROOT not in sys.path:
 # dmabuf IPC only on these hosts: RCCL's device-buffer exchange between the ranks of a node fails without it
 # (hipIpcGetMemHandle: invalid argument).  Set before the HIP runtime loads, also when a launcher started this rank.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# HIP streams share 4 hardware queues by default, dealt round-robin: two streams of a process may land on ONE queue and then
+# run in order -- the two-stream round of the `e2e` block (examples/propagate_clip.py) gained its 21 % for the 1st and 3rd pair
+# of streams a process created and nothing for the 2nd; with 8 queues every pair runs side by side.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -42,6 +42,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL between the ranks of a node)
+# HIP streams share 4 hardware queues by default (round-robin): two streams may land on one queue and then run in order; with 8,
+# every pair of streams this script creates runs side by side (--two-streams: +21 % or nothing, depending on the pair, with 4)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
