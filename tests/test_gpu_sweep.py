@@ -1,17 +1,21 @@
 """Seeded random sweeps over shapes and label distributions (ragged sizes, empty objects, sparse scribbles,
 row-major and C-major sources) -- the HIP path against the oracle.  Global fp32: bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+# MANET_SWEEP_SCALE=20 runs 20x the seeds (a soak; the default keeps the suite short)
+SCALE = int(os.environ.get("MANET_SWEEP_SCALE", "1"))
 
 
 def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * SCALE))
 def test_global_random_shapes_bit_exact(oracle, seed):
     from cvpr2020_manet_amd import ops
     rng = np.random.default_rng(1000 + seed)
@@ -40,10 +44,13 @@ def test_global_random_shapes_bit_exact(oracle, seed):
     scale = 1.0 + np.abs(want[want < 1e19]).max() if (want < 1e19).any() else 1.0
     ok = want < 1e19
     assert np.array_equal(x3 >= 1e19, ~ok)
-    np.testing.assert_allclose(x3[ok], want[ok], rtol=1e-4, atol=2e-5 * scale)
+    # (split-bf16: <= 2^-16 relative per PRODUCT, i.e. an absolute bound that scales with |q||k| -- not with the distance, which
+    # may be tiny beside the norms: seed 153 of a 25x soak, C = 1)
+    qk = float(np.sqrt((q.astype(np.float64) ** 2).sum(0).max() * (k.astype(np.float64) ** 2).sum(0).max()))
+    np.testing.assert_allclose(x3[ok], want[ok], rtol=1e-4, atol=2e-5 * scale + 5e-5 * qk)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 * SCALE))
 def test_local_random_shapes(oracle, seed):
     from cvpr2020_manet_amd import ops
     rng = np.random.default_rng(2000 + seed)
@@ -64,7 +71,7 @@ def test_local_random_shapes(oracle, seed):
     np.testing.assert_allclose(got[fin], want[fin], rtol=1e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(4 * SCALE))
 def test_topk_random(oracle, seed):
     from cvpr2020_manet_amd import ops
     rng = np.random.default_rng(3000 + seed)
