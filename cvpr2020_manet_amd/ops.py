@@ -219,9 +219,11 @@ class PreparedBank:
         _lib.check(rc, "manet_bank_prepare_ex")
 
     # compute="bf16r", adaptive policy: a frame whose filter pass sent more than this share of its query tiles to the rescue
-    # pass (the exact fp32 kernel) cost the filter AND the fp32 kernel; the next ADAPT_FRAMES frames then skip the filter
-    # (MANET_EPI_REFINE_EXACT: the same bits at the fp32 path's cost), after which one frame probes the filter again.
-    ADAPT_SHARE, ADAPT_FRAMES, ADAPT_PROBE_EVERY = 0.5, 16, 4
+    # pass (the exact fp32 kernel) cost the filter AND most of the fp32 kernel; the next ADAPT_FRAMES frames then skip the
+    # filter (MANET_EPI_REFINE_EXACT: the same bits at the fp32 path's cost), after which one frame probes the filter again.
+    # (The rescue launch is dealt to the rescued tiles only: a share r costs ~r of the fp32 kernel, so filtering pays below
+    # r ~ 1 - filter / fp32 kernel ~ 0.85 at cfg2 shape; r3's all-or-nothing rescue had the switch at one half.)
+    ADAPT_SHARE, ADAPT_FRAMES, ADAPT_PROBE_EVERY = 0.8, 16, 4
 
     def match(self, query_embeddings, k_nearest_neighbors=1, normalize=False, mem=None, out=None, adaptive=True):
         """query_embeddings: [..., C] float32 / bfloat16 tensor, or a PackedQuery (operand image made once,

@@ -90,7 +90,7 @@ def test_plain_bf16_error_on_video_like_embeddings():
 
 @pytest.mark.gpu
 def test_bf16r_adaptive_policy_skips_the_filter_on_indistinguishable_embeddings():
-    """ops.PreparedBank.match(adaptive=True): once a frame's rescue share arrives above one half, the next frames skip the bf16
+    """ops.PreparedBank.match(adaptive=True): once a frame's rescue share arrives above ADAPT_SHARE (0.8), the next frames skip the bf16
     filter (MANET_EPI_REFINE_EXACT: the exact fp32 kernel on every tile) -- the worst case costs the fp32 path, not the filter
     on top of it -- and the result stays the fp32 kernel's bits in both modes.  On distinguishable embeddings nothing is skipped."""
     from cvpr2020_manet_amd import ops
