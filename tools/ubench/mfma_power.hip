@@ -9,7 +9,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int PASSES = 3000;
 
-template <int NB, bool ACC_AGPR>
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// K8LAST (r4): the pass's 7th k-step as v_mfma_f32_32x32x8bf16_1k on half the operand -- 104 k-slots instead of 112.  The K8
+// instruction takes the K16 one's time at a fixed clock (mfma_x8.hip); does it take less POWER, i.e. does a power-limited chip
+// clock higher with it?
+template <int NB, bool ACC_AGPR, bool K8LAST = false>
 __global__ __launch_bounds__(512) void k(float *out, const unsigned *data, long long *ticks)
 {
     __shared__ __attribute__((aligned(16))) unsigned lds[12288];  // 48 KiB of fragments
@@ -31,7 +35,10 @@ __global__ __launch_bounds__(512) void k(float *out, const unsigned *data, long 
         for (int kk = 0; kk < 7; ++kk) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                if (ACC_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c[j]) : "v"(a[kk]), "v"(b[j][kk]));
+                if (K8LAST && kk == 6) {
+                    const u32x2 a2 = {a[kk][0], a[kk][1]}, b2 = {b[j][kk][0], b[j][kk][1]};
+                    asm volatile("v_mfma_f32_32x32x8bf16_1k %0, %1, %2, %0" : "+v"(c[j]) : "v"(a2), "v"(b2));
+                } else if (ACC_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c[j]) : "v"(a[kk]), "v"(b[j][kk]));
                 else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c[j]) : "v"(a[kk]), "v"(b[j][kk]));
             }
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[kk]) : "v"(addr), "n"(kk * 1024) : "memory");
@@ -48,13 +55,13 @@ __global__ __launch_bounds__(512) void k(float *out, const unsigned *data, long 
     if (threadIdx.x == 0) ticks[blockIdx.x] = clock64() - tk0;
 }
 
-template <int NB, bool ACC_AGPR>
+template <int NB, bool ACC_AGPR, bool K8LAST = false>
 void run(const char *name, int wps, float *out, unsigned *data, long long *ticks)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         if (rep == 1) hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((k<NB, ACC_AGPR>), dim3(256), dim3(256 * wps), 0, 0, out, data, ticks);
+        hipLaunchKernelGGL((k<NB, ACC_AGPR, K8LAST>), dim3(256), dim3(256 * wps), 0, 0, out, data, ticks);
     }
     hipEventRecord(e1, 0); hipDeviceSynchronize();
     float ms = 0; hipEventElapsedTime(&ms, e0, e1); ms /= 2;
@@ -84,6 +91,9 @@ int main()
         run<4, false>("4 blocks, all ArchVGPR (the shipped kernel's placement)", 2, out, data, ticks);
         run<4, true>("4 blocks, accumulators in AccVGPRs", 2, out, data, ticks);
         run<4, false>("4 blocks, all ArchVGPR", 1, out, data, ticks);
+        run<4, false, true>("4 blocks, 7th k-step as K8 (104 k-slots), per MFMA of 28", 2, out, data, ticks);
+        run<4, false, false>("4 blocks, 7 x K16 again (same clock state)", 2, out, data, ticks);
+        run<4, false, true>("4 blocks, 7th k-step as K8, again", 2, out, data, ticks);
     }
     return 0;
 }
