@@ -335,3 +335,11 @@ def test_resident_weights_1x1_kernel_against_the_lds_weights_kernel():
             torch.testing.assert_close(got, ref.relu() if relu else ref, rtol=2e-4, atol=2e-4)
     finally:
         lib.manet_tune_set(8, -2 ** 31)
+
+
+@pytest.mark.gpu
+def test_fuzz_head_and_mask_step_kernels():
+    """tools/fuzz_head.py: random shapes through the depthwise kernel, both 1x1 kernels (any Cin, add term, fused output layer),
+    head input assembly, label resize and upsample + argmax against torch (5 100 cases ran clean when it was written)"""
+    from tools import fuzz_head
+    assert fuzz_head.run(200, 20200614) == 0
