@@ -1,3 +1,5 @@
+"""A/B on the GPU box: ops.PreparedBank.match(adaptive=True) against adaptive=False on video-like embeddings at cfg2 size --
+what the adaptive policy's probes (one tiny launch into pinned host memory every 4th filtered frame) cost per match."""
 import os, sys, torch, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from cvpr2020_manet_amd import ops

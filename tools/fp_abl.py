@@ -1,3 +1,5 @@
+"""Ablations of manet_frame_prepare on the GPU box (needs a -DMANET_ABLATION build): HIP-event time per launch with single
+phases of the kernel switched off (manet_tune_set(MANET_TUNE_ABLATION, bits)); DESIGN.md 3.3."""
 import os, sys, ctypes, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 os.environ["MANET_TUNING"] = "1"

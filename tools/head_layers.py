@@ -1,3 +1,5 @@
+"""DynamicSegHead layer by layer on the GPU box: HIP-event time of layer 1 (shared-embedding route), layer 2, layer 4 + output
+layer and the whole head at [1,100,120,214] shared + [3,3,120,214] per-object inputs, for pointwise = f32 / split."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from cvpr2020_manet_amd.config import make_cfg
