@@ -22,7 +22,12 @@ embeddings were produced).
 
 The ONE JSON line also carries, at N = 1, the other single-GPU BASELINE configs as `also` legs
 (configs[2] = cfg3 and configs[4] = cfg5, bf16 arithmetic on 2-byte embeddings): ms per step, the
-dominant kernel's HIP-event time and roofline fraction, and their error against the fp32 oracle.
+dominant kernel's HIP-event time and roofline fraction, and their error against the fp32 oracle;
+`headline_exact_mode` (the headline workload through compute="bf16r": the fp32 bits at bf16 cost);
+`robustness` (cfg2 shape on i.i.d. / video-like / smooth / flat embeddings x f32 / bf16 / bf16r: what
+the distribution-dependent modes cost and err on each); `e2e` (the end-to-end propagated frame of
+examples/propagate_clip.py -- matching + segmentation head + mask step -- eager, HIP-graph replay and
+with the round's two directions on two HIP streams, for the fp32 and the split-bf16 head).
 
 Multi-GPU: `python bench.py --gpus N` starts its own N ranks (one process per GPU, RCCL); frames of
 the clip are sharded, K per rank (weak scaling; `--scaling strong`: a fixed 64-frame clip, BASELINE
