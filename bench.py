@@ -657,7 +657,7 @@ def e2e_block(device, args):
                        "upsample/argmax per frame; encoder outside the timed region" % args.e2e_frames,
            "unit": "frames/s", "modes": {}}
     logits = {}
-    for pw in ("f32", "split"):
+    for pw in ("f32", "split3", "split"):
         res, clip, final = pc.run_single(eargs, device, pointwise=pw, want_graph=True, want_stages=(pw == "f32"))
         with torch.no_grad():
             lg = {}
@@ -670,11 +670,11 @@ def e2e_block(device, args):
     out["value_graph"] = out["modes"]["f32"]["graph_frames_per_s"]
     # the round's two independent halves (forwards / backwards from the annotated frame) on two HIP streams of the one GPU
     out["value_two_streams"] = out["modes"]["f32"]["two_streams_frames_per_s"]
-    out["two_streams_masks_equal_eager"] = bool(out["modes"]["f32"]["two_streams_masks_equal_eager"]
-                                                and out["modes"]["split"]["two_streams_masks_equal_eager"])
+    out["two_streams_masks_equal_eager"] = bool(all(out["modes"][m]["two_streams_masks_equal_eager"] for m in out["modes"]))
     # split vs f32 head on the first propagated frame (same inputs: later frames see different previous masks)
     first = min(k for k in logits["f32"] if k > args.e2e_frames // 2)
     out["split_vs_f32_head_max_abs_logit_diff"] = float((logits["split"][first] - logits["f32"][first]).abs().max().item())
+    out["split3_vs_f32_head_max_abs_logit_diff"] = float((logits["split3"][first] - logits["f32"][first]).abs().max().item())
     out["split_vs_f32_head_logit_scale"] = float(logits["f32"][first].abs().max().item())
     # (no mask-agreement figure: random-init heads put the ids' logits within 1e-4 of each other on a quarter of the pixels, so
     # argmax flips there say nothing about a trained head; tests/test_seg_head.py bounds the kernel against an fp64 convolution)

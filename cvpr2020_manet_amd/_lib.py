@@ -72,6 +72,9 @@ SIGNATURES = {
     "manet_conv1x1_x3_weight_bytes": (_i64, [_i]),
     "manet_conv1x1_x3_pack": (_i, [_vp, _i, _i, _vp, _vp]),
     "manet_conv1x1_x3_f32": (_i, [_vp, _i64, _i, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "manet_conv1x1_x6_weight_bytes": (_i64, [_i]),
+    "manet_conv1x1_x6_pack": (_i, [_vp, _i, _i, _vp, _vp]),
+    "manet_conv1x1_x6_f32": (_i, [_vp, _i64, _i, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "manet_global_match_refine": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "manet_global_match_refine_stats": (_i, [_vp, _i64, _i, _i, ctypes.POINTER(ctypes.c_int64),
                                              ctypes.POINTER(ctypes.c_int64)]),

@@ -48,7 +48,7 @@ FLAGS = [
     # MI355X matching path (not in the reference; a reference cfg without them gets the defaults):
     #   MODEL_MATCH_COMPUTE  arithmetic of the global match: f32 (exact) | bf16 | bf16x3 | bf16r (bf16 filter + fp32 re-rank)
     #   MODEL_EMB_DTYPE      storage of extract_feature's output in HBM: f32 | bf16 (2-byte embeddings end to end)
-    #   MODEL_HEAD_POINTWISE the heads' 256-channel 1x1 layers in inference: f32 (exact fp32 MFMA) | split (split-bf16) | framework
+    #   MODEL_HEAD_POINTWISE the heads' 256-channel 1x1 layers in inference: f32 (exact fp32 MFMA) | split (split-bf16) | split3 (three-piece split: fp32-class) | framework
     #   MODEL_CACHE_FRAMES   keep prepared per-frame operands keyed on tensor identity (False: embeddings are rewritten in place)
     ("MODEL_MATCH_COMPUTE", S, "f32"), ("MODEL_EMB_DTYPE", S, "f32"), ("MODEL_HEAD_POINTWISE", S, "f32"),
     ("MODEL_CACHE_FRAMES", B, True),

@@ -433,36 +433,68 @@ __device__ __forceinline__ void x3_split(float x0, float x1, unsigned &hi, unsig
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){l0, l1}, x3_bf16x2));
 }
 
-// w2t [Cin][256] fp32 -> A-operand image [chunk][hi | lo][co block 8][lane 64] x 16 bytes; lane l of block b holds
-// output channel 32 b + (l & 31), input channels 16 chunk + 8 (l >> 5) + 0..7 (zero past Cin)
+// three pieces (r4, "split3"): x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 24 significand
+// bits -- every fp32 value is represented exactly (up to bf16's exponent range at the low end)
+__device__ __forceinline__ void x3_split3(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo)
+{
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0, x1}, x3_bf16x2));
+    const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
+    float r0, r1;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(x0), "v"(h0));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(x1), "v"(h1));
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r0, r1}, x3_bf16x2));
+    const float m0 = __uint_as_float(mid << 16), m1 = __uint_as_float(mid & 0xffff0000u);
+    float l0, l1;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(l0) : "v"(r0), "v"(m0));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(l1) : "v"(r1), "v"(m1));
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){l0, l1}, x3_bf16x2));
+}
+
+// w2t [Cin][256] fp32 -> A-operand image [chunk][hi | (mid |) lo][co block 8][lane 64] x 16 bytes; lane l of block b holds
+// output channel 32 b + (l & 31), input channels 16 chunk + 8 (l >> 5) + 0..7 (zero past Cin).  NP = pieces (2 or 3)
+template <int NP>
 __global__ __launch_bounds__(256) void conv1x1_x3_pack_kernel(const float *__restrict__ w2t, int Cin, uint4 *__restrict__ wpk, int n_chunks)
 {
     const int item = blockIdx.x * 256 + threadIdx.x;  // (chunk, block, lane)
     if (item >= n_chunks * 8 * 64) return;
     const int lane = item & 63, blk = (item >> 6) & 7, c = item >> 9;
     const int co = 32 * blk + (lane & 31), k0 = 16 * c + 8 * (lane >> 5);
-    unsigned hi[4], lo[4];
+    unsigned hi[4], mid[4], lo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int ka = k0 + 2 * j, kb = ka + 1;
         const float a = ka < Cin ? w2t[(long)ka * PW_CO + co] : 0.0f, b = kb < Cin ? w2t[(long)kb * PW_CO + co] : 0.0f;
-        x3_split(a, b, hi[j], lo[j]);
+        if (NP == 3) x3_split3(a, b, hi[j], mid[j], lo[j]);
+        else x3_split(a, b, hi[j], lo[j]);
     }
-    uint4 *dst = wpk + (long)c * (X3_WCHUNK / 16) + blk * 64 + lane;
+    uint4 *dst = wpk + (long)c * (NP * 8 * 1024 / 16) + blk * 64 + lane;
     dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    dst[8 * 64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    if (NP == 3) dst[8 * 64] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+    dst[(NP - 1) * 8 * 64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
-template <int ABL>
-__global__ __launch_bounds__(X3_NT, 3) void conv1x1_x3_kernel(const float *__restrict__ in, long in_bs, int Cin, long HW,
+// NP = 3 ("split3", r4): three pieces per factor, SIX products per pair -- hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi, the
+// dropped ones (mid*lo, lo*mid, lo*lo) below 2^-24 of the product: fp32-class results (each product good to ~2^-23, the sum in
+// fp32) at 6/16 of the fp32 pipe's time.  24 KiB of weights per chunk: 64 KiB of LDS, two workgroups per CU.
+template <int ABL, int NP = 2>
+__global__ __launch_bounds__(X3_NT, NP == 3 ? 2 : 3) void conv1x1_x3_kernel(const float *__restrict__ in, long in_bs, int Cin, long HW,
                                                               const char *__restrict__ wpk, const float *__restrict__ b2,
                                                               const float *__restrict__ add, int relu_out,
                                                               float *__restrict__ out, const float *__restrict__ head_w,
                                                               const float *__restrict__ head_b, float *__restrict__ head_out)
 {
-    __shared__ __attribute__((aligned(1024))) char wbuf[X3_NB][X3_WCHUNK];
+    constexpr int WCHUNK = NP * 8 * 1024;
+    __shared__ __attribute__((aligned(1024))) char wbuf[X3_NB][WCHUNK];
     __shared__ __attribute__((aligned(1024))) float xbuf[X3_NB][X3_KC * X3_P];
-    __shared__ float bsh[PW_CO];
+    // (the folded bias: its own 1 KiB for two pieces; with three the 64 KiB are full -- it moves into the weight ring once the
+    // loop is done with it)
+    float *bsh;
+    if constexpr (NP == 3) {
+        bsh = (float *)&wbuf[0][0];
+    } else {
+        __shared__ float bsh_own[PW_CO];
+        bsh = bsh_own;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = wave & 1, wc = wave >> 1;  // pixel half, output-channel half
@@ -481,9 +513,9 @@ __global__ __launch_bounds__(X3_NT, 3) void conv1x1_x3_kernel(const float *__res
     auto dma = [&](int c) __attribute__((always_inline)) {
         const unsigned slot = (unsigned)(c % X3_NB);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wave * 4 + i;
-            lds_dma16(wpk + (long)c * X3_WCHUNK + piece * 1024 + lane * 16, wbase + slot * (unsigned)X3_WCHUNK + (unsigned)piece * 1024u);
+        for (int i = 0; i < 2 * NP; ++i) {
+            const int piece = wave * (2 * NP) + i;
+            lds_dma16(wpk + (long)c * WCHUNK + piece * 1024 + lane * 16, wbase + slot * (unsigned)WCHUNK + (unsigned)piece * 1024u);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -500,7 +532,7 @@ __global__ __launch_bounds__(X3_NT, 3) void conv1x1_x3_kernel(const float *__res
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    bsh[tid] = b2[tid];
+    if (NP != 3) bsh[tid] = b2[tid];
     // chunks are fetched X3_NB - 1 steps ahead; a step waits for everything but the chunks issued behind its successor
     dma(0);
     if (X3_NB == 3 && n > 1) {
@@ -519,7 +551,7 @@ __global__ __launch_bounds__(X3_NT, 3) void conv1x1_x3_kernel(const float *__res
             continue;
         }
         const float *X = &xbuf[c % X3_NB][8 * (lane >> 5) * X3_P + wq * 64 + (lane & 31)];
-        uint4 bh[2], bl[2];
+        uint4 bh[2], bl[2], bm[NP == 3 ? 2 : 1];
         if (ABL & 16) {
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) bh[pb] = bl[pb] = make_uint4(lane + c, lane, c, pb);
@@ -529,16 +561,36 @@ __global__ __launch_bounds__(X3_NT, 3) void conv1x1_x3_kernel(const float *__res
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = X[j * X3_P + pb * 32];
-            x3_split(v[0], v[1], bh[pb].x, bl[pb].x);
-            x3_split(v[2], v[3], bh[pb].y, bl[pb].y);
-            x3_split(v[4], v[5], bh[pb].z, bl[pb].z);
-            x3_split(v[6], v[7], bh[pb].w, bl[pb].w);
+            if (NP == 3) {
+                x3_split3(v[0], v[1], bh[pb].x, bm[pb].x, bl[pb].x);
+                x3_split3(v[2], v[3], bh[pb].y, bm[pb].y, bl[pb].y);
+                x3_split3(v[4], v[5], bh[pb].z, bm[pb].z, bl[pb].z);
+                x3_split3(v[6], v[7], bh[pb].w, bm[pb].w, bl[pb].w);
+            } else {
+                x3_split(v[0], v[1], bh[pb].x, bl[pb].x);
+                x3_split(v[2], v[3], bh[pb].y, bl[pb].y);
+                x3_split(v[4], v[5], bh[pb].z, bl[pb].z);
+                x3_split(v[6], v[7], bh[pb].w, bl[pb].w);
+            }
         }
         }
         const uint4 *W = (const uint4 *)&wbuf[c % X3_NB][0] + (wc * 4) * 64 + lane;
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
-            const uint4 ah = W[blk * 64], al = W[(8 + blk) * 64];
+            const uint4 ah = W[blk * 64], al = W[((NP - 1) * 8 + blk) * 64];
+            if (NP == 3) {  // smallest terms first: (hi*lo, lo*hi, mid*mid), then (hi*mid, mid*hi), then hi*hi
+                const uint4 am = W[(8 + blk) * 64];
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    X3_MFMA(ah, bl[pb], acc[blk][pb]);
+                    X3_MFMA(al, bh[pb], acc[blk][pb]);
+                    X3_MFMA(am, bm[pb], acc[blk][pb]);
+                    X3_MFMA(ah, bm[pb], acc[blk][pb]);
+                    X3_MFMA(am, bh[pb], acc[blk][pb]);
+                    X3_MFMA(ah, bh[pb], acc[blk][pb]);
+                }
+                continue;
+            }
             if (ABL & 8) {
                 acc[blk][0][0] += __uint_as_float((ah.x ^ bl[0].x ^ bh[0].y ^ bl[0].z ^ bh[0].w) & 0xff);
                 acc[blk][1][0] += __uint_as_float((al.x ^ bl[1].x ^ bh[1].y ^ bl[1].z ^ bh[1].w ^ bh[1].x ^ bl[1].y ^ bh[0].x ^ bl[0].y ^ bh[0].z ^ bl[0].w ^ bh[1].z ^ bl[1].w) & 0xff);
@@ -556,6 +608,10 @@ __global__ __launch_bounds__(X3_NT, 3) void conv1x1_x3_kernel(const float *__res
         __syncthreads();
     }
 #undef X3_MFMA
+    if (NP == 3) {  // (everyone is past the loop's last barrier: the weight ring is free)
+        bsh[tid] = b2[tid];
+        __syncthreads();
+    }
     // C/D layout: column = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (output channel)
     const int co0 = wc * 128;
     if (head_w) {  // DynamicSegHead's output layer fused in (see conv1x1_mfma_kernel)
@@ -892,21 +948,50 @@ static int conv1x1_f32_impl(const float *in, int64_t in_batch_stride, int B, int
 // bytes of the packed split-bf16 weight image of a [Cin][256] 1x1 layer (manet_conv1x1_x3_pack)
 extern "C" int64_t manet_conv1x1_x3_weight_bytes(int Cin) { return Cin <= 0 ? 0 : (int64_t)((Cin + X3_KC - 1) / X3_KC) * X3_WCHUNK; }
 
-extern "C" int manet_conv1x1_x3_pack(const float *w2t, int Cin, int Cout, void *wpk, manet_stream_t stream)
+static int x3_pack_impl(const float *w2t, int Cin, int Cout, void *wpk, int pieces, manet_stream_t stream)
 {
     if (!w2t || !wpk || Cin <= 0) return manet_set_error(MANET_E_INVALID, "bad arguments");
     if (Cout != PW_CO) return manet_set_error(MANET_E_INVALID, "Cout=%d (this kernel is built for %d output channels)", Cout, PW_CO);
     if (((size_t)wpk & 15) != 0) return manet_set_error(MANET_E_INVALID, "wpk must be 16-byte aligned");
     const int n = (Cin + X3_KC - 1) / X3_KC;
-    hipLaunchKernelGGL(conv1x1_x3_pack_kernel, dim3((unsigned)(n * 2)), dim3(256), 0, (hipStream_t)stream, w2t, Cin, (uint4 *)wpk, n);
+    if (pieces == 3)
+        hipLaunchKernelGGL(conv1x1_x3_pack_kernel<3>, dim3((unsigned)(n * 2)), dim3(256), 0, (hipStream_t)stream, w2t, Cin, (uint4 *)wpk, n);
+    else
+        hipLaunchKernelGGL(conv1x1_x3_pack_kernel<2>, dim3((unsigned)(n * 2)), dim3(256), 0, (hipStream_t)stream, w2t, Cin, (uint4 *)wpk, n);
     return manet_check_launch("manet_conv1x1_x3_pack");
+}
+extern "C" int manet_conv1x1_x3_pack(const float *w2t, int Cin, int Cout, void *wpk, manet_stream_t stream)
+{
+    return x3_pack_impl(w2t, Cin, Cout, wpk, 2, stream);
+}
+// the three-piece form ("split3": hi + mid + lo, six products per pair): 24 KiB per 16 input channels
+extern "C" int64_t manet_conv1x1_x6_weight_bytes(int Cin) { return Cin <= 0 ? 0 : (int64_t)((Cin + X3_KC - 1) / X3_KC) * 3 * 8 * 1024; }
+extern "C" int manet_conv1x1_x6_pack(const float *w2t, int Cin, int Cout, void *wpk, manet_stream_t stream)
+{
+    return x3_pack_impl(w2t, Cin, Cout, wpk, 3, stream);
 }
 
 // 1x1 convolution with 256 output channels in split-bf16 arithmetic (conv1x1_x3_kernel); add: optional [256][HW] term
 // shared by every batch entry; head_w != NULL: DynamicSegHead's output layer fused (`out` is not written)
+static int x3_impl(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const void *wpk, const float *b2,
+                   const float *add, int Cout, int relu_out, float *out, const float *head_w, const float *head_b,
+                   float *head_out, int pieces, manet_stream_t stream);
 extern "C" int manet_conv1x1_x3_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const void *wpk,
                                     const float *b2, const float *add, int Cout, int relu_out, float *out, const float *head_w,
                                     const float *head_b, float *head_out, manet_stream_t stream)
+{
+    return x3_impl(in, in_batch_stride, B, Cin, HW, wpk, b2, add, Cout, relu_out, out, head_w, head_b, head_out, 2, stream);
+}
+// ... with three pieces per factor (wpk from manet_conv1x1_x6_pack): fp32-class results at 6/16 of the fp32 matrix pipe's time
+extern "C" int manet_conv1x1_x6_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const void *wpk,
+                                    const float *b2, const float *add, int Cout, int relu_out, float *out, const float *head_w,
+                                    const float *head_b, float *head_out, manet_stream_t stream)
+{
+    return x3_impl(in, in_batch_stride, B, Cin, HW, wpk, b2, add, Cout, relu_out, out, head_w, head_b, head_out, 3, stream);
+}
+static int x3_impl(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const void *wpk, const float *b2,
+                   const float *add, int Cout, int relu_out, float *out, const float *head_w, const float *head_b,
+                   float *head_out, int pieces, manet_stream_t stream)
 {
     if (!in || !wpk || !b2 || (!out && !head_w) || (head_w && !head_out) || B <= 0 || B > 65535 || Cin <= 0 || HW <= 0)
         return manet_set_error(MANET_E_INVALID, "bad arguments");
@@ -916,6 +1001,11 @@ extern "C" int manet_conv1x1_x3_f32(const float *in, int64_t in_batch_stride, in
         return manet_set_error(MANET_E_INVALID, "in / wpk must be 16-byte aligned, the batch stride a multiple of 4 elements");
     if (head_w && add) return manet_set_error(MANET_E_INVALID, "add and the fused output layer are exclusive");
     dim3 grid((unsigned)((HW + X3_P - 1) / X3_P), (unsigned)B);
+    if (pieces == 3) {
+        hipLaunchKernelGGL((conv1x1_x3_kernel<0, 3>), grid, dim3(X3_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin, (long)HW,
+                           (const char *)wpk, b2, add, relu_out, out, head_w, head_b, head_out);
+        return manet_check_launch("manet_conv1x1_x6_f32");
+    }
 #define X3_LAUNCH(A_)                                                                                                        \
     hipLaunchKernelGGL(conv1x1_x3_kernel<A_>, grid, dim3(X3_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin, (long)HW, \
                        (const char *)wpk, b2, add, relu_out, out, head_w, head_b, head_out)

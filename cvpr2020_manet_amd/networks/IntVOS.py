@@ -49,11 +49,14 @@ cfg = _default_cfg
 #   "split" : split-bf16 MFMA kernel (ops.conv1x1_split: fp32 factors as hi + lo bf16 pieces, fp32 accumulation; error
 #             <= 2^-16 relative per product -- between fp32 and the TF32 the reference's cuDNN path defaults to) -- the stage
 #             becomes a stream over its activation (2.3x faster); opt-in;
+#   "split3": the same kernel with THREE bf16 pieces per factor (hi + mid + lo = 24 significand bits) and six products per pair:
+#             fp32-class results (~2^-23 relative per product, fp32 accumulation; not the fmaf chain's bits) at 6/16 of the
+#             fp32 matrix pipe's time; opt-in;
 #   False / "framework" : the framework's GEMM as in r2.
 # This global is only the default of heads built OUTSIDE an IntVOS; a model carries its own mode
 # (IntVOS(cfg, fe, pointwise=...) / cfg.MODEL_HEAD_POINTWISE), stamped on its _split_separable_conv2d blocks.
 MFMA_POINTWISE = "f32"
-_POINTWISE_MODES = {"f32": "f32", True: "f32", "split": "split", False: False, "framework": False}
+_POINTWISE_MODES = {"f32": "f32", True: "f32", "split": "split", "split3": "split3", False: False, "framework": False}
 
 
 def _pointwise_mode(block=None):
@@ -254,10 +257,11 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
             mode = _pointwise_mode(self)
             if self.conv2.out_channels == ops.PW_COUT and mode and w2.is_cuda:  # the weight transposed [Cin, Cout]
                 w2t = w2.reshape(w2.shape[0], w2.shape[1]).t().contiguous()
-                if mode == "split":  # ops.conv1x1_split: packed hi / lo operand images
-                    val["sw"] = ops.SplitWeight(w2t)
+                if mode in ("split", "split3"):  # ops.conv1x1_split: packed hi / (mid /) lo operand images
+                    np_ = 3 if mode == "split3" else 2
+                    val["sw"] = ops.SplitWeight(w2t, pieces=np_)
                     if 0 < cs < w2t.shape[0]:
-                        val["sw_shared"], val["sw_object"] = ops.SplitWeight(w2t[:cs]), ops.SplitWeight(w2t[cs:])
+                        val["sw_shared"], val["sw_object"] = ops.SplitWeight(w2t[:cs], pieces=np_), ops.SplitWeight(w2t[cs:], pieces=np_)
                 else:  # ops.conv1x1_mfma
                     val["w2t"], val["w2t_shared"], val["w2t_object"] = w2t, w2t[:cs].contiguous(), w2t[cs:].contiguous()
             val["mode"] = mode
@@ -406,7 +410,8 @@ class IntVOS(nn.Module):
           emb_dtype     storage type of extract_feature's output: "f32" | "bf16" (the matching kernels then read 2-byte
                         embeddings end to end; the heads widen them)
           pointwise     the heads' 256-channel 1x1 layers in inference: "f32" exact fp32-MFMA kernel | "split" split-bf16
-                        MFMA kernel (<= 2^-16 relative per product, 2.3x faster) | "framework" the framework's GEMM
+                        MFMA kernel (<= 2^-16 relative per product, 2.3x faster) | "split3" three-piece split (fp32-class:
+                        ~2^-23 per product) | "framework" the framework's GEMM
           cache_frames  keep prepared per-frame operands keyed on the embedding tensor's identity (_prepared_frame).
                         False: every call prepares afresh -- REQUIRED when embeddings are rewritten in place without
                         torch noticing (HIP-graph replay of the encoder into a static buffer, `.data` writes)"""
@@ -415,7 +420,7 @@ class IntVOS(nn.Module):
         self.cfg = cfg
         pw = pointwise if pointwise is not None else getattr(cfg, "MODEL_HEAD_POINTWISE", "f32")
         if pw not in _POINTWISE_MODES:
-            raise ValueError("pointwise=%r ('f32', 'split' or 'framework')" % (pw,))
+            raise ValueError("pointwise=%r ('f32', 'split', 'split3' or 'framework')" % (pw,))
         self.pointwise = pw
         cf = cache_frames if cache_frames is not None else getattr(cfg, "MODEL_CACHE_FRAMES", True)
         self.cache_frames = bool(cf)

@@ -789,20 +789,25 @@ def conv1x1_mfma(x, w2t, b2, relu_out=False, head_weight=None, head_bias=None, a
 
 
 class SplitWeight:
-    """A 1x1 layer's folded weight packed for conv1x1_split (manet_conv1x1_x3_pack): the MFMA A-operand image of its hi
-    and lo bf16 pieces.  `cin` input channels, PW_COUT output channels."""
+    """A 1x1 layer's folded weight packed for conv1x1_split (manet_conv1x1_x3_pack / _x6_pack): the MFMA A-operand image of
+    its bf16 pieces -- pieces=2: hi + lo (16 significand bits, three products per pair), pieces=3: hi + mid + lo (24 bits,
+    six products: fp32-class).  `cin` input channels, PW_COUT output channels."""
 
-    def __init__(self, w2t):
+    def __init__(self, w2t, pieces=2):
         lib = _lib.load()
         _need_gpu(w2t, "w2t")
+        if pieces not in (2, 3):
+            raise ValueError("pieces must be 2 or 3")
         w2t = w2t.detach().float().contiguous()
         if w2t.dim() != 2 or w2t.shape[1] != PW_COUT:
             raise ValueError("w2t must be [Cin, %d] (ops.fold_pointwise)" % PW_COUT)
-        self.cin = int(w2t.shape[0])
-        self.packed = torch.empty(int(lib.manet_conv1x1_x3_weight_bytes(self.cin)), dtype=torch.uint8, device=w2t.device)
+        self.cin, self.pieces = int(w2t.shape[0]), int(pieces)
+        nbytes, pack = ((lib.manet_conv1x1_x6_weight_bytes, lib.manet_conv1x1_x6_pack) if pieces == 3
+                        else (lib.manet_conv1x1_x3_weight_bytes, lib.manet_conv1x1_x3_pack))
+        self.packed = torch.empty(int(nbytes(self.cin)), dtype=torch.uint8, device=w2t.device)
         with _on(w2t.device):
-            rc = lib.manet_conv1x1_x3_pack(w2t.data_ptr(), self.cin, PW_COUT, self.packed.data_ptr(), _stream_ptr(w2t.device))
-        _lib.check(rc, "manet_conv1x1_x3_pack")
+            rc = pack(w2t.data_ptr(), self.cin, PW_COUT, self.packed.data_ptr(), _stream_ptr(w2t.device))
+        _lib.check(rc, "manet_conv1x1_x%d_pack" % (3 if pieces == 2 else 6))
 
 
 def conv1x1_split_ok(x, cout):
@@ -812,7 +817,8 @@ def conv1x1_split_ok(x, cout):
 
 def conv1x1_split(x, weight, b2, relu_out=False, add=None, head_weight=None, head_bias=None):
     """conv2 -> bn2 [-> relu2] of a _split_separable_conv2d block (IntVOS.py:494,503-505) in split-bf16 arithmetic
-    (manet_conv1x1_x3_f32: fp32 factors as hi + lo bf16 pieces, fp32 accumulation; <= 2^-16 relative per product).
+    (manet_conv1x1_x3_f32: fp32 factors as hi + lo bf16 pieces, fp32 accumulation; <= 2^-16 relative per product; with a
+    three-piece SplitWeight manet_conv1x1_x6_f32: hi + mid + lo, six products, ~2^-23 per product -- fp32-class).
     x [B, Cin, h, w] fp32; weight a SplitWeight; b2 [256] -> [B, 256, h, w].
     add [1, 256, h, w] (or [256, h, w]): added to every batch entry before relu_out -- layer1's shared-embedding half.
     head_weight / head_bias: DynamicSegHead's output layer fused (see conv1x1_mfma) -> [B, 1, h, w]."""
@@ -844,11 +850,11 @@ def conv1x1_split(x, weight, b2, relu_out=False, add=None, head_weight=None, hea
     else:
         out = torch.empty((B, PW_COUT, h, w), dtype=torch.float32, device=x.device)
     ptr = lambda t: None if t is None else t.data_ptr()
+    fn = lib.manet_conv1x1_x6_f32 if weight.pieces == 3 else lib.manet_conv1x1_x3_f32  # (the weight's packing decides)
     with _on(x.device):
-        rc = lib.manet_conv1x1_x3_f32(x.data_ptr(), cin * h * w, B, cin, h * w, weight.packed.data_ptr(), b2.data_ptr(),
-                                      ptr(add), PW_COUT, int(bool(relu_out)), ptr(out), ptr(hw), ptr(hb), ptr(hout),
-                                      _stream_ptr(x.device))
-    _lib.check(rc, "manet_conv1x1_x3_f32")
+        rc = fn(x.data_ptr(), cin * h * w, B, cin, h * w, weight.packed.data_ptr(), b2.data_ptr(),
+                ptr(add), PW_COUT, int(bool(relu_out)), ptr(out), ptr(hw), ptr(hb), ptr(hout), _stream_ptr(x.device))
+    _lib.check(rc, "manet_conv1x1_x6_f32" if weight.pieces == 3 else "manet_conv1x1_x3_f32")
     return hout if head_weight is not None else out
 
 

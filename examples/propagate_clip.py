@@ -173,6 +173,9 @@ class StageTimer:
                 for k in sorted(tot, key=lambda k: -tot[k])}
 
 
+_STREAM_PAIRS = {}  # device -> the two HIP streams of Clip.one_round_two_streams
+
+
 class Clip:
     """a clip's embeddings + scribble + everything one interaction round needs"""
 
@@ -257,8 +260,12 @@ class Clip:
             lmaps[1][SEQ] = torch.zeros(104, 9, device=self.dev)
         # ... and so does the annotated frame's memory bank (the first propagated frame would otherwise build it on ITS stream)
         model.prepare_bank(ref, self.scribble, SEQ, self.gt)
-        if not hasattr(self, "_streams"):
-            self._streams = (torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev))
+        # ONE pair of streams per device and process: HIP deals a process's streams to its hardware queues round-robin, and
+        # two streams on one queue run in order -- the first pair a process creates sits on two queues (measured; later
+        # pairs may not: the 2nd pair with 4 queues, the 4th with 8)
+        if self.dev not in _STREAM_PAIRS:
+            _STREAM_PAIRS[self.dev] = (torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev))
+        self._streams = _STREAM_PAIRS[self.dev]
         main = torch.cuda.current_stream(self.dev)
         orders = [list(o) for o in self.propagation_order()]
         state = [[ref_label, ref], [ref_label, ref]]
@@ -495,7 +502,7 @@ def parse_args(argv=None):
     ap.add_argument("--fused-mask-step", action="store_true",
                     help="use ops.upsample_argmax instead of F.interpolate + argmax (test.py:253-255)")
     ap.add_argument("--graph", action="store_true", help="capture a propagated frame in a HIP graph and replay it")
-    ap.add_argument("--pointwise", type=str, default=None, choices=["split", "f32", "framework"],
+    ap.add_argument("--pointwise", type=str, default=None, choices=["split", "split3", "f32", "framework"],
                     help="the heads' 1x1 convolutions: exact fp32-MFMA kernel (default), the split-bf16 MFMA kernel, or the "
                          "framework's GEMM")
     ap.add_argument("--compute", type=str, default=None, help="arithmetic of the global match (f32 | bf16 | bf16x3 | bf16r)")

@@ -371,6 +371,15 @@ int manet_conv1x1_add_f32(const float *in, int64_t in_batch_stride, int B, int C
  *   manet_conv1x1_x3_f32: in as above but ANY Cin >= 1 (HW a multiple of 4); add = NULL or [256][HW] fp32 added to every batch
  *     entry's output before relu_out (layer1 of the shared-embedding form: the embedding half of the contraction, computed
  *     once per frame); head_w / head_b / head_out as manet_conv1x1_head_f32 (exclusive with add). */
+/* ... and with THREE pieces per factor ("split3": hi + mid + lo = 24 significand bits, six products per pair -- hi*hi + hi*mid +
+ * mid*hi + mid*mid + hi*lo + lo*hi, the dropped terms below 2^-24 of a product): fp32-class results (not the fmaf chain's bits:
+ * the sum is taken in another order) at 6/16 of the fp32 matrix pipe's time.  manet_conv1x1_x6_weight_bytes / _pack / _f32: as
+ * the _x3_ trio, 24 KiB of packed weights per 16 input channels. */
+int64_t manet_conv1x1_x6_weight_bytes(int Cin);
+int manet_conv1x1_x6_pack(const float *w2t, int Cin, int Cout, void *wpk, manet_stream_t stream);
+int manet_conv1x1_x6_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const void *wpk, const float *b2,
+                         const float *add, int Cout, int relu_out, float *out, const float *head_w, const float *head_b,
+                         float *head_out, manet_stream_t stream);
 int64_t manet_conv1x1_x3_weight_bytes(int Cin);
 int manet_conv1x1_x3_pack(const float *w2t, int Cin, int Cout, void *wpk, manet_stream_t stream);
 int manet_conv1x1_x3_f32(const float *in, int64_t in_batch_stride, int B, int Cin, int64_t HW, const void *wpk, const float *b2,

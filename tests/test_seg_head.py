@@ -343,3 +343,66 @@ def test_fuzz_head_and_mask_step_kernels():
     head input assembly, label resize and upsample + argmax against torch (5 100 cases ran clean when it was written)"""
     from tools import fuzz_head
     assert fuzz_head.run(200, 20200614) == 0
+
+
+@pytest.mark.gpu
+def test_three_piece_split_pointwise_is_fp32_class():
+    """ops.conv1x1_split with a three-piece SplitWeight (hi + mid + lo = 24 significand bits, six products per pair on the bf16
+    MFMA, fp32 accumulation): against an fp64 convolution its error is the fp32 kernel's class -- bound per output
+    2^-21 * sum_k |x_k| |w_k| (the dropped products < 2^-24 each, the rest is fp32 accumulation over up to 256 terms) -- two orders below the
+    two-piece kernel's 2^-15; same forms (relu_out, add, fused output layer, any Cin, partial tiles, non-finite inputs)."""
+    import torch
+    from cvpr2020_manet_amd import ops
+    torch.manual_seed(6)
+    with torch.no_grad():
+        worst3, worst32 = 0.0, 0.0
+        for (B, cin, h, w) in ((3, 256, 30, 54), (2, 100, 9, 12), (3, 3, 21, 36), (1, 1, 2, 2), (2, 17, 6, 10), (2, 33, 5, 52),
+                               (3, 256, 120, 214)):
+            x = torch.randn(B, cin, h, w, device="cuda") * 1.5
+            w2t = torch.randn(cin, 256, device="cuda") * 0.08
+            b2 = torch.randn(256, device="cuda")
+            sw = ops.SplitWeight(w2t, pieces=3)
+            assert sw.pieces == 3 and sw.packed.numel() == -(-cin // 16) * 24576
+            w64 = w2t.t().reshape(256, cin, 1, 1).double()
+            ref = torch.nn.functional.conv2d(x.double(), w64, b2.double())
+            mag = torch.nn.functional.conv2d(x.double().abs(), w64.abs()) + b2.abs().double().view(1, -1, 1, 1)
+            got = ops.conv1x1_split(x, sw, b2)
+            err = (got.double() - ref).abs()
+            assert bool((err <= 2.0 ** -21 * mag).all()), (cin, float((err / (2.0 ** -21 * mag)).max()))
+            worst3 = max(worst3, float((err / mag).max()))
+            worst32 = max(worst32, float(((ops.conv1x1_mfma(x, w2t, b2).double() - ref).abs() / mag).max()))
+            assert torch.equal(ops.conv1x1_split(x, sw, b2, relu_out=True), torch.relu(got))
+            add = torch.randn(1, 256, h, w, device="cuda")
+            torch.testing.assert_close(ops.conv1x1_split(x, sw, b2, add=add, relu_out=True), torch.relu(got + add), rtol=1e-6, atol=1e-6)
+            fin = torch.nn.Conv2d(256, 1, 1).cuda()
+            torch.testing.assert_close(ops.conv1x1_split(x, sw, b2, head_weight=fin.weight, head_bias=fin.bias),
+                                       fin(torch.relu(got)), rtol=1e-5, atol=1e-5)
+        print("max relative error (of sum |x||w| + |b|): three-piece split %.3g, fp32 MFMA kernel %.3g" % (worst3, worst32))
+        assert worst3 < 4 * max(worst32, 2.0 ** -24)  # the fp32 kernel's class
+        x = torch.randn(1, 8, 4, 8, device="cuda")
+        x[0, 3, 1, 2] = float("inf")
+        x[0, 5, 2, 7] = float("nan")
+        y = ops.conv1x1_split(x, ops.SplitWeight(torch.ones(8, 256, device="cuda"), pieces=3), torch.zeros(256, device="cuda"))
+        bad = ~torch.isfinite(y[0, 0])
+        assert bad.sum().item() == 2 and bool(bad[1, 2]) and bool(bad[2, 7])
+        with pytest.raises(ValueError):
+            ops.SplitWeight(torch.ones(8, 256, device="cuda"), pieces=4)
+    # the module route: pointwise="split3" against the fp32 head
+    from cvpr2020_manet_amd.networks import IntVOS as M
+    torch.manual_seed(7)
+    with torch.no_grad():
+        head = M.DynamicSegHead(in_dim=103, embed_dim=256).cuda().eval()
+        for m in head.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 2.0); m.weight.data.normal_(1, 0.1); m.bias.data.normal_(0, 0.1)
+        xs = torch.randn(3, 103, 24, 30, device="cuda")
+        outs = {}
+        for mode in ("f32", "split3", "split"):
+            for blk in head.modules():
+                if isinstance(blk, M._split_separable_conv2d):
+                    object.__setattr__(blk, "_pw_mode", mode)
+            outs[mode] = head.forward_shared(xs[:1, :100].contiguous(), xs[:, 100:].contiguous())
+        scale = float(outs["f32"].abs().max())
+        d3, d2 = float((outs["split3"] - outs["f32"]).abs().max()), float((outs["split"] - outs["f32"]).abs().max())
+        print("head logits vs the fp32 head: three-piece %.3g, two-piece %.3g (scale %.3g)" % (d3, d2, scale))
+        assert d3 <= 2e-6 * max(scale, 1.0) and d3 < d2
