@@ -690,13 +690,17 @@ def e2e_parallel_main(args, device, rank, world, backend):
     chain ranks (0: forwards from the annotated frame, 1: backwards), which run local match + head + mask frame by frame
     (examples/propagate_clip.py)."""
     from examples import propagate_clip as pc
-    eargs = pc.parse_args(["--frames", str(args.e2e_frames), "--fused-mask-step", "--gpus", str(world)])
+    eargs = pc.parse_args(["--frames", str(args.e2e_frames), "--fused-mask-step", "--gpus", str(world)]
+                          + (["--two-streams"] if world == 1 else []))
     if world > 1:
         res = pc.run_parallel(eargs, device, rank, world)
     else:
         r1, clip, final = pc.run_single(eargs, device)
         res = {"frames": r1["frames"], "world": 1, "backend": None, "pointwise": r1["pointwise"], "compute": r1["compute"],
                "parallel_ms_per_round": r1["eager_ms_per_round"], "parallel_frames_per_s": r1["eager_frames_per_s"],
+               # one GPU: the round's two directions on two HIP streams (what two chain ranks do on two GPUs)
+               "two_streams_frames_per_s": r1["two_streams_frames_per_s"],
+               "two_streams_masks_equal_eager": r1["two_streams_masks_equal_eager"],
                "masks_bit_equal_to_single_rank": True, "mask_digest": r1["mask_digest"], "collective": None}
     if rank != 0:
         return None
