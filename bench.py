@@ -171,6 +171,12 @@ class Workload:
         """algorithmic bytes of the local stage: both embeddings read once + labels + the [h,w,n_ids] result"""
         return 2.0 * (2 if self.emb == "bf16" else 4) * C * self.H * self.W + 4.0 * self.H * self.W * (1 + self.n_ids)
 
+    def describe_short(self, args):
+        return ("BASELINE configs[%d]: grid %dx%d, C=%d, %d-frame fully-labelled bank (M=%d), %d ids, %s arithmetic on %s-stored %s "
+                "embeddings; step = frame prepare + global match + fused normalise/min-merge + local match d=%d; bank %s"
+                % (self.cfg - 1, self.H, self.W, C, self.T, self.T * self.H * self.W, self.n_ids, self.compute, self.emb, self.data,
+                   self.d, "re-packed per frame" if args.one_shot else "sorted/packed once per clip, timed"))
+
     def describe(self, args):
         M = self.T * self.H * self.W
         return ("BASELINE configs[%d]: %s embeddings, grid %dx%d, C=%d, %d-frame fully-labelled bank (M=%d), %d ids, %s arithmetic, "
@@ -460,6 +466,8 @@ def cpu_baseline(wl, bank_rows, bank_lab, gpu_global=None, gpu_local=None):
     fused_fps = 1.0 / frame_s
     best = max(fused_fps, blas.get("frames_per_s", 0.0))
     res = {"value": best, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample_short": "global: %d of %d query px x full %d-row bank, %dx%.2fs; local d=%d whole frame %dx%.2fs; C port, %d thr"
+                           % (nq, N, bank_rows.shape[0], reps, t_glob, wl.d, lreps, t_loc, cores),
            "forms": {"fused_c_port_frames_per_s": fused_fps, "blas_port": blas,
                      "reported": "blas_port" if best > fused_fps else "fused_c_port"},
            "sample": "global match: %d of %d query pixels x full %d-row bank, %d repetition(s), %.2f s each (scaled "
@@ -715,6 +723,120 @@ def e2e_parallel_main(args, device, rank, world, backend):
             "collective": res.get("collective"), "e2e_parallel": res}
 
 
+def _r5(x):
+    """floats to 5 significant digits, recursively (the compact line is read by a driver that keeps an 8 KB tail)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return x if x != x or x in (float("inf"), float("-inf")) else float("%.5g" % x)
+    if isinstance(x, dict):
+        return {k: _r5(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r5(v) for v in x]
+    return x
+
+
+COMPACT_LIMIT = 4096  # bytes of the LAST stdout line (VERDICT r4: the driver could not parse a 20.6 KB line)
+
+
+def compact_line(full):
+    """The driver-facing line: the contract's keys + `config`, `roofline`, `cpu_baseline`, `parity`, and scalar summaries of every
+    other block, <= COMPACT_LIMIT bytes.  The full blocks go to bench_full.json next to this script and to an earlier stdout
+    line prefixed `#bench_full `."""
+    if full is None:
+        return None
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    out = {k: full.get(k) for k in keep if k in full}
+    cfg = dict(full.get("config") or {})
+    if cfg.get("workload_short"):
+        cfg["workload"] = cfg.pop("workload_short")
+    elif isinstance(cfg.get("workload"), str) and len(cfg["workload"]) > 330:
+        cfg["workload"] = cfg["workload"][:327] + "..."
+    out["config"] = cfg
+    roof = full.get("roofline")
+    if roof:
+        r = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
+                                      "algorithmic_flops_per_launch")}
+        src = roof.get("traffic_source") or {}
+        r["traffic_stale"], r["traffic_kernel_source_sha"] = src.get("stale"), src.get("kernel_source_sha")
+        out["roofline"] = r
+    cb = full.get("cpu_baseline")
+    if cb:
+        smp = cb.get("sample_short") or cb.get("sample") or ""
+        out["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": smp if len(smp) <= 120 else smp[:117] + "..."}
+    elif "cpu_baseline" in full:
+        out["cpu_baseline"] = None
+    if full.get("parity"):
+        out["parity"] = {k: v for k, v in full["parity"].items() if k != "reference"}
+    ls = full.get("local_stage")
+    if ls:
+        out["local_stage"] = {"frac": ls.get("frac"), "stage_ms": ls.get("stage_ms"), "window_kernel_ms": ls.get("window_kernel_ms"),
+                              "frame_prepare_ms": ls.get("frame_prepare_ms"), "valu_frac": (ls.get("valu") or {}).get("frac"),
+                              "max_distance": ls.get("max_distance")}
+    if full.get("collective") is not None:
+        out["collective"] = full["collective"]
+    if "value_one_shot" in full:
+        out["value_one_shot"] = full["value_one_shot"]
+    hx = full.get("headline_exact_mode")
+    if hx:
+        out["headline_exact_mode"] = {"dtype": hx.get("dtype"), "value": hx.get("value"),
+                                      "bit_equal_to_f32": hx.get("bit_equal_to_f32_on_probe_frame")}
+    if full.get("also"):
+        legs = []
+        for a in full["also"]:
+            un = ((a.get("parity") or {}).get("unrounded_fp32_inputs") or {}).get(a.get("dtype")) or {}
+            legs.append({"cfg": a.get("cfg"), "dtype": a.get("dtype"), "value": a.get("value"), "ms_per_step": a.get("ms_per_step"),
+                         "frac": (a.get("roofline") or {}).get("frac"), "kernel_ms": a.get("kernel_ms"),
+                         "err_max": un.get("err_vs_fp32_oracle_normalised_max"),
+                         "exact_value": (a.get("exact_mode") or {}).get("value"),
+                         "local_window_ms": (a.get("local_stage") or {}).get("window_kernel_ms")})
+        out["also"] = legs
+    rb = full.get("robustness")
+    if rb and rb.get("summary"):
+        s = rb["summary"]
+        out["robustness"] = {"f32_fps": s.get("f32_frames_per_s"), "bf16r_fps": s.get("bf16r_frames_per_s_iid_video_smooth_flat"),
+                             "bf16_err_0.1": s.get("bf16_max_err_scale_0.1"), "bf16_err_0.3": s.get("bf16_max_err_scale_0.3")}
+    e = full.get("e2e")
+    if e:
+        ek = ("value", "value_graph", "value_two_streams", "value_scribble_bank", "value_bank_frames_5", "bank", "bank_rows",
+              "masks_equal_eager_graph_two_streams")
+        ce = {k: e[k] for k in ek if k in e}
+        w = e.get("workload") or ""
+        ce["workload"] = w if len(w) <= 200 else w[:197] + "..."
+        out["e2e"] = ce
+    if full.get("e2e_parallel"):
+        ep = full["e2e_parallel"]
+        out["e2e_parallel"] = {k: ep.get(k) for k in ("frames", "world", "backend", "parallel_frames_per_s",
+                                                      "two_streams_frames_per_s", "masks_bit_equal_to_single_rank") if k in ep}
+    out["full"] = "bench_full.json"
+    out = _r5(out)
+    # belt and braces: the line must fit whatever a later block grows to
+    for drop in ("e2e_parallel", "headline_exact_mode", "value_one_shot", "robustness", "also", "e2e", "local_stage"):
+        if len(json.dumps(out)) <= COMPACT_LIMIT:
+            break
+        out.pop(drop, None)
+    return out
+
+
+def emit(line):
+    """rank 0: the full line to bench_full.json and to a prefixed stdout line, then the compact line LAST"""
+    try:  # RCCL writes a version banner through C stdio: flush it first so the JSON line comes last
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    full = json.dumps(line)
+    try:
+        with open(os.path.join(ROOT, "bench_full.json"), "w") as f:
+            f.write(full + "\n")
+    except OSError:
+        pass
+    sys.stdout.write("#bench_full " + full + "\n")
+    sys.stdout.write(json.dumps(compact_line(line)) + "\n")
+    sys.stdout.flush()
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU,
     torch.distributed.run, rendezvous on 127.0.0.1) and relay rank 0's JSON line.  Called BEFORE anything
@@ -828,11 +950,7 @@ def main():
         if use_dist:
             dist.destroy_process_group()
         if rank == 0:
-            try:
-                ctypes.CDLL(None).fflush(None)
-            except Exception:
-                pass
-            print(json.dumps(line), flush=True)
+            emit(line)
         return
 
     K, Wm = args.steps, args.warmup
@@ -870,7 +988,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.compute,
             "data": "synthetic",
-            "config": {"workload": wl.describe(args), "frames_per_gpu": K,
+            "config": {"workload": wl.describe(args), "workload_short": wl.describe_short(args), "frames_per_gpu": K,
                        "clip_frames": world * K,
                        "bank_exchange": "1 RCCL all-gather in the timed region" if world > 1 else "none (1 GPU)"},
             "roofline": roof,
@@ -912,11 +1030,7 @@ def main():
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
-        try:  # RCCL writes a version banner through C stdio: flush it first so the JSON line comes last
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(line), flush=True)
+        emit(line)
 
 
 if __name__ == "__main__":
