@@ -253,6 +253,7 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
             w2 = (self.conv2.weight.detach().float() * scale2[:, None, None, None]).contiguous()
             b2 = (self.conv2.bias.detach().float() * scale2 + shift2 if self.conv2.bias is not None else shift2).contiguous()
             val = {"scale1": scale1.contiguous(), "shift1": shift1.contiguous(), "w2": w2, "b2": b2,
+                   "b2_zero": torch.zeros_like(b2),  # (made here: exists before a driver forks its streams, prepare_bank)
                    "w2_shared": w2[:, :cs].contiguous(), "w2_object": w2[:, cs:].contiguous()}
             mode = _pointwise_mode(self)
             if self.conv2.out_channels == ops.PW_COUT and mode and w2.is_cuda:  # the weight transposed [Cin, Cout]
@@ -273,11 +274,11 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         channels, h*w a multiple of 4), else the framework's convolution with the same folded weights"""
         skey = {"all": "sw", "shared": "sw_shared", "object": "sw_object"}[which]
         if skey in k and ops.conv1x1_split_ok(y, self.conv2.out_channels):
-            b2 = k["b2"] if bias else k.setdefault("b2_zero", torch.zeros_like(k["b2"]))
+            b2 = k["b2"] if bias else k["b2_zero"]
             return ops.conv1x1_split(y, k[skey], b2, relu_out=relu)
         wkey = {"all": "w2t", "shared": "w2t_shared", "object": "w2t_object"}[which]
         if wkey in k and ops.conv1x1_mfma_ok(y, self.conv2.out_channels):
-            b2 = k["b2"] if bias else k.setdefault("b2_zero", torch.zeros_like(k["b2"]))
+            b2 = k["b2"] if bias else k["b2_zero"]
             return ops.conv1x1_mfma(y, k[wkey], b2, relu_out=relu)
         w = {"all": "w2", "shared": "w2_shared", "object": "w2_object"}[which]
         z = F.conv2d(y, k[w], k["b2"] if bias else None)
@@ -317,11 +318,11 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         p1 = ops.dwconv7x7_bn_relu(per_object, w1[cs:], b1[cs:], scale=scale[cs:], shift=shift[cs:])
         if "sw_object" in k and ops.conv1x1_split_ok(p1, self.conv2.out_channels):
             # the shared half once, then the per-object half with it added in the epilogue (no broadcast-add pass)
-            zero = k.setdefault("b2_zero", torch.zeros_like(k["b2"]))
+            zero = k["b2_zero"]
             return ops.conv1x1_split(p1, k["sw_object"], k["b2"], relu_out=not defer_relu,
                                      add=ops.conv1x1_split(s1, k["sw_shared"], zero))
         if "w2t_object" in k and ops.conv1x1_mfma_ok(p1, self.conv2.out_channels):  # the same form on the fp32 matrix pipe
-            zero = k.setdefault("b2_zero", torch.zeros_like(k["b2"]))
+            zero = k["b2_zero"]
             return ops.conv1x1_mfma(p1, k["w2t_object"], k["b2"], relu_out=not defer_relu,
                                     add=ops.conv1x1_mfma(s1, k["w2t_shared"], zero))
         y = self._pointwise(p1, k, "object", True, False)
@@ -449,7 +450,8 @@ class IntVOS(nn.Module):
         for m in self.semantic_embedding:
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
-        self._dist_mirror = {}             # seq_name -> (data_ptr of its local_map_dist table, {(frame, round): weight})
+        self._dist_mirror = {}             # seq_name -> [its local_map_dist table, its version after this module's last write,
+                                           #              {(frame, round): weight}]: _mirror_of
         self._bank_cache = OrderedDict()   # seq_name -> (identity key, ops.PreparedBank, keyed tensors): _prepared_bank
         self._frame_cache = OrderedDict()  # identity key of a [C,h,w] embedding -> ops.PreparedFrame: _prepared_frame
         self.dynamic_seghead = DynamicSegHead()  # propagation head
@@ -491,6 +493,23 @@ class IntVOS(nn.Module):
         while len(self._bank_cache) > MAX_CACHED_BANKS:
             self._bank_cache.popitem(last=False)
         return bank
+
+    def _mirror_of(self, seq_name, dist_tab):
+        """Host mirror of the weights THIS module wrote into `dist_tab` (the caller's local_map_dist_dic[seq_name]), or None
+        when the table cannot be tracked.  Valid only for the very tensor object it was made for (held here, so its address
+        cannot be recycled: test.py:121-124,313-314 drops the dicts after a session and builds fresh ones for the next session
+        on the same sequence name -- ADVICE r4: a data_ptr key took the new table for the old one) and only while the table's
+        version counter still is what this module's last write left (an external write -- zero_(), a caller's own assignment
+        -- starts the mirror afresh: the comparison then asks the device, as the reference does)."""
+        try:
+            ver = dist_tab._version
+        except RuntimeError:  # inference tensors carry no version counter
+            self._dist_mirror.pop(seq_name, None)
+            return None
+        m = self._dist_mirror.get(seq_name)
+        if m is None or m[0] is not dist_tab or m[1] != ver:
+            m = self._dist_mirror[seq_name] = [dist_tab, ver, {}]
+        return m
 
     # ---- per-frame operands (SURVEY 8f rank 4: the producer side of the path) ------------------------------------
     def _frame_key(self, emb_chw, d):
@@ -818,21 +837,23 @@ class IntVOS(nn.Module):
                 dist_tab, map_tab = local_map_dist_dic[seq_names[n]], local_map_tmp_dic[seq_names[n]]
                 # python arithmetic first, as the reference: frame == annotated frame raises ZeroDivisionError
                 weight = 1.0 / (abs(frame_num[n] - start_annotated_frame))
-                dist_tab[frame_num[n]][interaction_num - 1] = weight
-                # (host mirror of the weights this module wrote into THIS table: the comparison two lines down then needs no
+                # (host mirror of the weights this module wrote into THIS table: the comparison a few lines down then needs no
                 # device read -- in the reference it is a device-to-host synchronisation per frame from the second round on)
-                mirror = self._dist_mirror.get(seq_names[n])
-                if mirror is None or mirror[0] != dist_tab.data_ptr():
-                    mirror = self._dist_mirror[seq_names[n]] = (dist_tab.data_ptr(), {})
+                mirror = self._mirror_of(seq_names[n], dist_tab)  # (validated BEFORE this call's own write)
+                dist_tab[frame_num[n]][interaction_num - 1] = weight
                 fkey = int(frame_num[n])
-                # (as the table holds it: rounded to float32)
-                mirror[1][(fkey, interaction_num - 1)] = float(np.float32(weight)) if dist_tab.dtype == torch.float32 else None
+                if mirror is not None:
+                    mirror[1] = dist_tab._version
+                    # (as the table holds it: rounded to float32)
+                    mirror[2][(fkey, interaction_num - 1)] = float(np.float32(weight)) if dist_tab.dtype == torch.float32 else None
                 slot_ = map_tab[frame_num[n]][interaction_num - 1]
                 if prev_frame_nn_features_n.data_ptr() != slot_.data_ptr():  # (not written in place above)
                     slot_.copy_(prev_frame_nn_features_n.squeeze(0).detach())
                 newer_wins = True  # (first round: there is nothing older)
                 if interaction_num > 1:
-                    now_, before_ = mirror[1][(fkey, interaction_num - 1)], mirror[1].get((fkey, interaction_num - 2))
+                    now_ = before_ = None
+                    if mirror is not None:
+                        now_, before_ = mirror[2][(fkey, interaction_num - 1)], mirror[2].get((fkey, interaction_num - 2))
                     if now_ is not None and before_ is not None:
                         newer_wins = now_ > before_
                     else:  # a table this module did not fill (or not in this process): ask the device, as the reference does
@@ -901,7 +922,12 @@ class IntVOS(nn.Module):
                 if seq_names[n] not in local_map_tmp_dic:
                     local_map_tmp_dic[seq_names[n]] = torch.ones_like(nn_features_n).unsqueeze(0).repeat(
                         MAX_CLIP_FRAMES, MAX_INTERACTIONS, 1, 1, 1, 1)
-                local_map_dist_dic[seq_names[n]][frame_num[n]][interaction_num - 1] = 0
+                dist_tab = local_map_dist_dic[seq_names[n]]
+                mirror = self._mirror_of(seq_names[n], dist_tab)
+                dist_tab[frame_num[n]][interaction_num - 1] = 0
+                if mirror is not None:  # (this write is the module's own: the mirror follows it)
+                    mirror[1] = dist_tab._version
+                    mirror[2][(int(frame_num[n]), interaction_num - 1)] = 0.0
                 local_map_dics = (local_map_tmp_dic, local_map_dist_dic)
             # ---- head input (:741-760)
             to_cat_scribble_mask_to_cat = (seq_ref_scribble_label.float() == gt_id.float())

@@ -185,6 +185,20 @@ def global_match(reference_embeddings, query_embeddings, reference_labels, n_ids
     return out
 
 
+_PROBE_POOL = {"block": None, "next": 0}
+
+
+def _probe_slot():
+    """Two pinned int32 the adaptive probe kernel of compute="bf16r" writes through a raw pointer.  Slots of ONE pinned block
+    that lives as long as the process (a per-bank pin_memory() tensor could go back to torch's pinned allocator
+    with a device write still in flight -- the allocator knows nothing of it); handed out round robin, 1024 of them."""
+    if _PROBE_POOL["block"] is None:
+        _PROBE_POOL["block"] = torch.zeros(1024, 2, dtype=torch.int32).pin_memory()
+    i = _PROBE_POOL["next"]
+    _PROBE_POOL["next"] = (i + 1) % 1024
+    return _PROBE_POOL["block"][i]
+
+
 class PreparedBank:
     """A memory bank sorted by object id and packed for the MFMA loop, reusable across frames
     (test.py:237-259 matches every frame of a clip against the same annotated frame)."""
@@ -302,7 +316,7 @@ class PreparedBank:
             # says when it is there -- looked at by a later call, never waited for.  Every ADAPT_PROBE_EVERY-th filtered frame
             # only: a probe costs ~10 us of stream time, and what the share says changes with the clip, not with the frame.
             if ad["host"] is None:
-                ad["host"] = torch.zeros(2, dtype=torch.int32).pin_memory()
+                ad["host"] = _probe_slot()
             with _on(dev):
                 rc2 = lib.manet_global_match_refine_rescued_async(ws.data_ptr(), N, C, self.n_ids, ad["host"].data_ptr(),
                                                                   _stream_ptr(dev))
@@ -323,6 +337,7 @@ class PreparedBank:
         if self.compute != _lib.COMPUTE_BF16_REFINE or getattr(self, "_last", None) is None:
             raise RuntimeError("refine_stats: no compute='bf16r' match has run on this bank")
         ws, N = self._last
+        torch.cuda.current_stream(ws.device).synchronize()  # (the C call copies on the null stream, which torch's side streams do not block)
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)
         _lib.check(_lib.load().manet_global_match_refine_stats(ws.data_ptr(), N, self.C, self.n_ids, ctypes.byref(a),
                                                                ctypes.byref(b)), "manet_global_match_refine_stats")
@@ -337,6 +352,7 @@ class PreparedBank:
         if self.compute != _lib.COMPUTE_BF16_REFINE or getattr(self, "_last", None) is None:
             raise RuntimeError("refine_stats: no compute='bf16r' match has run on this bank")
         ws, N = self._last
+        torch.cuda.current_stream(ws.device).synchronize()  # (as refine_stats)
         s4 = (ctypes.c_int64 * 4)()
         _lib.check(_lib.load().manet_global_match_refine_stats2(ws.data_ptr(), N, self.C, self.n_ids, s4),
                    "manet_global_match_refine_stats2")

@@ -198,7 +198,8 @@ int manet_embed_finish(const float *conv_out, int64_t s_f, int64_t s_y, int64_t 
 /* MANET_COMPUTE_BF16_REFINE on a prepared bank when the query's packed image exists already (manet_frame_prepare /
  * manet_query_pack with MANET_COMPUTE_BF16 or _BF16_REFINE): the fp32 re-rank also needs the query as stored, so this entry
  * point takes both.  query_image == NULL: same as manet_global_match_prepared_ex(..., MANET_COMPUTE_BF16_REFINE, ...).
- * manet_global_match_refine_stats reads back (blocking copy -- tests / benchmarks) what the last call on `match_ws` did:
+ * manet_global_match_refine_stats reads back (blocking copy on the NULL stream -- tests / benchmarks; it does not wait for work on
+ * non-blocking streams: synchronise the stream the match ran on first, as ops.PreparedBank.refine_stats does) what the last call on `match_ws` did:
  * candidate rows the filter pass listed (+, per 32 x 32 block it listed whole, the number of (query, half pass) lanes that held
  * a qualifying row: a lower bound of that block's qualifying rows), and whether some 32-query block's candidate bucket (128 rows per pair on
  * average, 1 024 whole 32 x 32 blocks) was incomplete -- 1: the 256-query tiles of those blocks also went through the exact fp32 kernel (the bank

@@ -140,7 +140,7 @@ def test_state_dict_names_match_reference_default_model():
     assert model.semantic_embedding[3].weight is model.embedding_conv.weight
 
 
-def test_host_logic_on_cpu_with_oracle_backed_ops(monkeypatch, oracle):
+def _oracle_backed_ops(monkeypatch, oracle):
     from cvpr2020_manet_amd import ops
 
     def fake_global(reference_embeddings, query_embeddings, reference_labels, n_ids, k_nearest_neighbors=1,
@@ -170,9 +170,72 @@ def test_host_logic_on_cpu_with_oracle_backed_ops(monkeypatch, oracle):
     monkeypatch.setattr(ops, "global_match", fake_global)
     monkeypatch.setattr(ops, "local_match", fake_local)
     monkeypatch.setattr(ops, "normalize_merge_", fake_merge)
+
+
+def test_host_logic_on_cpu_with_oracle_backed_ops(monkeypatch, oracle):
+    _oracle_backed_ops(monkeypatch, oracle)
     g = load_golden("e2e_tiny")
     model = build_model(g, "cpu")
     compare(run_script(model, g, "cpu"), g, tol_logits=2e-4)
+
+
+def _session(model, embs, scribs, rounds, nobj, dist_buffer):
+    """one interactive session on a sequence as test.py:121-124,313-314 runs it: FRESH dicts, `rounds` = annotated frame per
+    round; the [104,9] weight table lives in `dist_buffer` (the caller's memory: a new tensor object at the same address)"""
+    seq, F_ = "clip", embs.shape[0]
+    dist_buffer[:] = 0
+    gmap, lmaps = {}, ({}, {seq: torch.from_numpy(dist_buffer)})
+    gt = torch.Tensor([nobj])
+    H, W = scribs[0].shape[-2:]
+    up = lambda x: torch.argmax(nn.functional.interpolate(x, size=(H, W), mode="bilinear", align_corners=True), dim=1)
+    logits, prev_round = {}, None
+    for r, start in enumerate(rounds, 1):
+        tmp, lmaps = model.int_seghead(ref_frame_embedding=embs[start:start + 1], ref_scribble_label=scribs[r - 1],
+                                       prev_round_label=prev_round, global_map_tmp_dic=gmap, local_map_dics=lmaps,
+                                       interaction_num=r, seq_names=[seq], gt_ids=gt, frame_num=[start], first_inter=r == 1)
+        prev_round = up(tmp[seq]).float().unsqueeze(0)
+        for order in (range(start + 1, F_), range(start - 1, -1, -1)):
+            prev_label, prev_emb = up(tmp[seq]).unsqueeze(0), embs[start:start + 1]
+            for ii in order:
+                out, gmap, lmaps = model.prop_seghead(embs[start:start + 1], prev_emb, embs[ii:ii + 1], scribs[r - 1], prev_label,
+                                                      seq_names=[seq], gt_ids=gt, global_map_tmp_dic=gmap, local_map_dics=lmaps,
+                                                      interaction_num=r, start_annotated_frame=start, frame_num=[ii],
+                                                      dynamic_seghead=model.dynamic_seghead)
+                logits[(r, ii)] = out[seq].clone()
+                prev_label, prev_emb = up(out[seq]).unsqueeze(0), embs[ii:ii + 1]
+    return logits, lmaps
+
+
+def test_second_session_on_a_sequence_does_not_see_the_first_sessions_weights(monkeypatch, oracle):
+    """the host mirror of local_map_dist_dic was keyed on the table's ADDRESS.  test.py drops the dicts after
+    a session and builds fresh ones for the next session on the same sequence name; the new [104,9] table often lands on the
+    freed address, the old session's weights then counted as this session's -- frame 2 in round 2 of sessions [0] -> [2, 0]
+    got the placeholder slot instead of its new local map.  Here the second session's table IS at the first one's address
+    (same caller-owned buffer, new tensor object): its results must equal those of a model that never saw the first session."""
+    _oracle_backed_ops(monkeypatch, oracle)
+    g = load_golden("e2e_tiny")
+    t = lambda a: torch.from_numpy(a)
+    scribs = [t(g["scrib"]), t(g["scrib2"])]
+    nobj = int(g["nobj"])
+    buf = np.zeros((104, 9), dtype=np.float32)
+    with torch.no_grad():
+        seen = build_model(g, "cpu")
+        embs = seen.extract_feature(t(g["imgs"]))
+        assert embs.shape[0] >= 4
+        _session(seen, embs, scribs, [0], nobj, buf)
+        got, lm = _session(seen, embs, scribs, [2, 0], nobj, buf)
+        assert lm[1]["clip"].data_ptr() == buf.ctypes.data  # (the address-reuse case, deterministically)
+        fresh = build_model(g, "cpu")
+        want, _ = _session(fresh, embs, scribs, [2, 0], nobj, np.zeros((104, 9), dtype=np.float32))
+    assert sorted(got) == sorted(want) and (2, 2) in got
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    # an external write to the table (not through the module) drops the mirror instead of trusting it
+    tab = lm[1]["clip"]
+    m = seen._mirror_of("clip", tab)
+    assert m is not None and m[2]
+    tab.zero_()
+    assert seen._mirror_of("clip", tab)[2] == {}
 
 
 def test_cpu_tensors_are_refused_by_the_product_path():
