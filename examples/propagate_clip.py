@@ -124,6 +124,47 @@ def make_scribble(dev, eh, ew, nobj):
     return scribble
 
 
+ROI_MARGIN = 20  # grid pixels (test.py:325)
+
+
+def rough_ROI(ref_scribble_labels):
+    """The first interaction round's labelling rule of the reference driver (test.py:229-230 -> test.py:323-343): inside the
+    scribbles' bounding box grown by 20 grid pixels the labels stay as they are (-1 = unlabelled), EVERYTHING outside becomes
+    background (0).  So the memory bank `prop_seghead` matches against in round 1 is the scribble strokes PLUS every pixel
+    outside the box -- thousands of rows, not the ~1 000 pixels of the strokes.  [b, 1, h, w] -> [b, 1, h, w]; the box's far
+    side is rows [.., min(h_max + 20, h - 1)) -- exclusive, so the last row / column of the grid is always outside (kept: the
+    reference's slice).  Computed on the device (row / column occupancy -> two comparisons), one host read for the
+    reference's error: a frame without any labelled pixel raises, as torch.min over an empty index list does there.
+    Pinned by tests/golden/rough_roi.npz (the reference function's own outputs)."""
+    lab = ref_scribble_labels
+    b, _, h, w = lab.shape
+    marked = (lab != -1).reshape(b, h, w)
+    if not bool(marked.flatten(1).any(1).all()):
+        raise RuntimeError("rough_ROI: a frame without labelled pixels (the reference's torch.min over an empty index list raises)")
+    rows, cols = marked.any(2), marked.any(1)  # [b, h], [b, w]
+    ih = torch.arange(h, device=lab.device).expand(b, h)
+    iw = torch.arange(w, device=lab.device).expand(b, w)
+    h_min = torch.where(rows, ih, h).amin(1, keepdim=True)
+    h_max = torch.where(rows, ih, -1).amax(1, keepdim=True)
+    w_min = torch.where(cols, iw, w).amin(1, keepdim=True)
+    w_max = torch.where(cols, iw, -1).amax(1, keepdim=True)
+    in_rows = (ih >= (h_min - ROI_MARGIN).clamp(min=0)) & (ih < (h_max + ROI_MARGIN).clamp(max=h - 1))
+    in_cols = (iw >= (w_min - ROI_MARGIN).clamp(min=0)) & (iw < (w_max + ROI_MARGIN).clamp(max=w - 1))
+    inside = (in_rows[:, :, None] & in_cols[:, None, :]).unsqueeze(1)
+    return torch.where(inside, lab, torch.zeros_like(lab))
+
+
+def full_labels(dev, eh, ew, nobj, shift=0):
+    """every pixel of the grid labelled (what a propagated mask used as an annotation would give: M = h*w rows per frame, the
+    bank's upper bound of SURVEY 8): one rectangle per object over background"""
+    lab = torch.zeros((1, 1, eh, ew), device=dev)
+    for o in range(1, nobj + 1):
+        y0 = (15 * o + 3 * shift) % max(eh - 50, 1)
+        x0 = (40 * o + 5 * shift) % max(ew - 80, 1)
+        lab[0, 0, y0:y0 + 45, x0:x0 + 70] = o
+    return lab
+
+
 class StageTimer:
     """HIP-event brackets around the ops the propagated frame is made of (one instrumented round, outside any timed
     region): per-stage microseconds per frame, each stage = the launches of one ops.* call (named by its dominant kernel)."""
@@ -179,7 +220,15 @@ _STREAM_PAIRS = {}  # device -> the two HIP streams of Clip.one_round_two_stream
 class Clip:
     """a clip's embeddings + scribble + everything one interaction round needs"""
 
-    def __init__(self, cfg, model, embedding_memory, H, W, nobj, fused_mask_step=True):
+    def __init__(self, cfg, model, embedding_memory, H, W, nobj, fused_mask_step=True, bank="roi", bank_frames=1):
+        """bank: what `prop_seghead` matches against (the interaction head always sees the raw scribble, test.py:208):
+             "scribble"  the strokes alone (~1 000 rows; no round of test.py produces this: r1-r4's workload)
+             "roi"       the strokes after the reference driver's rough_ROI (test.py:229-230): + every pixel outside the strokes'
+                         box as background -- the first interaction round's bank
+             "full"      every pixel labelled (M = h*w rows per frame: the upper bound)
+           bank_frames T: T annotated frames stacked along H (reference_embeddings [T*h, w, C], IntVOS.py:160-210 takes any
+                         h_r; TEST_MODE passes the labels through unscaled) -- T = 5 is the metric's 5-frame memory.  The
+                         annotated frames are `start` and T - 1 others spread over the clip, each with its own labels."""
         self.cfg, self.model, self.emb = cfg, model, embedding_memory
         self.F, _, self.eh, self.ew = embedding_memory.shape
         self.H, self.W, self.nobj = H, W, nobj
@@ -188,6 +237,33 @@ class Clip:
         self.scribble = make_scribble(self.dev, self.eh, self.ew, nobj)
         self.gt = torch.Tensor([nobj])
         self.fused = fused_mask_step
+        self.bank, self.bank_frames = bank, int(bank_frames)
+        if bank not in ("scribble", "roi", "full"):
+            raise ValueError("bank=%r (scribble | roi | full)" % (bank,))
+        if not 1 <= self.bank_frames <= self.F:
+            raise ValueError("bank_frames=%d for a clip of %d frames" % (self.bank_frames, self.F))
+        if self.bank_frames > 1 and not cfg.TEST_MODE:
+            raise ValueError("a stacked bank needs TEST_MODE (labels are passed through at grid resolution)")
+        # the annotated frames of the bank: `start` first, the others spread over the clip
+        others = [int(round(i * (self.F - 1) / max(self.bank_frames - 1, 1))) for i in range(self.bank_frames)]
+        frames = [self.start] + [f for f in others if f != self.start]
+        f = 0
+        while len(frames) < self.bank_frames:
+            if f not in frames:
+                frames.append(f)
+            f += 1
+        self.bank_frame_ids = frames[:self.bank_frames]
+        labs = []
+        for j, _ in enumerate(self.bank_frame_ids):
+            sc = self.scribble if j == 0 else torch.roll(self.scribble, shifts=(7 * j, 11 * j), dims=(2, 3))
+            labs.append({"scribble": lambda: sc, "roi": lambda: rough_ROI(sc),
+                         "full": lambda: full_labels(self.dev, self.eh, self.ew, nobj, shift=j)}[bank]())
+        self.bank_label = labs[0] if len(labs) == 1 else torch.cat(labs, 2)  # [1, 1, T*h, w]
+        if self.bank_frames == 1:
+            self.bank_emb = self.emb[self.start:self.start + 1]
+        else:
+            self.bank_emb = torch.cat([self.emb[f:f + 1] for f in self.bank_frame_ids], 2)  # [1, C, T*h, w]
+        self.bank_rows = int((self.bank_label != -1).sum().item())
 
     def mask_step(self, logits):
         from cvpr2020_manet_amd import ops
@@ -220,7 +296,7 @@ class Clip:
             prev_label, prev_emb = ref_label, ref
             for ii in order:
                 cur = self.emb[ii:ii + 1]
-                tmp, gmap, lmaps = model.prop_seghead(ref, prev_emb, cur, self.scribble, prev_label,
+                tmp, gmap, lmaps = model.prop_seghead(self.bank_emb, prev_emb, cur, self.bank_label, prev_label,
                                                       normalize_nearest_neighbor_distances=True,
                                                       use_local_map=True, seq_names=[SEQ], gt_ids=self.gt,
                                                       k_nearest_neighbors=cfg.KNNS, global_map_tmp_dic=gmap,
@@ -259,7 +335,7 @@ class Clip:
         if SEQ not in lmaps[1]:
             lmaps[1][SEQ] = torch.zeros(104, 9, device=self.dev)
         # ... and so does the annotated frame's memory bank (the first propagated frame would otherwise build it on ITS stream)
-        model.prepare_bank(ref, self.scribble, SEQ, self.gt)
+        model.prepare_bank(self.bank_emb, self.bank_label, SEQ, self.gt)
         # ONE pair of streams per device and process: HIP deals a process's streams to its hardware queues round-robin, and
         # two streams on one queue run in order -- the first pair a process creates sits on two queues (measured; later
         # pairs may not: the 2nd pair with 4 queues, the 4th with 8)
@@ -278,7 +354,7 @@ class Clip:
                 ii = orders[di][i]
                 with torch.cuda.stream(self._streams[di]):
                     cur = self.emb[ii:ii + 1]
-                    tmp, _, _ = model.prop_seghead(ref, state[di][1], cur, self.scribble, state[di][0],
+                    tmp, _, _ = model.prop_seghead(self.bank_emb, state[di][1], cur, self.bank_label, state[di][0],
                                                    normalize_nearest_neighbor_distances=True, use_local_map=True,
                                                    seq_names=[SEQ], gt_ids=self.gt, k_nearest_neighbors=cfg.KNNS,
                                                    global_map_tmp_dic=gmap, local_map_dics=lmaps, interaction_num=1,
@@ -312,7 +388,7 @@ class Clip:
         s_gmap = {SEQ: torch.ones(104, self.eh, self.ew, n_ids, 1, device=dev)}
 
         def frame_body():
-            tmp, _ = model.prop_seghead(ref, s_prev_emb, s_cur_emb, self.scribble, s_prev_label,
+            tmp, _ = model.prop_seghead(self.bank_emb, s_prev_emb, s_cur_emb, self.bank_label, s_prev_label,
                                         normalize_nearest_neighbor_distances=True, use_local_map=True,
                                         seq_names=[SEQ], gt_ids=self.gt, k_nearest_neighbors=cfg.KNNS,
                                         global_map_tmp_dic=s_gmap, local_map_dics=None, interaction_num=1,
@@ -359,7 +435,7 @@ def mask_digest(masks):
     return hashlib.sha256(masks.to(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16]
 
 
-def run_single(args, dev, pointwise=None, want_graph=False, want_stages=False):
+def run_single(args, dev, pointwise=None, want_graph=False, want_stages=False, bank=None, bank_frames=None):
     """one process, one GPU: eager (and graph) frames/s of the end-to-end propagated frame"""
     cfg, model = build_model(dev, args.compute, args.emb_dtype, pointwise if pointwise is not None else args.pointwise)
     with torch.no_grad():
@@ -367,10 +443,13 @@ def run_single(args, dev, pointwise=None, want_graph=False, want_stages=False):
         emb = synthetic_clip(model, dev, args.frames, args.height, args.width, args.objects, packed=not args.no_packed)
         if args.prepare_clip and not isinstance(emb, BatchedClip):
             emb = model.prepare_clip(emb)
-        clip = Clip(cfg, model, emb, args.height, args.width, args.objects, fused_mask_step=args.fused_mask_step)
+        clip = Clip(cfg, model, emb, args.height, args.width, args.objects, fused_mask_step=args.fused_mask_step,
+                    bank=bank if bank is not None else args.bank,
+                    bank_frames=bank_frames if bank_frames is not None else args.bank_frames)
         final, dt = clip.timed_round(rounds=args.rounds)
         res = {"frames": args.frames, "grid": [clip.eh, clip.ew], "objects": args.objects, "pointwise": model.pointwise,
-               "compute": model.compute, "eager_ms_per_round": dt * 1e3, "eager_frames_per_s": (args.frames - 1) / dt,
+               "compute": model.compute, "bank": clip.bank, "bank_frames": clip.bank_frames, "bank_rows": clip.bank_rows,
+               "eager_ms_per_round": dt * 1e3, "eager_frames_per_s": (args.frames - 1) / dt,
                "mask_digest": mask_digest(final)}
         if want_stages:
             with StageTimer() as st:
@@ -416,7 +495,8 @@ def run_parallel(args, dev, rank, world):
         emb = cp.all_gather_clip(mine, F_)
         torch.cuda.synchronize()
         clip_gather_ms = (time.perf_counter() - t0) * 1e3
-        clip = Clip(cfg, model, emb, args.height, args.width, args.objects, fused_mask_step=args.fused_mask_step)
+        clip = Clip(cfg, model, emb, args.height, args.width, args.objects, fused_mask_step=args.fused_mask_step,
+                    bank=args.bank, bank_frames=args.bank_frames)
         start = clip.start
         ref = emb[start:start + 1]
         my_frames = [f for f in range(s0, e0)]
@@ -431,7 +511,7 @@ def run_parallel(args, dev, rank, world):
             """this rank's block -> normalised + merged global maps; ONE collective ships every rank's to the chain rank(s)"""
             t1 = time.perf_counter()
             if my_frames:
-                rows = model.global_maps(ref, clip.scribble, emb[s0:e0], my_frames, SEQ, clip.gt)
+                rows = model.global_maps(clip.bank_emb, clip.bank_label, emb[s0:e0], my_frames, SEQ, clip.gt)
             else:
                 rows = torch.empty((0, L), dtype=torch.float32, device=dev)
             torch.cuda.synchronize()
@@ -471,7 +551,8 @@ def run_parallel(args, dev, rank, world):
         want, dt1 = clip.timed_round()
         same = bool(torch.equal(final, want))
         return {"frames": F_, "world": world, "backend": dist.get_backend(), "pointwise": model.pointwise,
-                "compute": model.compute, "parallel_ms_per_round": dt * 1e3, "parallel_frames_per_s": (F_ - 1) / dt,
+                "compute": model.compute, "bank": clip.bank, "bank_frames": clip.bank_frames, "bank_rows": clip.bank_rows,
+                "parallel_ms_per_round": dt * 1e3, "parallel_frames_per_s": (F_ - 1) / dt,
                 "single_rank_ms_per_round": dt1 * 1e3, "single_rank_frames_per_s": (F_ - 1) / dt1,
                 "masks_bit_equal_to_single_rank": same, "mask_digest": mask_digest(final),
                 "chain_ranks": list(chain_ranks),
@@ -512,6 +593,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-packed", action="store_true",
                     help="extract the embeddings through the stock module chain (bn2, relu2, cast as separate passes; frames "
                          "prepared on first use) instead of the fused embedding epilogue (extract_feature(packed=True))")
+    ap.add_argument("--bank", type=str, default="roi", choices=["scribble", "roi", "full"],
+                    help="labels of the bank prop_seghead matches against: roi = the scribble after the reference driver's "
+                         "rough_ROI (test.py:229-230: everything outside the strokes' box +-20 is background -- the default, what "
+                         "test.py's first round produces); scribble = the strokes alone (r1-r4's workload); full = every pixel")
+    ap.add_argument("--bank-frames", type=int, default=1,
+                    help="annotated frames stacked into the bank (5 = the metric's 5-frame memory)")
     ap.add_argument("--rounds", type=int, default=1, help="timed interaction rounds (after one warm-up round)")
     ap.add_argument("--two-streams", action="store_true",
                     help="also time the round with the forward and the backward half of the chain on two HIP streams")

