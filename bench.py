@@ -695,6 +695,15 @@ def e2e_block(device, args):
                                                   "mask_digest")}
         del clip
         torch.cuda.empty_cache()
+    # the same roi round with the global match through compute="bf16r" (bf16 filter + exact fp32 re-rank: the fp32 kernel's
+    # distances bit for bit, so the masks must be the f32 round's) -- at this bank size the fp32 match is half the frame
+    res, clip, final = pc.run_single(pc.parse_args(base + ["--bank", "roi", "--compute", "bf16r"]), device, pointwise="f32")
+    out["banks"]["roi_bf16r"] = {k: res[k] for k in ("bank", "bank_frames", "bank_rows", "compute", "eager_ms_per_round",
+                                                     "eager_frames_per_s", "mask_digest")}
+    out["value_bf16r_match"] = res["eager_frames_per_s"]
+    out["bf16r_match_masks_equal_f32"] = bool(res["mask_digest"] == f32["mask_digest"])
+    del clip
+    torch.cuda.empty_cache()
     out["value_scribble_bank"] = out["banks"]["scribble"]["eager_frames_per_s"]
     out["value_bank_frames_5"] = out["banks"]["roi_T5"]["eager_frames_per_s"]
     out["value_full_bank_frames_5"] = out["banks"]["full_T5"]["eager_frames_per_s"]
@@ -820,7 +829,8 @@ def compact_line(full):
     e = full.get("e2e")
     if e:
         ek = ("value", "value_graph", "value_two_streams", "value_scribble_bank", "value_bank_frames_5",
-              "value_full_bank_frames_5", "bank", "bank_rows", "masks_equal_eager_graph_two_streams")
+              "value_full_bank_frames_5", "value_bf16r_match", "bf16r_match_masks_equal_f32", "bank", "bank_rows",
+              "masks_equal_eager_graph_two_streams")
         ce = {k: e[k] for k in ek if k in e}
         w = e.get("workload") or ""
         ce["workload"] = w if len(w) <= 200 else w[:197] + "..."
