@@ -234,7 +234,14 @@ def gather_frame_rows(local_rows, num_frames, dst=0, group=None, timing=False):
     if f_local:
         slab[:f_local] = local_rows
     staged = dist.get_backend(group) == "gloo" and slab.is_cuda  # gloo has no device collectives: stage through the host
-    if timing and slab.is_cuda:
+    # RCCL: the collective runs on the backend's own stream, which this stream waits on -- two events on THIS stream bracket it
+    # on the device's clock, as in exchange_bank_and_halo (r4 took host wall time around two device syncs: it also counted
+    # the syncs' latency)
+    device_events = timing and slab.is_cuda and not staged
+    if device_events:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    elif timing and slab.is_cuda:
         torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     send = slab.cpu() if staged else slab
@@ -252,11 +259,19 @@ def gather_frame_rows(local_rows, num_frames, dst=0, group=None, timing=False):
             if b > a:
                 parts.append(bufs[r][:b - a])
         out = torch.cat(parts).to(dev)
-    if timing and slab.is_cuda:
-        torch.cuda.synchronize(dev)
+    g_ms, g_clock = None, None
+    if device_events:
+        e1.record()
+        e1.synchronize()
+        g_ms, g_clock = e0.elapsed_time(e1), "device events"
+    elif timing:
+        if slab.is_cuda:
+            torch.cuda.synchronize(dev)
+        g_ms = (time.perf_counter() - t0) * 1e3
+        g_clock = "host wall time (staged through host memory)" if slab.is_cuda else "host wall time"
     LAST_GATHER.clear()
     LAST_GATHER.update({"backend": dist.get_backend(group), "world": world, "dst": dst, "slab_bytes": int(per * L * 4),
-                        "gathered_bytes": int(world * per * L * 4), "gather_ms": (time.perf_counter() - t0) * 1e3 if timing else None})
+                        "gathered_bytes": int(world * per * L * 4), "gather_ms": g_ms, "gather_clock": g_clock})
     return out
 
 

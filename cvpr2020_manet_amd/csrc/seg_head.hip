@@ -40,8 +40,9 @@ constexpr int DW_IMG = DW_NP * DW_LW * 2;    // floats per interleaved image
 // are issued before the current item's arithmetic and land under it, the weights are read once.  (One workgroup per
 // (tile, plane), as before: every workgroup of a launch read, then computed, then wrote, in step with its neighbours -- the
 // memory system saw alternating read and write bursts: 53 us for 158 MB at [3,256,120,214].)
+// (the 4-byte-load form of odd widths needs ~148 registers: three workgroups per CU -- at four it spilled 20 of them, r4)
 template <bool FAST, int ABL = 0>
-__global__ __launch_bounds__(256, 4) void dwconv7x7_bn_relu_kernel(const float *__restrict__ in, int B, int C, int h, int w,
+__global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(const float *__restrict__ in, int B, int C, int h, int w,
                                                                    const float *__restrict__ weight,
                                                                    const float *__restrict__ bias,
                                                                    const float *__restrict__ scale,
@@ -702,13 +703,23 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
     const int co0 = half * 128 + wave * 32;
     if (tid < 128) bsh[tid] = b2[half * 128 + tid];
     // A operand: lane (co = l31, kk) holds w[2 s + kk][co0 + co] for every k-step s (zero past Cin)
-    float a[RW_KMAX / 2];
-#pragma unroll
-    for (int s = 0; s < RW_KMAX / 2; ++s) {
-        const int k = 2 * s + kk;
-        a[s] = k < Cin ? w2t[(long)k * PW_CO + co0 + l31] : 0.0f;
-    }
     const int nch = (Cin + RW_KC - 1) / RW_KC;  // (Cin % 32 == 0: checked by the launcher)
+    // (Cin is a whole number of 32-channel stages: ONE uniform branch per stage around 16 plain loads -- r4 predicated every one of
+    // the 128 loads on k < Cin: 128 exec-mask branches in the prologue of each of the 512 workgroups, ~5 us of a launch)
+    float a[RW_KMAX / 2];
+    {
+        const float *wl = w2t + (long)kk * PW_CO + co0 + l31;
+#pragma unroll
+        for (int g = 0; g < RW_KMAX / RW_KC; ++g) {
+            if (g < nch) {
+#pragma unroll
+                for (int s = 0; s < RW_KC / 2; ++s) a[g * (RW_KC / 2) + s] = wl[(long)(g * RW_KC + 2 * s) * PW_CO];
+            } else {
+#pragma unroll
+                for (int s = 0; s < RW_KC / 2; ++s) a[g * (RW_KC / 2) + s] = 0.0f;
+            }
+        }
+    }
     const unsigned xbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&xbuf[0][0]);
     // step = (tile, chunk); step number n lives in ring slot n % RW_NB.  All of a step's address arithmetic is SCALAR (the
     // tile / chunk counters advance incrementally: no division, no per-lane 64-bit multiply): a lane contributes one 32-bit
@@ -766,13 +777,8 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
     int st = 0;  // step number of (t, c); its stage was read into F during step st - 1, step st reads stage st + 1
     int cur_b = b0, cur_p = t0 - b0 * tpp;
     for (int t = t0; t < t1; ++t) {
-        f32x16 acc[2][2];  // [pixel block][k-step parity]
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
+        f32x16 acc[2][2];  // [pixel block][k-step parity]; a tile's first four MFMAs take C = 0 (no zeroing pass)
+        const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int c = 0; c < RW_KMAX / RW_KC; ++c) {
             if (c < nch) {  // (uniform)
@@ -781,10 +787,11 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
 #pragma unroll
                 for (int s = 0; s < RW_KC / 2; s += 2) {
                     const int ks = c * (RW_KC / 2) + s, f = s % FH;
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], F0[f], acc[0][0], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], F1[f], acc[1][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks + 1], F0[f + 1], acc[0][1], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks + 1], F1[f + 1], acc[1][1], 0, 0, 0);
+                    const bool first = c == 0 && s == 0;  // (compile-time: both loops are unrolled)
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], F0[f], first ? zero16 : acc[0][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], F1[f], first ? zero16 : acc[1][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks + 1], F0[f + 1], first ? zero16 : acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks + 1], F1[f + 1], first ? zero16 : acc[1][1], 0, 0, 0);
                     if (!(abl & 8)) {
                         // k-steps s, s + 1 of this step's second half (s < FH), or of the next stage's first half (a stale
                         // read behind the last step)
@@ -824,8 +831,12 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
                 cur_p = 0;
                 ++cur_b;
             }
-            // stores count in vmcnt too and return out of order with loads: drain them before the next counted wait
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // No drain of the stores here (r5).  vmcnt counts loads and stores alike and the two kinds may complete out of order
+            // with respect to EACH OTHER, but loads complete in issue order among themselves: a counted wait "at most n
+            // outstanding" behind n younger DMA pieces still implies the older piece has landed (were it outstanding, so would
+            // be its n younger ones: n + 1) -- outstanding stores only make the wait conservative.  r4 drained the 16 stores with
+            // vmcnt(0) at the end of every tile: both waves of a SIMD reach that point together (all workgroups run in step), so
+            // the matrix pipe idled for a store round trip per tile: 101.4 -> 96.6 us at [3,256,120,214].
         }
     }
 }

@@ -67,6 +67,29 @@ def test_two_rank_strong_scaling_flow_on_one_gpu():
     assert line["collective"]["world"] == 2
 
 
+@pytest.mark.gpu
+def test_eight_rank_configs3_partition_on_one_gpu():
+    """BASELINE configs[3] at its real shape: a 64-frame 480p clip sharded 8 frames per rank over 8 ranks --
+    sharing the one GPU here, the collective over gloo; on an 8-GPU node the same command runs over RCCL -- 5-frame bank dealt
+    round robin (one slot per rank), ONE all-gather in the timed region"""
+    env = dict(os.environ, MANET_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--scaling", "strong", "--cfg", "2",
+                        "--no-cpu-baseline", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    import json
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["value"] > 0 and line["steps"] == 8
+    assert line["config"]["clip_frames"] == 64 and line["config"]["frames_per_gpu"] == 8
+    col = line["collective"]
+    assert col["world"] == 8 and col["backend"] == "gloo" and col["ownership"] == "round_robin"
+    assert col["bank_slots_per_rank"] == 1 and col["gathered_bytes"] == 8 * col["slab_bytes"]
+    # slab = one bank slot (embedding + labels) + the halo frame, fp32 at the 480p grid
+    assert col["slab_bytes"] == 4 * (100 * 120 * 214 + 120 * 214) + 4 * 100 * 120 * 214
+    assert len(r.stdout.strip().splitlines()[-1]) < 4096
+
+
 def test_mismatched_world_size_is_an_error():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env,
@@ -82,7 +105,7 @@ def _run_json(cmd, env, timeout=900):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,frames", [(2, 9), (3, 5)])
+@pytest.mark.parametrize("world,frames", [(2, 9), (3, 5), (8, 64), (8, 5)])
 def test_clip_parallel_propagation_masks_bit_equal_to_one_rank(world, frames):
     """the multi-GPU split that speeds up what test.py does.  N ranks (sharing the one GPU here, gloo)
     extract the embeddings of their frame blocks (one all-gather assembles the clip), compute the normalised + merged global

@@ -101,7 +101,13 @@ def _worker(rank, world, port, F, bank_frames, q, bf16=False, ownership="block")
     (2, 8, [0, 2, 5, 6, 7], True, "block"),
     (3, 2, [0, 1], True, "block"),         # world > frames with 2-byte storage: the empty rank must size its slab alike
     (2, 8, [0, 1, 2, 3, 7], False, "round_robin"),  # clustered annotations: slab stays ceil(T / world) slots
-    (3, 9, [4, 5], True, "round_robin")])
+    (3, 9, [4, 5], True, "round_robin"),
+    # BASELINE configs[3]'s partition at its real shape (world sizes above 3 had never run anywhere): 64 frames,
+    # 8 per rank, a 5-frame bank spread over the clip -- one slot per rank either way; and the bank clustered in one block
+    (8, 64, [0, 16, 32, 48, 63], False, "block"), (8, 64, [0, 16, 32, 48, 63], True, "round_robin"),
+    (8, 64, [8, 9, 10, 11, 12], False, "round_robin"),
+    # ... and a clip shorter than the node is wide: three ranks own no frame (empty blocks, halo from the last rank that has one)
+    (8, 5, [0, 2, 4], False, "block"), (8, 5, [0, 1, 2, 3, 4], True, "round_robin")])
 def test_exchange_bank_and_halo_gloo(world, F, bank, bf16, ownership):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -110,7 +116,7 @@ def test_exchange_bank_and_halo_gloo(world, F, bank, bf16, ownership):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(300)
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(world))
     assert res == [(r, True) for r in range(world)]
@@ -159,7 +165,7 @@ def _worker_gather(rank, world, port, F, bf16, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,F,bf16", [(2, 8, False), (3, 7, True), (3, 2, False)])
+@pytest.mark.parametrize("world,F,bf16", [(2, 8, False), (3, 7, True), (3, 2, False), (8, 64, False), (8, 5, True)])
 def test_all_gather_clip_and_gather_frame_rows_gloo(world, F, bf16):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -168,7 +174,7 @@ def test_all_gather_clip_and_gather_frame_rows_gloo(world, F, bf16):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(300)
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(world))
     assert res == [(r, True) for r in range(world)]

@@ -406,3 +406,4 @@ def test_three_piece_split_pointwise_is_fp32_class():
         d3, d2 = float((outs["split3"] - outs["f32"]).abs().max()), float((outs["split"] - outs["f32"]).abs().max())
         print("head logits vs the fp32 head: three-piece %.3g, two-piece %.3g (scale %.3g)" % (d3, d2, scale))
         assert d3 <= 2e-6 * max(scale, 1.0) and d3 < d2
+
