@@ -8,6 +8,7 @@ pointers, so the backward is explicit:
                   gradient to ONE bank row per (query pixel, object) -- the forward kernel records it
                   (manet_global_match_arg_f32), the backward is a gather / scatter-add
                   (manet_global_match_backward_f32).
+  GlobalMatchTopkFn  the same with k > 1 (IntVOS.py:87-94): k exact arg-min passes, a gather / scatter-add per rank.
   LocalMatchFn    local_previous_frame_nearest_neighbor_features_per_object, downsample on (:345-434): the
                   forward records the winning window offset and keeps the normalised pooled volume; the
                   backward walks min -> where -> bilinear -> sigmoid -> (x - y)^2 -> avg_pool2d in reverse.
@@ -89,6 +90,78 @@ class GlobalMatchFn(torch.autograd.Function):
                                                      1 if (gr is None or M0 == 0) else gr.stride(1), _stream_ptr(dev))
         _lib.check(rc, "manet_global_match_backward_f32")
         return gr, gq, None, None
+
+
+class GlobalMatchTopkFn(torch.autograd.Function):
+    """nearest_neighbor_features_per_object with k_nearest_neighbors > 1 (reference IntVOS.py:87-94): out [N, n_ids] =
+    mean of the k smallest distances per (query, object), entries past the object's row count replaced by the farthest real
+    neighbour.  The reference gets the gradient from autograd through topk -> where -> max -> mean: each real neighbour of rank
+    j receives g / k, and the farthest real one additionally the share of every replaced entry ((k - v) g / k with v real
+    neighbours; nothing at all when the object has no row: `dists * valid` multiplies the padding by zero).  Forward:
+    manet_global_match_topk_arg_f32 (k exact passes of the arg-min kernel); backward: one gather / scatter-add launch per rank."""
+
+    @staticmethod
+    def forward(ctx, ref, qry, labels, n_ids, k):
+        lib = _lib.load()
+        M0, C = ref.shape
+        N = qry.shape[0]
+        dev = qry.device
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(lib.manet_global_match_topk_arg_workspace_bytes(N, M0, C, n_ids, ctypes.byref(nbytes)),
+                   "manet_global_match_topk_arg_workspace_bytes")
+        ws = _scratch(dev, nbytes.value)
+        d = torch.empty((k, N, n_ids), dtype=torch.float32, device=dev)
+        arg = torch.empty((k, N, n_ids), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.manet_global_match_topk_arg_f32(qry.data_ptr(), qry.stride(0), qry.stride(1), ref.data_ptr(),
+                                                     ref.stride(0) if M0 > 0 else C, ref.stride(1) if M0 > 0 else 1,
+                                                     labels.data_ptr(), N, M0, C, n_ids, k, d.data_ptr(), arg.data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "manet_global_match_topk_arg_f32")
+        # IntVOS.py:88-94 on the k sorted distances (rank along dim 0)
+        valid = d < 1e20
+        masked = d * valid.float()
+        pad, jstar = masked.max(dim=0, keepdim=True)
+        out = torch.where(valid, d, pad.expand_as(d)).mean(dim=0)
+        # per-rank weights of the incoming gradient: 1/k for a real neighbour, + (k - v)/k on the rank the padding came from
+        # (times that rank's own validity: with no real neighbour the padding is 0 * d -- no gradient)
+        nvalid = valid.sum(dim=0, keepdim=True)
+        wgt = valid.float() / k
+        extra = (k - nvalid).float() / k
+        wgt.scatter_add_(0, jstar, extra * torch.gather(valid.float(), 0, jstar))
+        arg = torch.where(valid, arg, torch.full_like(arg, -1))
+        ctx.save_for_backward(ref, qry, arg, wgt)
+        ctx.n_ids, ctx.k = n_ids, k
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        ref, qry, arg, wgt = ctx.saved_tensors
+        M0, C = ref.shape
+        N = qry.shape[0]
+        dev = qry.device
+        need_ref, need_qry = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_ref or need_qry):
+            return None, None, None, None, None
+        g = grad_out.contiguous().float()
+        gq_sum = gr_sum = None
+        for j in range(ctx.k):
+            gj = (g * wgt[j]).contiguous()
+            gq = torch.empty((N, C), dtype=torch.float32, device=dev) if need_qry else None
+            gr = torch.empty((M0, C), dtype=torch.float32, device=dev) if need_ref else None
+            with torch.cuda.device(dev):
+                rc = lib.manet_global_match_backward_f32(qry.data_ptr(), qry.stride(0), qry.stride(1), ref.data_ptr(),
+                                                         ref.stride(0) if M0 > 0 else C, ref.stride(1) if M0 > 0 else 1,
+                                                         arg[j].data_ptr(), gj.data_ptr(), N, M0, C, ctx.n_ids,
+                                                         None if gq is None else gq.data_ptr(), C, 1,
+                                                         None if gr is None else gr.data_ptr(), C, 1, _stream_ptr(dev))
+            _lib.check(rc, "manet_global_match_backward_f32")
+            if need_qry:
+                gq_sum = gq if gq_sum is None else gq_sum.add_(gq)
+            if need_ref:
+                gr_sum = gr if gr_sum is None else gr_sum.add_(gr)
+        return gr_sum, gq_sum, None, None, None
 
 
 def _dense(t):

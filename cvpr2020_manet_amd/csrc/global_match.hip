@@ -995,8 +995,11 @@ __device__ __forceinline__ void topk_insert(float (&m)[K], float d)
 //          in `keys64` -- equal distances resolve to the smallest slot, i.e. the first row in the sorted bank.
 // (KS = 64 -- C in 105..128 -- with the top-k lists or the arg-min slots does not fit 256 VGPRs: those two forms take one
 // workgroup per CU instead of spilling)
-template <int KS, int KNN, bool ARG = false>
-__global__ __launch_bounds__(256, (KS == 64 && (KNN > 1 || ARG)) ? 1 : 2) void global_match_f32_kernel(const char *__restrict__ qpack,
+// NTH (with ARG, r5 -- the training path of k_nearest_neighbors > 1, IntVOS.py:87-94): the minimum is taken over the (distance
+//          key, bank slot) pairs STRICTLY ABOVE a per-(object, query) bound -- `keys` then points at the previous pass's 64-bit
+//          pairs -- so pass j of k yields the j-th nearest row and its slot, exactly, ties ordered by slot.
+template <int KS, int KNN, bool ARG = false, bool NTH = false>
+__global__ __launch_bounds__(256, ((KS == 64 && (KNN > 1 || ARG)) || NTH) ? 1 : 2) void global_match_f32_kernel(const char *__restrict__ qpack,
                                                                   const char *__restrict__ bpack,
                                                                   const int *__restrict__ meta,
                                                                   int n_ids, int nQT, int S,
@@ -1005,7 +1008,9 @@ __global__ __launch_bounds__(256, (KS == 64 && (KNN > 1 || ARG)) ? 1 : 2) void g
                                                                   float *__restrict__ topk, int block_map)
 {
     static_assert(!ARG || KNN == 1, "arg-min tracking is the k = 1 path");
+    static_assert(!NTH || ARG, "the bounded form is a variant of the arg-min form");
     unsigned long long *keys64 = (unsigned long long *)topk;  // ARG: the top-k region holds the 64-bit pairs
+    const unsigned long long *bound64 = (const unsigned long long *)keys;  // NTH: the previous pass's pairs
     constexpr int NG = (KS + 3) / 4;
     constexpr size_t TILE_BYTES = bank_tile_bytes(NG);
     constexpr size_t QBLK_BYTES = query_block_bytes(NG);
@@ -1070,17 +1075,30 @@ __global__ __launch_bounds__(256, (KS == 64 && (KNN > 1 || ARG)) ? 1 : 2) void g
     int seg_end = meta[META_SEG + o + 1];
     float m0[KNN], m1[KNN];
     int a0 = -1, a1 = -1;  // ARG: bank slot (without the lane's +4h) of the running minimum, -1 = none yet
+    unsigned long long B0 = ~0ull, B1 = ~0ull, lo0 = 0, lo1 = 0;  // NTH: running minimum pairs, and the bounds they must exceed
     auto reset = [&]() {
 #pragma unroll
         for (int j = 0; j < KNN; ++j) m0[j] = m1[j] = (KNN == 1) ? MANET_WRONG_LABEL_PADDING_DISTANCE : INFINITY;
         a0 = a1 = -1;
+        B0 = B1 = ~0ull;
+    };
+    auto load_bounds = [&](int obj) {
+        if (NTH) {
+            lo0 = bound64[(size_t)obj * N_pad + qbase];
+            lo1 = bound64[(size_t)obj * N_pad + qbase + 32];
+        }
     };
     reset();
+    load_bounds(o);
 
     auto flush = [&](int obj) {
         if (ARG) {
             unsigned long long k0 = ((unsigned long long)key_of(m0[0]) << 32) | (unsigned)(a0 < 0 ? -1 : a0 + 4 * h);
             unsigned long long k1 = ((unsigned long long)key_of(m1[0]) << 32) | (unsigned)(a1 < 0 ? -1 : a1 + 4 * h);
+            if (NTH) {
+                k0 = B0;
+                k1 = B1;
+            }
             const unsigned long long o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32);
             k0 = k0 < o0 ? k0 : o0;
             k1 = k1 < o1 ? k1 : o1;
@@ -1133,6 +1151,7 @@ __global__ __launch_bounds__(256, (KS == 64 && (KNN > 1 || ARG)) ? 1 : 2) void g
             flush(o);
             reset();
             do { ++o; seg_end = meta[META_SEG + o + 1]; } while (t >= seg_end);
+            load_bounds(o);
         }
         const char *tb = smem + (size_t)buf * TILE_BYTES;
         const f32x4 *A = (const f32x4 *)tb;
@@ -1164,7 +1183,17 @@ __global__ __launch_bounds__(256, (KS == 64 && (KNN > 1 || ARG)) ? 1 : 2) void g
                 const float d01 = fmaf(-2.0f, c01[r], xs1 + y0[i]);
                 const float d10 = fmaf(-2.0f, c10[r], xs0 + y1[i]);
                 const float d11 = fmaf(-2.0f, c11[r], xs1 + y1[i]);
-                if (ARG) {  // strict <: the first row in bank order wins a tie; a NaN never wins
+                if (NTH) {  // the smallest (distance key, slot) pair above the bound; a NaN (key 0) never qualifies
+                    const unsigned slot = (unsigned)(t * BT + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    const unsigned long long k00 = ((unsigned long long)key_of(d00) << 32) | slot;
+                    const unsigned long long k10 = ((unsigned long long)key_of(d10) << 32) | (slot + 32u);
+                    const unsigned long long k01 = ((unsigned long long)key_of(d01) << 32) | slot;
+                    const unsigned long long k11 = ((unsigned long long)key_of(d11) << 32) | (slot + 32u);
+                    if (k00 > lo0 && k00 < B0) B0 = k00;
+                    if (k10 > lo0 && k10 < B0) B0 = k10;
+                    if (k01 > lo1 && k01 < B1) B1 = k01;
+                    if (k11 > lo1 && k11 < B1) B1 = k11;
+                } else if (ARG) {  // strict <: the first row in bank order wins a tie; a NaN never wins
                     const int slot = t * BT + (r & 3) + 8 * (r >> 2);
                     if (d00 < m0[0]) { m0[0] = d00; a0 = slot; }
                     if (d10 < m0[0]) { m0[0] = d10; a0 = slot + 32; }
@@ -2807,16 +2836,16 @@ int block_map_arg(int nQT, int slots, int S = 0)
     return (bm & 0xff) | (small_S << 8);
 }
 
-template <int KS, int KNN, bool ARG = false>
+template <int KS, int KNN, bool ARG = false, bool NTH = false>
 void launch_main_f32(const char *qpack, const char *bpack, const int *meta, int n_ids, int nQT, int S,
                      long N_pad, unsigned *keys, float *topk, hipStream_t st)
 {
     size_t lds = 2 * bank_tile_bytes((KS + 3) / 4);
     // per call (cheap, host side): the attribute is per device and the library keeps no state
-    (void)hipFuncSetAttribute((const void *)global_match_f32_kernel<KS, KNN, ARG>,
+    (void)hipFuncSetAttribute((const void *)global_match_f32_kernel<KS, KNN, ARG, NTH>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     manet_profile_record(st, true);
-    hipLaunchKernelGGL((global_match_f32_kernel<KS, KNN, ARG>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack,
+    hipLaunchKernelGGL((global_match_f32_kernel<KS, KNN, ARG, NTH>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack,
                        bpack, meta, n_ids, nQT, S, N_pad, keys, topk, block_map_arg(nQT, 512, S));
     manet_profile_record(st, false);
 }
@@ -3512,6 +3541,65 @@ int manet_global_match_arg_f32(const float *query, int64_t q_stride_n, int64_t q
                        (const unsigned long long *)keys64, (const int *)(bws + BL.off_src), meta, (long)N, ML.N_pad, n_ids,
                        out, arg_out);
     return manet_check_launch("manet_global_match_arg_f32");
+}
+
+/* k_nn nearest rows per (query, object), with their row numbers: the forward of the TRAINING path of k_nearest_neighbors > 1
+ * (IntVOS.py:87-94; manet_hip.h).  k_nn passes of the arg-min kernel, pass j bounded from below by pass j - 1's (distance key,
+ * slot) pair: exact, ascending, ties ordered by bank slot.  out / arg_out: [k_nn][N][n_ids]; beyond an object's row count the
+ * distance is the padding value 1e20 and the row -1. */
+int manet_global_match_topk_arg_workspace_bytes(int64_t N, int64_t M0, int C, int n_ids, size_t *bytes)
+{
+    if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
+    int rc = check_common(N, M0, C, n_ids, 1, MANET_COMPUTE_F32);
+    if (rc) return rc;
+    MatchLayout ML = match_layout(N, C, n_ids, MANET_COMPUTE_F32, 1, true);
+    *bytes = bank_layout(M0, C, n_ids, MANET_COMPUTE_F32).total + ML.total +
+             manet_align_up((size_t)n_ids * ML.N_pad * sizeof(unsigned long long), 1024);
+    return MANET_OK;
+}
+
+int manet_global_match_topk_arg_f32(const float *query, int64_t q_stride_n, int64_t q_stride_c, const float *bank,
+                                    int64_t b_stride_m, int64_t b_stride_c, const int32_t *labels, int64_t N, int64_t M0,
+                                    int C, int n_ids, int k_nn, float *out, int32_t *arg_out, void *workspace,
+                                    size_t workspace_bytes, manet_stream_t stream)
+{
+    const int compute = MANET_COMPUTE_F32;
+    int rc = check_common(N, M0, C, n_ids, k_nn, compute);
+    if (rc) return rc;
+    if (!query || !out || !arg_out || !workspace) return manet_set_error(MANET_E_INVALID, "null pointer");
+    BankLayout BL = bank_layout(M0, C, n_ids, compute);
+    MatchLayout ML = match_layout(N, C, n_ids, compute, 1, true);
+    const size_t kbytes = manet_align_up((size_t)n_ids * ML.N_pad * sizeof(unsigned long long), 1024);
+    if (workspace_bytes < BL.total + ML.total + kbytes)
+        return manet_set_error(MANET_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, BL.total + ML.total + kbytes);
+    char *bws = (char *)workspace, *mws = bws + BL.total;
+    rc = manet_bank_prepare(bank, b_stride_m, b_stride_c, labels, M0, C, n_ids, compute, bws, BL.total, stream);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int *meta = (const int *)(bws + BL.off_meta);
+    unsigned long long *kbuf[2] = {(unsigned long long *)(mws + ML.off_topk), (unsigned long long *)(mws + ML.total)};
+    rc = launch_query_pack(query, MANET_EMB_F32, (long)q_stride_n, (long)q_stride_c, (long)N, ML.N_pad, C, ML.G,
+                           mws + ML.off_q, nullptr, 0, st);
+    if (rc) return rc;
+    int S = pick_splits(ML.nQT, BL.T_max, 512);
+    tl_bank_bytes_hint = (double)BL.T_max * (double)BL.tile_bytes;  // (block_map_arg)
+    const char *qpack = mws + ML.off_q, *bpack = bws + BL.off_pack;
+    const long total = (long)N * n_ids;
+    for (int j = 0; j < k_nn; ++j) {
+        unsigned long long *cur = kbuf[j & 1], *prev = kbuf[(j & 1) ^ 1];
+        fill32(cur, 0xffffffffu, (size_t)2 * n_ids * ML.N_pad, st);
+        if (j == 0) fill32(prev, 0u, (size_t)2 * n_ids * ML.N_pad, st);  // bound 0: every real pair qualifies
+        switch (pick_ks(C)) {
+        case 16: launch_main_f32<16, 1, true, true>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, (unsigned *)prev, (float *)cur, st); break;
+        case 50: launch_main_f32<50, 1, true, true>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, (unsigned *)prev, (float *)cur, st); break;
+        case 52: launch_main_f32<52, 1, true, true>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, (unsigned *)prev, (float *)cur, st); break;
+        default: launch_main_f32<64, 1, true, true>(qpack, bpack, meta, n_ids, ML.nQT, S, ML.N_pad, (unsigned *)prev, (float *)cur, st); break;
+        }
+        hipLaunchKernelGGL(global_finish_arg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           (const unsigned long long *)cur, (const int *)(bws + BL.off_src), meta, (long)N, ML.N_pad, n_ids,
+                           out + (size_t)j * total, arg_out + (size_t)j * total);
+    }
+    return manet_check_launch("manet_global_match_topk_arg_f32");
 }
 
 int manet_global_match_backward_f32(const float *query, int64_t q_stride_n, int64_t q_stride_c, const float *bank,

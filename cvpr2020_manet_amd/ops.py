@@ -51,10 +51,10 @@ def _global_match_autograd(reference_embeddings, query_embeddings, reference_lab
     """Training route of global_match (train_stage1.py:126-156 back-propagates through it): the arg-min forward +
     explicit backward of autograd.GlobalMatchFn; normalisation (IntVOS.py:611-612) and the min-merge with the
     stored map (:620-622, the stored copy detached as in the reference) are ordinary differentiable torch ops."""
-    from .autograd import GlobalMatchFn
-    if k_nearest_neighbors != 1 or COMPUTE[compute] != _lib.COMPUTE_F32:
-        raise RuntimeError("cvpr2020_manet_amd.ops.global_match: the backward exists for k_nearest_neighbors=1, "
-                           "compute='f32' only (got k=%d, compute=%r)" % (k_nearest_neighbors, compute))
+    from .autograd import GlobalMatchFn, GlobalMatchTopkFn
+    if COMPUTE[compute] != _lib.COMPUTE_F32 or not 1 <= k_nearest_neighbors <= 8:
+        raise RuntimeError("cvpr2020_manet_amd.ops.global_match: the backward exists for compute='f32' and "
+                           "k_nearest_neighbors 1..8 only (got k=%d, compute=%r)" % (k_nearest_neighbors, compute))
     ref, M0, C = _flat(reference_embeddings, "reference_embeddings")
     qry, N, C2 = _flat(query_embeddings, "query_embeddings")
     if C != C2:
@@ -63,7 +63,12 @@ def _global_match_autograd(reference_embeddings, query_embeddings, reference_lab
     if lab.numel() != M0:
         raise ValueError("reference_labels has %d entries for %d reference pixels" % (lab.numel(), M0))
     ref, qry = ref.float(), qry.float()  # (a differentiable widening if the embeddings are stored in bf16)
-    out, _ = GlobalMatchFn.apply(ref, qry, lab, n_ids)
+    if k_nearest_neighbors > 1:
+        if M0 < k_nearest_neighbors:
+            raise RuntimeError("selected index k out of range")  # what torch.topk raises (IntVOS.py:87)
+        out = GlobalMatchTopkFn.apply(ref, qry, lab, n_ids, int(k_nearest_neighbors))
+    else:
+        out, _ = GlobalMatchFn.apply(ref, qry, lab, n_ids)
     if normalize:
         out = (torch.sigmoid(out) - 0.5) * 2
     if mem is not None:

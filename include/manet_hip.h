@@ -417,6 +417,20 @@ int manet_global_match_backward_f32(const float *query, int64_t q_stride_n, int6
                                     int64_t gq_stride_c, float *grad_bank, int64_t gb_stride_m,
                                     int64_t gb_stride_c, manet_stream_t stream);
 
+/* Training with k_nearest_neighbors > 1 (r5; IntVOS.py:87-94: topk(-d, k) per (query, object), entries past the object's row
+ * count (>= 1e20) replaced by the farthest real neighbour, mean -- autograd sends 1/k of the gradient to each selected row and
+ * the replaced entries' share to the farthest real one).  manet_global_match_topk_arg_f32 returns the k_nn smallest distances
+ * per (query, object) in ascending order WITH their rows: out / arg_out [k_nn][N][n_ids]; beyond an object's row count the
+ * distance is 1e20 and the row -1.  k_nn passes of the arg-min kernel, pass j bounded from below by pass j - 1's (distance,
+ * bank slot) pair: exact; equal distances are ordered by their position in the object-sorted bank.  The backward is k_nn calls
+ * of manet_global_match_backward_f32 (one per rank j, with that rank's rows and weights; cvpr2020_manet_amd/autograd.py). */
+int manet_global_match_topk_arg_workspace_bytes(int64_t N, int64_t M0, int C, int n_ids, size_t *bytes);
+int manet_global_match_topk_arg_f32(const float *query, int64_t q_stride_n, int64_t q_stride_c,
+                                    const float *bank, int64_t b_stride_m, int64_t b_stride_c,
+                                    const int32_t *labels, int64_t N, int64_t M0, int C, int n_ids, int k_nn,
+                                    float *out, int32_t *arg_out, void *workspace, size_t workspace_bytes,
+                                    manet_stream_t stream);
+
 /* manet_local_match_arg_f32: manet_local_match_f32 (downsample on) that also returns
  *   arg_out [h][w][n_ids] int32 = the window offset l = dy*(2d+1)+dx whose masked value is the minimum
  *   (first offset on ties), -1 when the constant 1.0 of IntVOS.py:429-430 wins, and keeps

@@ -382,6 +382,33 @@ def variant_grad():
     save("grad_tiny", **out, **sd0)
 
 
+def variant_grad_knn():
+    """the gradients the reference's autograd gives through the k > 1 branch of the global match
+    (IntVOS.py:87-94: topk -> where(valid, d, farthest real neighbour) -> mean), TRAINING configuration (TEST_MODE False).
+    Labels include an object with FEWER than k pixels (the padding rule carries gradient) and one with none (all padding:
+    `dists * valid` kills the gradient)."""
+    torch, R = import_reference(["--TEST_MODE", "False"])
+    g = torch.Generator().manual_seed(20200701)
+    out = {}
+    for i, (C, h, w, k, n_obj) in enumerate([(16, 9, 11, 3, 4), (100, 6, 7, 5, 2), (8, 5, 6, 2, 3)]):
+        ref = emb(torch, g, C, h, w).requires_grad_(True)
+        qry = emb(torch, g, C, h + 1, w + 2).requires_grad_(True)  # query grid differs from the bank's
+        lab = torch.randint(0, 2, (h, w, 1), generator=g).int()   # ids 0 / 1 plentiful
+        lab[0, 0, 0], lab[1, 2, 0] = 2, 2                         # id 2: two pixels only (< k for k = 3, 5; = k for k = 2)
+        if n_obj >= 4:
+            lab[2, 3, 0] = 3                                      # id 3: one pixel; id 4 (n_obj = 4): none
+        o, ids = R.nearest_neighbor_features_per_object(ref.permute(1, 2, 0), qry.permute(1, 2, 0), lab, k,
+                                                        gt_ids=torch.tensor(float(n_obj)), n_chunks=3)
+        wgt = torch.randn(o.shape, generator=g)
+        norm = (torch.sigmoid(o) - 0.5) * 2
+        g_ref, g_qry = torch.autograd.grad((norm * wgt).sum(), [ref, qry])
+        out.update({"c%d_ref_chw" % i: ref.detach(), "c%d_qry_chw" % i: qry.detach(), "c%d_labels" % i: lab, "c%d_k" % i: k,
+                    "c%d_n_obj" % i: n_obj, "c%d_weight" % i: wgt, "c%d_out" % i: o.detach(), "c%d_grad_ref" % i: g_ref,
+                    "c%d_grad_qry" % i: g_qry})
+    out["n_cases"] = 3
+    save("grad_knn", **out)
+
+
 def variant_rough_roi():
     """The caller-side labelling rule of the first interaction round (test.py:229-230 -> rough_ROI, test.py:323-343): what the
     bank `prop_seghead` matches against really holds.  test.py itself cannot be imported here (davisinteractive, cv2, ... at
@@ -442,6 +469,7 @@ VARIANTS = {
     "config": variant_config,
     "grad": variant_grad,
     "rough_roi": variant_rough_roi,
+    "grad_knn": variant_grad_knn,
 }
 
 if __name__ == "__main__":

@@ -159,6 +159,71 @@ def test_correlation_backward_vs_torch_autograd(ops, cfgc):
     torch.testing.assert_close(gb, rb, rtol=1e-4, atol=1e-6)
 
 
+def test_global_match_knn_gradients_match_reference_autograd(ops):
+    """k_nearest_neighbors > 1 in training (IntVOS.py:87-94).  tests/golden/grad_knn.npz = the reference's
+    own autograd through topk -> where(valid, d, farthest real neighbour) -> mean (oracle/gen_golden.py:variant_grad_knn), on
+    banks with an object of fewer than k pixels (the padding rule carries gradient to the farthest real one), an object with
+    one pixel and one with none (no gradient)."""
+    g = load_golden("grad_knn")
+    for i in range(int(g["n_cases"])):
+        ref, qry = dev(g["c%d_ref_chw" % i], True), dev(g["c%d_qry_chw" % i], True)
+        lab, k, n_ids = dev(g["c%d_labels" % i]), int(g["c%d_k" % i]), int(g["c%d_n_obj" % i]) + 1
+        out = ops.global_match(ref.permute(1, 2, 0), qry.permute(1, 2, 0), lab, n_ids, k_nearest_neighbors=k)
+        assert out.requires_grad
+        want = g["c%d_out" % i].reshape(-1, n_ids)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=2e-5, atol=2e-6)
+        with torch.no_grad():  # ... and the inference kernel's top-k gives the same values
+            plain = ops.global_match(ref.permute(1, 2, 0), qry.permute(1, 2, 0), lab, n_ids, k_nearest_neighbors=k)
+        torch.testing.assert_close(out.detach(), plain, rtol=1e-6, atol=1e-6)
+        w = dev(g["c%d_weight" % i]).reshape(out.shape)
+        norm = (torch.sigmoid(out) - 0.5) * 2
+        gr, gq = torch.autograd.grad((norm * w).sum(), [ref, qry])
+        np.testing.assert_allclose(gr.cpu().numpy(), g["c%d_grad_ref" % i], rtol=RTOL, atol=ATOL, err_msg="case %d ref" % i)
+        np.testing.assert_allclose(gq.cpu().numpy(), g["c%d_grad_qry" % i], rtol=RTOL, atol=ATOL, err_msg="case %d qry" % i)
+
+
+def test_topk_arg_passes_are_exact_and_ordered(ops):
+    """manet_global_match_topk_arg_f32 against a brute-force top-k: the k smallest distances per (query, object) in ascending
+    order with the rows that attain them; past an object's row count 1e20 / -1; exact duplicates of a row appear once each"""
+    import ctypes
+    from cvpr2020_manet_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(5)
+    C, N, M, n_ids, k = 100, 300, 500, 4, 6
+    q = torch.relu(torch.randn(N, C, device="cuda")) * 0.3
+    b = torch.relu(torch.randn(M, C, device="cuda")) * 0.3
+    b[17] = b[3]  # an exact duplicate row (same label below): both must be listed, once each
+    lab = torch.randint(0, 2, (M,), device="cuda", dtype=torch.int32)
+    lab[17] = lab[3]
+    lab[:4][lab[:4] >= 0] = lab[:4]  # (no-op; keeps the first rows' labels)
+    lab[100:103] = 2  # object 2: three rows (< k); object 3: none
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.manet_global_match_topk_arg_workspace_bytes(N, M, C, n_ids, ctypes.byref(nbytes)), "ws")
+    ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device="cuda")
+    d = torch.empty(k, N, n_ids, device="cuda")
+    arg = torch.empty(k, N, n_ids, dtype=torch.int32, device="cuda")
+    rc = lib.manet_global_match_topk_arg_f32(q.data_ptr(), C, 1, b.data_ptr(), C, 1, lab.data_ptr(), N, M, C, n_ids, k,
+                                             d.data_ptr(), arg.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "manet_global_match_topk_arg_f32")
+    full = ((q * q).sum(1, keepdim=True) + (b * b).sum(1)[None] - 2 * q @ b.t()).double()
+    for o in range(n_ids):
+        rows = torch.nonzero(lab == o).flatten()
+        v = min(k, rows.numel())
+        if v:
+            top, idx = torch.topk(full[:, rows], v, dim=1, largest=False)
+            got_d = d[:v, :, o].t().double()
+            torch.testing.assert_close(got_d, top, rtol=1e-5, atol=2e-6)
+            got_rows = arg[:v, :, o].t().long()
+            assert bool((lab[got_rows.flatten()] == o).all())
+            # the listed rows attain the listed distances, and no row is listed twice for a query
+            torch.testing.assert_close(torch.gather(full, 1, got_rows), got_d, rtol=1e-5, atol=2e-6)
+            srt = torch.sort(got_rows, dim=1).values
+            assert v == 1 or bool((srt[:, 1:] != srt[:, :-1]).all())
+            assert bool((d[1:v, :, o] >= d[:v - 1, :, o]).all())
+        assert bool((arg[v:, :, o] == -1).all()) and bool((d[v:, :, o] >= 1e20).all())
+
+
 def test_unsupported_training_configurations_raise(ops):
     q = (torch.rand(6, 7, 16, device="cuda")).requires_grad_(True)
     k = torch.rand(6, 7, 16, device="cuda")
@@ -166,7 +231,7 @@ def test_unsupported_training_configurations_raise(ops):
     with pytest.raises(RuntimeError, match="backward exists"):
         ops.global_match(k, q, lab, 2, compute="bf16")
     with pytest.raises(RuntimeError, match="backward exists"):
-        ops.global_match(k, q, lab, 2, k_nearest_neighbors=2)
+        ops.global_match(k, q, lab, 2, k_nearest_neighbors=9)
     with pytest.raises(RuntimeError, match="downsample"):
         ops.local_match(k, q, lab, 2, 2, downsample=False)
 
