@@ -12,6 +12,7 @@ pointers, so the backward is explicit:
   LocalMatchFn    local_previous_frame_nearest_neighbor_features_per_object, downsample on (:345-434): the
                   forward records the winning window offset and keeps the normalised pooled volume; the
                   backward walks min -> where -> bilinear -> sigmoid -> (x - y)^2 -> avg_pool2d in reverse.
+  LocalMatchFullFn  the same with MODEL_LOCAL_DOWNSAMPLE = False (:299-313): raw full-resolution distances, no sigmoid / bilinear.
   CorrelationFn   correlation_package (correlation.py:7-45): forward + manet_correlation_backward_f32.
 
 `ops.global_match` / `ops.local_match` / `ops.correlation_forward` route here when grad mode is on and an
@@ -230,6 +231,49 @@ class LocalMatchFn(torch.autograd.Function):
                                                     gc.stride(2), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
         _lib.check(rc, "manet_local_match_backward_f32")
         return gp, gc, None, None, None
+
+
+class LocalMatchFullFn(torch.autograd.Function):
+    """out [h, w, n_ids] for MODEL_LOCAL_DOWNSAMPLE = False (reference IntVOS.py:299-313 + :398-432): raw full-resolution
+    window distances, masked minimum against the constant 1.0; the gradient of the min flows to one window offset per (pixel,
+    object) -- none where the constant wins -- and from there to x - y of the two embeddings."""
+
+    @staticmethod
+    def forward(ctx, prev, cur, labels, n_ids, max_distance):
+        lib = _lib.load()
+        h, w, C = cur.shape
+        dev = cur.device
+        P = 2 * max_distance + 1
+        out = torch.empty((h, w, n_ids), dtype=torch.float32, device=dev)
+        arg = torch.empty((h, w, n_ids), dtype=torch.int32, device=dev)
+        vol = torch.empty((h, w, P * P), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.manet_local_match_full_arg_f32(prev.data_ptr(), prev.stride(0), prev.stride(1), prev.stride(2),
+                                                    cur.data_ptr(), cur.stride(0), cur.stride(1), cur.stride(2),
+                                                    labels.data_ptr(), h, w, C, n_ids, max_distance, out.data_ptr(),
+                                                    arg.data_ptr(), vol.data_ptr(), _stream_ptr(dev))
+        _lib.check(rc, "manet_local_match_full_arg_f32")
+        ctx.save_for_backward(prev, cur, arg)
+        ctx.n_ids, ctx.max_distance = n_ids, max_distance
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        prev, cur, arg = ctx.saved_tensors
+        h, w, C = cur.shape
+        dev = cur.device
+        P = 2 * ctx.max_distance + 1
+        g = grad_out.contiguous().float()
+        pc, cc = prev.permute(2, 0, 1).contiguous(), cur.permute(2, 0, 1).contiguous()  # (no copy for C-major embeddings)
+        gp, gc = torch.empty_like(pc), torch.empty_like(cc)
+        dv = torch.empty((P * P, h * w), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.manet_local_match_full_backward_f32(pc.data_ptr(), cc.data_ptr(), arg.data_ptr(), g.data_ptr(), h, w, C,
+                                                         ctx.n_ids, ctx.max_distance, gp.data_ptr(), gc.data_ptr(),
+                                                         dv.data_ptr(), _stream_ptr(dev))
+        _lib.check(rc, "manet_local_match_full_backward_f32")
+        return gp.permute(1, 2, 0), gc.permute(1, 2, 0), None, None, None
 
 
 class CorrelationFn(torch.autograd.Function):

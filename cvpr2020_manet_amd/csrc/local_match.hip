@@ -878,6 +878,52 @@ __global__ void local_min_arg_kernel(const float *__restrict__ dvol, const int *
     arg[i] = am;
 }
 
+// The same for MODEL_LOCAL_DOWNSAMPLE = False (IntVOS.py:299-313 + :398-432, r5): the volume is the RAW full-resolution
+// distances [h][w][P*P] (no sigmoid, no bilinear), the labels are still gathered at stride 2 (the reference's unfold, :404)
+// and the constant that competes with them is still 1.0 (:429) -- the reference's quirk, kept.
+__global__ void local_min_arg_full_kernel(const float *__restrict__ vol, const int *__restrict__ labels, int h, int w, int d,
+                                          int n_ids, float *__restrict__ out, int *__restrict__ arg)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)h * w * n_ids) return;
+    const int o = (int)(i % n_ids);
+    const long pix = i / n_ids;
+    const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+    const int P = 2 * d + 1;
+    const float *v0 = vol + pix * P * P;
+    float m = INFINITY;
+    int am = -1;
+    for (int by = 0; by < P; ++by) {
+        const int yy = y + 2 * (by - d);
+        const bool yin = (yy >= 0 && yy < h);
+        for (int bx = 0; bx < P; ++bx) {
+            const int xx = x + 2 * (bx - d);
+            const int lab = (yin && xx >= 0 && xx < w) ? labels[(long)yy * w + xx] : 0;
+            const int l = by * P + bx;
+            const bool hit = (lab == o);
+            const float v = hit ? v0[l] : 1.0f;
+            if (v < m) {
+                m = v;
+                am = hit ? l : -1;
+            }
+        }
+    }
+    out[i] = m;
+    arg[i] = am;
+}
+
+// dV[l][pixel] += g for the winning offset of every (pixel, object) (several objects of a pixel may pick the same offset)
+__global__ void local_bwd_scatter_full_kernel(const int *__restrict__ arg, const float *__restrict__ gout, long npix, int n_ids,
+                                              float *__restrict__ dv)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * n_ids) return;
+    const int l = arg[i];
+    const float g = gout[i];
+    if (l < 0 || g == 0.0f) return;
+    atomicAdd(dv + (long)l * npix + i / n_ids, g);
+}
+
 // dVn[l][i][j] += g * bilinear weight, for the winning offset of every (pixel, object)  (backward of
 // F.interpolate(..., 'bilinear', align_corners=True) restricted to the offsets the min selected)
 __global__ void local_bwd_scatter_kernel(const int *__restrict__ arg, const float *__restrict__ gout, int h, int w,
@@ -1161,6 +1207,54 @@ int manet_local_match_backward_f32(const float *prev, int64_t p_sy, int64_t p_sx
                        (const float *)gyp, C, h, w, hp, wp, grad_cur, (long)gc_sy, (long)gc_sx, (long)gc_sc, grad_prev,
                        (long)gp_sy, (long)gp_sx, (long)gp_sc);
     return manet_check_launch("manet_local_match_backward_f32");
+}
+
+/* MODEL_LOCAL_DOWNSAMPLE = False in training (r5; IntVOS.py:299-313, :398-432).  manet_local_match_full_arg_f32: the raw
+ * full-resolution distance volume (kept in vol_out [h][w][(2d+1)^2] for nobody -- the backward recomputes differences from the
+ * embeddings -- but it is the caller's memory: h*w*(2d+1)^2 floats), the masked minimum and the winning window offset.
+ * manet_local_match_full_backward_f32: both embeddings as CONTIGUOUS [C][h][w] planes, gradients likewise; dv_ws
+ * [(2d+1)^2][h*w] floats of scratch. */
+int manet_local_match_full_arg_f32(const float *prev, int64_t p_sy, int64_t p_sx, int64_t p_sc, const float *cur, int64_t c_sy,
+                                   int64_t c_sx, int64_t c_sc, const int32_t *prev_labels, int h, int w, int C, int n_ids,
+                                   int max_distance, float *out, int32_t *arg_out, float *vol_out, manet_stream_t stream)
+{
+    int rc = check_local(h, w, C, max_distance, 0);
+    if (rc) return rc;
+    if (n_ids <= 0 || n_ids > MANET_MAX_IDS)
+        return manet_set_error(MANET_E_INVALID, "n_ids=%d (supported 1..%d)", n_ids, MANET_MAX_IDS);
+    if (!cur || !prev || !prev_labels || !out || !arg_out || !vol_out) return manet_set_error(MANET_E_INVALID, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    launch_dist(max_distance, st, cur, (long)c_sy, (long)c_sx, (long)c_sc, prev, (long)p_sy, (long)p_sx, (long)p_sc, h, w, C, 0,
+                vol_out);
+    long tot = (long)h * w * n_ids;
+    hipLaunchKernelGGL(local_min_arg_full_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float *)vol_out,
+                       prev_labels, h, w, max_distance, n_ids, out, arg_out);
+    return manet_check_launch("manet_local_match_full_arg_f32");
+}
+
+int manet_local_match_full_backward_f32(const float *prev_chw, const float *cur_chw, const int32_t *arg, const float *grad_out,
+                                        int h, int w, int C, int n_ids, int max_distance, float *grad_prev_chw,
+                                        float *grad_cur_chw, float *dv_ws, manet_stream_t stream)
+{
+    int rc = check_local(h, w, C, max_distance, 0);
+    if (rc) return rc;
+    if (!cur_chw || !prev_chw || !arg || !grad_out || !grad_prev_chw || !grad_cur_chw || !dv_ws)
+        return manet_set_error(MANET_E_INVALID, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int P = 2 * max_distance + 1;
+    const long plane = (long)h * w, nv = plane * P * P;
+    {
+        unsigned blocks = (unsigned)((nv + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(fill_f32_kernel, dim3(blocks), dim3(256), 0, st, dv_ws, 0.0f, nv);
+    }
+    long tot = plane * n_ids;
+    hipLaunchKernelGGL(local_bwd_scatter_full_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, arg, grad_out, plane,
+                       n_ids, dv_ws);
+    long n = plane * C;
+    hipLaunchKernelGGL(local_bwd_dist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cur_chw, prev_chw,
+                       (const float *)dv_ws, C, h, w, max_distance, grad_cur_chw, grad_prev_chw);
+    return manet_check_launch("manet_local_match_full_backward_f32");
 }
 
 }  // extern "C"

@@ -568,10 +568,7 @@ def local_match(prev_frame_embedding, query_embedding, prev_frame_labels, n_ids,
     import ctypes
     lib = _lib.load()
     if _wants_grad(prev_frame_embedding, query_embedding):
-        from .autograd import LocalMatchFn
-        if not downsample:
-            raise RuntimeError("cvpr2020_manet_amd.ops.local_match: the backward exists for the downsample "
-                               "configuration (MODEL_LOCAL_DOWNSAMPLE=True, the reference's default) only")
+        from .autograd import LocalMatchFn, LocalMatchFullFn
         prev = _hwc(prev_frame_embedding, "prev_frame_embedding")
         cur = _hwc(query_embedding, "query_embedding")
         if tuple(prev.shape) != tuple(cur.shape):
@@ -579,7 +576,7 @@ def local_match(prev_frame_embedding, query_embedding, prev_frame_labels, n_ids,
         lab = _labels(prev_frame_labels, "prev_frame_labels")
         if lab.numel() != cur.shape[0] * cur.shape[1]:
             raise ValueError("prev_frame_labels must have height*width entries")
-        return LocalMatchFn.apply(prev, cur, lab, n_ids, max_distance)
+        return (LocalMatchFn if downsample else LocalMatchFullFn).apply(prev, cur, lab, n_ids, max_distance)
     both_bf16 = (prev_frame_embedding.dtype == torch.bfloat16 and query_embedding.dtype == torch.bfloat16
                  and downsample)  # 2-byte embeddings are read as they are by the pooling pass
     prev = _hwc(prev_frame_embedding, "prev_frame_embedding", both_bf16)

@@ -454,6 +454,19 @@ int manet_local_match_backward_f32(const float *prev, int64_t p_sy, int64_t p_sx
                                    int64_t gc_sy, int64_t gc_sx, int64_t gc_sc, void *workspace,
                                    size_t workspace_bytes, manet_stream_t stream);
 
+/* The same for MODEL_LOCAL_DOWNSAMPLE = False (r5; IntVOS.py:299-313 raw full-resolution distances, :398-432 labels gathered
+ * at stride 2 and the constant 1.0 -- the reference's own combination, kept).  manet_local_match_full_arg_f32: out [h][w][n_ids]
+ * (= manet_local_match_f32 with downsample 0), arg_out = the winning window offset (-1: the constant won), vol_out
+ * [h][w][(2d+1)^2] the caller's scratch for the volume.  manet_local_match_full_backward_f32: embeddings and gradients as
+ * CONTIGUOUS [C][h][w] planes (fully overwritten); dv_ws [(2d+1)^2][h*w] floats of scratch. */
+int manet_local_match_full_arg_f32(const float *prev, int64_t p_sy, int64_t p_sx, int64_t p_sc, const float *cur,
+                                   int64_t c_sy, int64_t c_sx, int64_t c_sc, const int32_t *prev_labels, int h, int w,
+                                   int C, int n_ids, int max_distance, float *out, int32_t *arg_out, float *vol_out,
+                                   manet_stream_t stream);
+int manet_local_match_full_backward_f32(const float *prev_chw, const float *cur_chw, const int32_t *arg,
+                                        const float *grad_out, int h, int w, int C, int n_ids, int max_distance,
+                                        float *grad_prev_chw, float *grad_cur_chw, float *dv_ws, manet_stream_t stream);
+
 /* correlation_package backward (correlation_cuda.cc:89-167): gradients w.r.t. both inputs,
  * [B][C][H][W] fp32 contiguous, fully overwritten. */
 int manet_correlation_backward_f32(const float *in1, const float *in2, const float *grad_out, int B,

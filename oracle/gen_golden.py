@@ -409,6 +409,32 @@ def variant_grad_knn():
     save("grad_knn", **out)
 
 
+def variant_grad_ds0():
+    """gradients of the local match with MODEL_LOCAL_DOWNSAMPLE False (IntVOS.py:299-313: raw full-resolution
+    distances; :398-432: labels gathered at stride 2, constant 1.0), from the reference's own autograd.  Embeddings scaled so
+    that part of the window distances fall below the constant 1.0 (only those carry gradient)."""
+    torch, R = import_reference(["--TEST_MODE", "False", "--MODEL_LOCAL_DOWNSAMPLE", "False"])
+    assert R.cfg.MODEL_LOCAL_DOWNSAMPLE is False
+    g = torch.Generator().manual_seed(20200702)
+    out = {}
+    for i, (C, h, w, d, nobj, scale) in enumerate([(16, 12, 15, 2, 2, 0.45), (8, 9, 11, 1, 1, 0.7), (20, 10, 13, 3, 3, 0.4)]):
+        prev = emb(torch, g, C, h, w, scale).requires_grad_(True)
+        cur = emb(torch, g, C, h, w, scale).requires_grad_(True)
+        lab = torch.randint(0, nobj + 1, (h, w, 1), generator=g).int()
+        ids = torch.arange(0, nobj + 1).int()
+        o = R.local_previous_frame_nearest_neighbor_features_per_object(prev.permute(1, 2, 0), cur.permute(1, 2, 0), lab, ids,
+                                                                      max_distance=d)
+        wgt = torch.randn(o.shape, generator=g)
+        gp, gc = torch.autograd.grad((o * wgt).sum(), [prev, cur])
+        frac = float((o < 1.0).float().mean())
+        assert 0.2 < frac < 0.98, frac  # both branches of the min are exercised
+        out.update({"l%d_prev_chw" % i: prev.detach(), "l%d_cur_chw" % i: cur.detach(), "l%d_labels" % i: lab, "l%d_d" % i: d,
+                    "l%d_n_ids" % i: nobj + 1, "l%d_weight" % i: wgt, "l%d_out" % i: o.detach(), "l%d_grad_prev" % i: gp,
+                    "l%d_grad_cur" % i: gc})
+    out["n_cases"] = 3
+    save("grad_ds0", **out)
+
+
 def variant_rough_roi():
     """The caller-side labelling rule of the first interaction round (test.py:229-230 -> rough_ROI, test.py:323-343): what the
     bank `prop_seghead` matches against really holds.  test.py itself cannot be imported here (davisinteractive, cv2, ... at
@@ -470,6 +496,7 @@ VARIANTS = {
     "grad": variant_grad,
     "rough_roi": variant_rough_roi,
     "grad_knn": variant_grad_knn,
+    "grad_ds0": variant_grad_ds0,
 }
 
 if __name__ == "__main__":

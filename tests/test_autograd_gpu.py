@@ -93,6 +93,26 @@ def test_local_match_gradients_match_reference_autograd(ops, g, i):
     np.testing.assert_allclose(gc.cpu().numpy(), g["l%d_grad_cur" % i], rtol=RTOL, atol=2e-5 * scale)
 
 
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_local_match_no_downsample_gradients_match_reference_autograd(ops, i):
+    """MODEL_LOCAL_DOWNSAMPLE False in training (IntVOS.py:299-313 raw full-resolution distances; :398-432
+    stride-2 label gather, constant 1.0): forward values and both gradients of the reference's own autograd
+    (tests/golden/grad_ds0.npz, oracle/gen_golden.py:variant_grad_ds0)"""
+    g0 = load_golden("grad_ds0")
+    prev, cur = dev(g0["l%d_prev_chw" % i], True), dev(g0["l%d_cur_chw" % i], True)
+    lab, d, n_ids = dev(g0["l%d_labels" % i]), int(g0["l%d_d" % i]), int(g0["l%d_n_ids" % i])
+    out = ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), lab, n_ids, d, downsample=False)
+    assert out.requires_grad
+    np.testing.assert_allclose(out.detach().cpu().numpy().reshape(g0["l%d_out" % i].shape), g0["l%d_out" % i], rtol=1e-5, atol=2e-6)
+    with torch.no_grad():  # the training forward equals the inference path
+        assert torch.equal(out.detach(), ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), lab, n_ids, d, downsample=False))
+    w = dev(g0["l%d_weight" % i]).reshape(out.shape)
+    gp, gc = torch.autograd.grad((out * w).sum(), [prev, cur])
+    scale = max(np.abs(g0["l%d_grad_cur" % i]).max(), 1e-6)
+    np.testing.assert_allclose(gp.cpu().numpy(), g0["l%d_grad_prev" % i], rtol=RTOL, atol=2e-5 * scale)
+    np.testing.assert_allclose(gc.cpu().numpy(), g0["l%d_grad_cur" % i], rtol=RTOL, atol=2e-5 * scale)
+
+
 def test_training_step_through_forward_matches_reference(ops, g):
     """IntVOS.forward in train() mode + backward: logits and parameter gradients of the reference's own run"""
     from cvpr2020_manet_amd.config import make_cfg
@@ -195,7 +215,6 @@ def test_topk_arg_passes_are_exact_and_ordered(ops):
     b[17] = b[3]  # an exact duplicate row (same label below): both must be listed, once each
     lab = torch.randint(0, 2, (M,), device="cuda", dtype=torch.int32)
     lab[17] = lab[3]
-    lab[:4][lab[:4] >= 0] = lab[:4]  # (no-op; keeps the first rows' labels)
     lab[100:103] = 2  # object 2: three rows (< k); object 3: none
     nbytes = ctypes.c_size_t(0)
     _lib.check(lib.manet_global_match_topk_arg_workspace_bytes(N, M, C, n_ids, ctypes.byref(nbytes)), "ws")
@@ -232,8 +251,6 @@ def test_unsupported_training_configurations_raise(ops):
         ops.global_match(k, q, lab, 2, compute="bf16")
     with pytest.raises(RuntimeError, match="backward exists"):
         ops.global_match(k, q, lab, 2, k_nearest_neighbors=9)
-    with pytest.raises(RuntimeError, match="downsample"):
-        ops.local_match(k, q, lab, 2, 2, downsample=False)
 
 
 def test_correlation_classes_keep_the_reference_interface_and_dtypes(ops):
