@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box: the round's tracked evidence.  usage: tools/capture_profiles.sh RTAG   (e.g. r03)
-#   gpurun_out/RTAG/RTAG_bench_line.json                 the default `python bench.py` line (headline + `also` legs + cpu baseline)
+#   gpurun_out/RTAG/RTAG_bench_line.json                 the default `python bench.py` compact line (what the driver parses);
+#   gpurun_out/RTAG/RTAG_bench_full.json                 ... and the full blocks of the same run (the `#bench_full` stdout line)
 #   for each of: cfg2 f32 (headline), cfg3 bf16, cfg5 bf16, cfg3 bf16r and cfg2 bf16r (fp32-stored embeddings)
 #     gpurun_out/RTAG/RTAG_cfgN_<compute>_{bench_line_under_rocprof.json,kernel_stats.csv,pmc_summary.csv}
 #                                                        rocprofv3 kernel stats + separate --pmc passes (tools/profile_gpu.sh)
@@ -9,7 +10,9 @@
 # capture (the r2 bench lines quoted an older capture's traffic).
 R=$1
 mkdir -p gpurun_out/$R
-python bench.py > gpurun_out/$R/${R}_bench_line.json 2> gpurun_out/$R/${R}_bench.err
+python bench.py > gpurun_out/$R/${R}_bench_stdout.txt 2> gpurun_out/$R/${R}_bench.err
+tail -n 1 gpurun_out/$R/${R}_bench_stdout.txt > gpurun_out/$R/${R}_bench_line.json                          # the compact driver line
+grep -h '^#bench_full ' gpurun_out/$R/${R}_bench_stdout.txt | sed 's/^#bench_full //' > gpurun_out/$R/${R}_bench_full.json  # every block
 for c in "2 f32 auto" "3 bf16 auto" "5 bf16 auto" "3 bf16r f32" "2 bf16r f32"; do
   set -- $c
   tag=${R}_cfg$1_$2

@@ -3,6 +3,7 @@
 # per-config traffic json bench.py reads -- from the same capture.   usage: tools/publish_profiles.sh SRC rNN
 SRC=$1; R=$2
 cp gpurun_out/$SRC/${SRC}_bench_line.json profiles/${R}_bench_line.json
+cp gpurun_out/$SRC/${SRC}_bench_full.json profiles/${R}_bench_full.json
 cp gpurun_out/$SRC/${SRC}_local_pmc_summary.csv profiles/${R}_local_pmc_summary.csv
 cp gpurun_out/$SRC/${SRC}_e2e_per_frame_kernels.csv profiles/${R}_e2e_per_frame_kernels.csv
 cp gpurun_out/$SRC/${SRC}_head_pointwise.log profiles/${R}_head_pointwise.log
