@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""prints the `robustness` block of a bench.py JSON line (file argument) as a table"""
+"""prints the `robustness` block of a bench.py run as a table: file argument = bench_full.json, or a capture of bench.py's
+stdout (the `#bench_full ` line is read; the compact last line carries only the block's summary)"""
 import json
 import sys
 
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+lines = open(sys.argv[1]).read().strip().splitlines()
+full = [l[len("#bench_full "):] for l in lines if l.startswith("#bench_full ")]
+d = json.loads(full[-1] if full else lines[-1])
 rb = d["robustness"]
 print(rb["summary"])
 for leg in rb["legs"]:
