@@ -41,14 +41,17 @@ constexpr int DW_IMG = DW_NP * DW_LW * 2;    // floats per interleaved image
 // (tile, plane), as before: every workgroup of a launch read, then computed, then wrote, in step with its neighbours -- the
 // memory system saw alternating read and write bursts: 53 us for 158 MB at [3,256,120,214].)
 // (the 4-byte-load form of odd widths needs ~148 registers: three workgroups per CU -- at four it spilled 20 of them, r4)
-template <bool FAST, int ABL = 0>
+// RELU_IN / RELU (r5): compile-time -- as run-time flags each staged element paid a select on top of its max (76 v_cndmask +
+// 76 v_max per item against 392 packed FMAs), each output one more.
+template <bool FAST, bool RELU_IN, bool RELU, int ABL = 0>
 __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(const float *__restrict__ in, int B, int C, int h, int w,
                                                                    const float *__restrict__ weight,
                                                                    const float *__restrict__ bias,
                                                                    const float *__restrict__ scale,
-                                                                   const float *__restrict__ shift, int relu,
-                                                                   int relu_in, float *__restrict__ out, int per_item)
+                                                                   const float *__restrict__ shift,
+                                                                   float *__restrict__ out, int per_item)
 {
+    constexpr bool relu_in = RELU_IN, relu = RELU;
     // E: element (r, col) at ((r >> 1) * LW + col) * 2 + (r & 1), r = row - (y0 - 3); O: the same for r - 1
     __shared__ __attribute__((aligned(16))) float tile[2 * DW_IMG];
     // per_item (r4): few channels (layer 1's 3 per-object ones: 24 workgroups walking 3 items each = 3 serial round trips on a
@@ -873,9 +876,16 @@ extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, 
     // the batch walk pays when every CU has workgroups to overlap; below two workgroups per CU the items go into the grid
     const int per_item = (B > 1 && (long)grid.x * grid.y * C < 512) ? 1 : 0;
     if (per_item) grid.z = (unsigned)(B * C);
+#define DW_LAUNCH2(F_, RI_, R_, A_)                                                                                    \
+    hipLaunchKernelGGL((dwconv7x7_bn_relu_kernel<F_, RI_, R_, A_>), grid, dim3(256), 0, (hipStream_t)stream, in, B, C, h, w, weight, \
+                       bias, bn_scale, bn_shift, out, per_item)
 #define DW_LAUNCH(F_, A_)                                                                                              \
-    hipLaunchKernelGGL((dwconv7x7_bn_relu_kernel<F_, A_>), grid, dim3(256), 0, (hipStream_t)stream, in, B, C, h, w, weight, bias, \
-                       bn_scale, bn_shift, relu, relu_in, out, per_item)
+    do {                                                                                                               \
+        if (relu_in && relu) DW_LAUNCH2(F_, true, true, A_);                                                           \
+        else if (relu_in) DW_LAUNCH2(F_, true, false, A_);                                                             \
+        else if (relu) DW_LAUNCH2(F_, false, true, A_);                                                                \
+        else DW_LAUNCH2(F_, false, false, A_);                                                                         \
+    } while (0)
     if (w % 2 == 0 && w >= 2 && ((size_t)in & 7) == 0 && ((size_t)out & 7) == 0) {
 #ifdef MANET_ABLATION
         switch (manet_tune_get(MANET_TUNE_ABLATION, 0)) {  // timing experiments only (tools/pw_bench.py --dw)
@@ -889,6 +899,7 @@ extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, 
 #endif
     } else
         DW_LAUNCH(false, 0);
+#undef DW_LAUNCH2
 #undef DW_LAUNCH
     return manet_check_launch("manet_dwconv7x7_bn_relu_f32");
 }

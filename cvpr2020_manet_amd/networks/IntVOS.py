@@ -343,24 +343,27 @@ class DynamicSegHead(nn.Module):  # reference IntVOS.py:509-525
         nn.init.kaiming_normal_(self.conv.weight, mode="fan_out", nonlinearity="relu")
 
     def _tail(self, x):
-        """layers 2-4 + the 1x1 output conv on the inference fast path; x = layer1's output BEFORE its last ReLU
-        (each block's ReLU is applied by the next block's fused depthwise kernel as it reads)"""
-        x = self.layer2(x, relu_in=True, defer_relu=True)
-        x = self.layer3(x, relu_in=True, defer_relu=True)
+        """layers 2-4 + the 1x1 output conv on the inference fast path; x = layer1's output.  r5: every block's last ReLU
+        is applied in the epilogue of its own 1x1 kernel, where it is free -- r2-r4 left it to the NEXT block's depthwise
+        kernel (`relu_in`, from the days the 1x1 stage was the framework's GEMM and a ReLU meant a pass): 60 v_max per
+        staged tile in a VALU-bound kernel, 60 against 54 us at [3,256,120,214].  Same values either way.  (`relu_in` /
+        `defer_relu` remain for blocks whose 1x1 stage falls back to the framework's convolution.)"""
+        x = self.layer2(x)
+        x = self.layer3(x)
         if self.conv.kernel_size == (1, 1) and self.conv.out_channels == 1:
             # output layer fused with layer4's ReLU -- into the epilogue of layer4's own 1x1 kernel when that runs on the
             # MFMA path (layer4's activation is never written), else one pass over it (ops.relu_conv1x1_c1)
-            return self.layer4(x, relu_in=True, defer_relu=True, head=(self.conv.weight, self.conv.bias))
-        return self.conv(self.layer4(x, relu_in=True))
+            return self.layer4(x, defer_relu=True, head=(self.conv.weight, self.conv.bias))
+        return self.conv(self.layer4(x))
 
     def forward(self, x):
         if self.layer1._fast(x):
-            return self._tail(self.layer1(x, defer_relu=True))
+            return self._tail(self.layer1(x))
         return self.conv(self.layer4(self.layer3(self.layer2(self.layer1(x)))))
 
     def forward_shared(self, shared, per_object):
         """forward(cat([shared.repeat(n,1,1,1), per_object], 1)) without materialising the input"""
-        return self._tail(self.layer1.forward_shared(shared, per_object, defer_relu=True))
+        return self._tail(self.layer1.forward_shared(shared, per_object))
 
 
 def _run_head(head, embedding_chw, per_object):

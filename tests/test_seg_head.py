@@ -136,6 +136,16 @@ def test_output_layer_and_deferred_relu_on_gpu():
         shared = head.forward_shared(x[:1, :16], x[:, 16:])
         lit = head(torch.cat((x[:1, :16].repeat(2, 1, 1, 1), x[:, 16:]), 1))
         torch.testing.assert_close(shared, lit, rtol=1e-4, atol=1e-4)
+    # r5: the blocks' ReLUs moved from the NEXT block's depthwise read (r2-r4) into their own 1x1 epilogue: the same bits
+    head = M.DynamicSegHead(in_dim=103, embed_dim=256).cuda().eval()
+    x = torch.randn(3, 103, 24, 36, device="cuda")
+    with torch.no_grad():
+        now = head(x)
+        y = head.layer1(x, defer_relu=True)
+        y = head.layer2(y, relu_in=True, defer_relu=True)
+        y = head.layer3(y, relu_in=True, defer_relu=True)
+        was = head.layer4(y, relu_in=True, defer_relu=True, head=(head.conv.weight, head.conv.bias))
+        assert torch.equal(now, was)
 
 
 @pytest.mark.gpu
