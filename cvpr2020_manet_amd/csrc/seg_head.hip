@@ -42,7 +42,7 @@ constexpr int DW_IMG = DW_NP * DW_LW * 2;    // floats per interleaved image
 // memory system saw alternating read and write bursts: 53 us for 158 MB at [3,256,120,214].)
 // (the 4-byte-load form of odd widths needs ~148 registers: three workgroups per CU -- at four it spilled 20 of them, r4)
 // RELU_IN / RELU (r5): compile-time -- as run-time flags each staged element paid a select on top of its max (76 v_cndmask +
-// 76 v_max per item against 392 packed FMAs), each output one more.
+// 76 v_max per item against 392 packed FMAs), each output one more.  (Worth ~1 % on a warm GPU: the kernel hides it.)
 template <bool FAST, bool RELU_IN, bool RELU, int ABL = 0>
 __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(const float *__restrict__ in, int B, int C, int h, int w,
                                                                    const float *__restrict__ weight,

@@ -346,7 +346,7 @@ class DynamicSegHead(nn.Module):  # reference IntVOS.py:509-525
         """layers 2-4 + the 1x1 output conv on the inference fast path; x = layer1's output.  r5: every block's last ReLU
         is applied in the epilogue of its own 1x1 kernel, where it is free -- r2-r4 left it to the NEXT block's depthwise
         kernel (`relu_in`, from the days the 1x1 stage was the framework's GEMM and a ReLU meant a pass): 60 v_max per
-        staged tile in a VALU-bound kernel, 60 against 54 us at [3,256,120,214].  Same values either way.  (`relu_in` /
+        staged tile less (0.5 us of 47 at [3,256,120,214]: that kernel hides them).  Same values either way.  (`relu_in` /
         `defer_relu` remain for blocks whose 1x1 stage falls back to the framework's convolution.)"""
         x = self.layer2(x)
         x = self.layer3(x)
