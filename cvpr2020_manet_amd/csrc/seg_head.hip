@@ -328,11 +328,13 @@ __global__ __launch_bounds__(PW_NT, 3) void conv1x1_mfma_kernel(const float *__r
     const int tail = Cin - (n - 1) * PW_KC;  // channels of the last chunk: 1 .. 16
     // A partial last chunk multiplies all 16 rows like the others (no branch in the MFMA loop: a branch per k-step keeps
     // hipcc from overlapping a k-step's LDS reads with the previous k-step's MFMAs): its missing weight rows are ZERO in LDS,
-    // so whatever finite in-slice rows an earlier chunk left there contribute nothing.  (n == 1: the in-slice rows were
-    // never written; they are zeroed too.)
+    // so whatever finite in-slice rows an earlier chunk left there contribute nothing.  (n <= 2: the last chunk is the FIRST
+    // use of its buffer -- its in-slice rows past the tail were never written and hold whatever the previous kernel left in
+    // LDS, NaN bit patterns included; they are zeroed too.  r4 did that for n == 1 only: Cin in 17..32 multiplied
+    // uninitialised LDS by zero -- found in r5 when another kernel's LDS image changed.)
     auto zero_tail = [&](int buf) __attribute__((always_inline)) {
         for (int i = tid; i < (PW_KC - tail) * PW_CO; i += PW_NT) wbuf[buf][tail * PW_CO + i] = 0.0f;
-        if (n == 1)
+        if (n <= 2)
             for (int i = tid; i < (PW_KC - tail) * PW_P; i += PW_NT) xbuf[buf][tail * PW_P + i] = 0.0f;
     };
     dma(0, 0);
@@ -681,13 +683,16 @@ __global__ __launch_bounds__(X3_NT, NP == 3 ? 2 : 3) void conv1x1_x3_kernel(cons
 //   conv1x1_mfma_kernel becomes two interleaved ones: results agree to summation-order rounding, not bit for bit.
 //   stage = 32 input channels x 64 pixels (8 KiB, 2 DMA pieces per wave), ring of 4, fetched 3 steps ahead ACROSS tile
 //   boundaries; a step's fragments F[s] are refilled with the next step's k-step s right behind the MFMAs that consumed them.
-constexpr int RW_P = 64, RW_KC = 32, RW_NB = 4, RW_NT = 256, RW_KMAX = 256;
+// r5: the stage size is a template parameter -- 64 input channels per stage where Cin allows (half the barriers and counted waits per
+// tile: a wave then issues 64 MFMAs between two barriers), 32 otherwise.
+constexpr int RW_P = 64, RW_NB = 4, RW_NT = 256, RW_KMAX = 256;
 __device__ __forceinline__ void rw_wait_vmcnt(int n)  // wave-uniform n: 0, 2, 4 (pieces of the steps still in flight)
 {
     if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+template <int RW_KC>
 __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__restrict__ in, long in_bs, int Cin, long HW,
                                                               const float *__restrict__ w2t, const float *__restrict__ b2,
                                                               int relu_out, float *__restrict__ out, int tpp, int total_tiles,
@@ -737,11 +742,12 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
     const unsigned lane_off_last = (unsigned)(((long)(lane >> 4) * HW + lpix) * 4);
     auto issue = [&]() __attribute__((always_inline)) {
         if (pf_left <= 0 || ((abl & 4) && issued >= RW_NB - 1)) return;  // (uniform)
-        const float *sbase = in + (long)pf_b * in_bs + (long)(pf_c * RW_KC + wave * 8) * HW + (long)pf_p * RW_P;
+        // this wave's pieces: channel rows (RW_KC / 4) wave .. + RW_KC / 4 - 1 of the chunk, four rows (1 KiB) per piece
+        const float *sbase = in + (long)pf_b * in_bs + (long)(pf_c * RW_KC + wave * (RW_KC / 4)) * HW + (long)pf_p * RW_P;
         const unsigned voff = (pf_p == tpp - 1) ? lane_off_last : lane_off;
-        const unsigned dst = xbase + (unsigned)(issued % RW_NB) * (unsigned)(RW_KC * RW_P * 4) + (unsigned)wave * 2048u;
-        lds_dma16_s(sbase, voff, dst);                       // channel rows 8 wave .. 8 wave + 3 of the chunk
-        lds_dma16_s(sbase + 4 * HW, voff, dst + 1024u);      // ... + 4 .. + 7
+        const unsigned dst = xbase + (unsigned)(issued % RW_NB) * (unsigned)(RW_KC * RW_P * 4) + (unsigned)wave * (unsigned)(RW_KC / 4 * 256);
+#pragma unroll
+        for (int pc = 0; pc < RW_KC / 16; ++pc) lds_dma16_s(sbase + (long)(4 * pc) * HW, voff, dst + 1024u * pc);
         ++issued;
         if (++pf_c == nch) {
             pf_c = 0;
@@ -760,10 +766,10 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
     for (int s = 0; s < RW_KMAX / 2; ++s) asm volatile("" : "+v"(a[s]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // F holds the NEXT eight k-steps' fragments: the first half of a step refills it with the step's own second half, the
-    // second half with the first eight k-steps of the next stage (16 registers; a whole step's 32 would not fit beside 128
-    // weights and 64 accumulators)
-    constexpr int FH = RW_KC / 4;  // k-steps per half step
+    // F holds the NEXT eight k-steps' fragments: k-step s of a stage is refilled, right behind the MFMAs that consumed it, with
+    // k-step s + 8 -- of the same stage, or the first eight of the next one (16 registers; a whole step's would not fit beside
+    // 128 weights and 64 accumulators)
+    constexpr int FH = 8;  // k-steps the fragment registers run ahead
     float F0[FH], F1[FH];
     // pixel block pb of the tile = the pixels of PARITY pb (MFMA column n <-> pixel 2 n + pb): a lane's two fragments of a
     // k-step are neighbours in LDS (one ds_read_b64, two k-steps per ds_read2_b64), and its two outputs of a channel are
@@ -796,9 +802,8 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
                     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks + 1], F0[f + 1], first ? zero16 : acc[0][1], 0, 0, 0);
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks + 1], F1[f + 1], first ? zero16 : acc[1][1], 0, 0, 0);
                     if (!(abl & 8)) {
-                        // k-steps s, s + 1 of this step's second half (s < FH), or of the next stage's first half (a stale
-                        // read behind the last step)
-                        const float *X = s < FH ? Xc + 2 * (s + FH) * RW_P : Xn + 2 * (s - FH) * RW_P;
+                        // k-steps s + 8, s + 9 of this stage, or of the next stage's first eight (a stale read behind the last step)
+                        const float *X = s + FH < RW_KC / 2 ? Xc + 2 * (s + FH) * RW_P : Xn + 2 * (s + FH - RW_KC / 2) * RW_P;
                         const f32x2 va = *(const f32x2 *)X, vb = *(const f32x2 *)(X + 2 * RW_P);
                         F0[f] = va[0];
                         F1[f] = va[1];
@@ -808,7 +813,7 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // the refill (one ds_read2_b64) right behind them
                 }
-                rw_wait_vmcnt(2 * (issued - 1 - (st + 2)));  // step st + 2 has landed: only the steps behind it may be out
+                rw_wait_vmcnt((RW_KC / 16) * (issued - 1 - (st + 2)));  // step st + 2 has landed: only the steps behind it may be out
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of stages st, st + 1 have returned
                 if (!(abl & 2)) __syncthreads();
                 ++st;
@@ -946,7 +951,7 @@ static int conv1x1_f32_impl(const float *in, int64_t in_batch_stride, int B, int
         return manet_set_error(MANET_E_INVALID, "in / w2t must be 16-byte aligned, the batch stride a multiple of 4 elements");
     // weights resident in registers (conv1x1_rw_kernel) when the layer allows: whole 32-channel stages, no fused output layer
     if (head_w && add) return manet_set_error(MANET_E_INVALID, "add and the fused output layer are exclusive");
-    if (!head_w && !add && Cin % RW_KC == 0 && Cin <= RW_KMAX && manet_tune_get(MANET_TUNE_CONV1X1, 0) != 1) {
+    if (!head_w && !add && Cin % 32 == 0 && Cin <= RW_KMAX && manet_tune_get(MANET_TUNE_CONV1X1, 0) != 1) {
         const int tpp = (int)((HW + RW_P - 1) / RW_P);
         const long total = (long)tpp * B;
         int G = 256;  // pixel-range groups: one per CU; each is served by two workgroups (the output-channel halves)
@@ -957,8 +962,12 @@ static int conv1x1_f32_impl(const float *in, int64_t in_batch_stride, int B, int
 #else
         const int rw_abl = 0;
 #endif
-        hipLaunchKernelGGL(conv1x1_rw_kernel, dim3(blocks), dim3(RW_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin,
-                           (long)HW, w2t, b2, relu_out, out, tpp, (int)total, G, rw_abl);
+        if (Cin % 64 == 0 && manet_tune_get(MANET_TUNE_CONV1X1, 0) != 2)  // (2: 32-channel stages everywhere, A/B timing)
+            hipLaunchKernelGGL(conv1x1_rw_kernel<64>, dim3(blocks), dim3(RW_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin,
+                               (long)HW, w2t, b2, relu_out, out, tpp, (int)total, G, rw_abl);
+        else
+            hipLaunchKernelGGL(conv1x1_rw_kernel<32>, dim3(blocks), dim3(RW_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin,
+                               (long)HW, w2t, b2, relu_out, out, tpp, (int)total, G, rw_abl);
         return manet_check_launch("manet_conv1x1_f32 (resident weights)");
     }
     dim3 grid((unsigned)((HW + PW_P - 1) / PW_P), (unsigned)B);

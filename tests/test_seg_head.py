@@ -269,7 +269,12 @@ def _pointwise_module_cases(M, ops, torch):
         lit = head(torch.cat((xs[:1, :100].repeat(3, 1, 1, 1), xs[:, 100:]), 1))
         torch.testing.assert_close(shared, lit, rtol=1e-3, atol=1e-3)
         # r4: any Cin (rows past Cin inside a 4-row DMA piece re-read row Cin - 1 against zero weight rows), and the `add` term
-        for (B, cin, h, w) in ((3, 3, 24, 30), (1, 1, 4, 4), (2, 6, 5, 12), (2, 18, 9, 12), (3, 103, 6, 10), (3, 3, 120, 214)):
+        for (B, cin, h, w) in ((3, 3, 24, 30), (1, 1, 4, 4), (2, 6, 5, 12), (2, 18, 9, 12), (2, 31, 9, 12), (3, 103, 6, 10),
+                               (3, 3, 120, 214)):
+            # (LDS is not cleared between kernels: leave NaNs in every stage row first -- a partial last chunk must not multiply
+            # rows it never wrote by its zero weights; r4 did for Cin in 17..32)
+            ops.conv1x1_mfma(torch.full((1, 48, 16, 64), float("nan"), device="cuda"), torch.zeros(48, 256, device="cuda"),
+                             torch.zeros(256, device="cuda"))
             x = torch.randn(B, cin, h, w, device="cuda")
             w2t = torch.randn(cin, 256, device="cuda") * 0.2
             bb = torch.randn(256, device="cuda")

@@ -40,7 +40,11 @@ def main():
             lib.manet_tune_set(8, 1)
             return ops.conv1x1_mfma(x, w2t, b2)
 
-        forms = {"resident weights": rw, "LDS weights": lds, "framework GEMM": lambda: torch.nn.functional.conv2d(x, wconv, b2),
+        def rw32():
+            lib.manet_tune_set(8, 2)
+            return ops.conv1x1_mfma(x, w2t, b2)
+
+        forms = {"resident weights": rw, "resident weights, 32-channel stages": rw32, "LDS weights": lds, "framework GEMM": lambda: torch.nn.functional.conv2d(x, wconv, b2),
                  "split-bf16": lambda: ops.conv1x1_split(x, sw, b2)}
         best = {k: 1e9 for k in forms}
         mean_us(rw, 200)  # warm-up
