@@ -311,3 +311,78 @@ def test_global_backward_skips_the_gradient_nobody_asked_for(ops):
     out2 = ops.global_match(k2, q2, lab, 2)
     gk2, gq2 = torch.autograd.grad(out2.sum(), [k2, q2])
     assert torch.equal(gq, gq2) and gk2.abs().sum() > 0
+
+
+def _torch_knn_reference(ref, qry, lab, n_ids, k):
+    """the reference's k > 1 formula (IntVOS.py:23-40, :76-94) restated with torch ops -- the CHECKER of the fuzz test below,
+    differentiated by torch.autograd"""
+    xs = (qry * qry).sum(1, keepdim=True)
+    ys = (ref * ref).sum(1, keepdim=True).t()
+    d = xs + ys - 2.0 * qry @ ref.t()                                     # [N, M]
+    ids = torch.arange(n_ids, device=lab.device, dtype=lab.dtype)
+    wrong = (lab[None, :] != ids[:, None]).float()                        # [n_ids, M]
+    dd = d[:, None, :] + wrong[None] * 1e20                               # [N, n_ids, M]
+    top = -torch.topk(-dd, k, dim=2).values
+    valid = top < 1e20
+    pad = (top * valid.float()).max(dim=2, keepdim=True).values
+    return torch.where(valid, top, pad.expand_as(top)).mean(dim=2)        # [N, n_ids]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_knn_gradients_fuzz_against_torch_autograd(ops, seed):
+    """random shapes / label sets (objects with 0, 1, < k and many rows, unlabelled rows) for k = 2..8: forward values and both
+    gradients of GlobalMatchTopkFn against torch.autograd through the formula above"""
+    g = torch.Generator(device="cuda").manual_seed(100 + seed)
+    C = [100, 16, 64, 7, 128, 33][seed]
+    N, M = [257, 64, 500, 33, 300, 129][seed], [400, 90, 700, 40, 256, 513][seed]
+    n_ids, k = [4, 3, 6, 2, 5, 3][seed], [3, 2, 8, 5, 4, 6][seed]
+    ref = (torch.relu(torch.randn(M, C, generator=g, device="cuda")) * 0.3).requires_grad_(True)
+    qry = (torch.relu(torch.randn(N, C, generator=g, device="cuda")) * 0.3).requires_grad_(True)
+    lab = torch.randint(-1, max(n_ids - 2, 1), (M,), generator=g, device="cuda", dtype=torch.int32)
+    if n_ids >= 3:
+        lab[:2] = n_ids - 2   # an object with two rows (< k for k >= 3); the last id has none
+    out = ops.global_match(ref, qry, lab, n_ids, k_nearest_neighbors=k)
+    want = _torch_knn_reference(ref, qry, lab, n_ids, k)
+    torch.testing.assert_close(out, want, rtol=2e-5, atol=2e-5)
+    w = torch.randn(out.shape, generator=g, device="cuda")
+    gr, gq = torch.autograd.grad((out * w).sum(), [ref, qry])
+    wr, wq = torch.autograd.grad((want * w).sum(), [ref, qry])
+    scale = float(wq.abs().max())
+    torch.testing.assert_close(gq, wq, rtol=2e-4, atol=2e-5 * scale)
+    torch.testing.assert_close(gr, wr, rtol=2e-4, atol=2e-5 * scale)
+
+
+def _torch_local_full_reference(prev, cur, lab, n_ids, d):
+    """IntVOS.py:299-313 + :398-432 restated with torch ops (the checker): raw full-resolution window distances with the 1e20
+    padding, labels gathered at stride 2 with zero padding, where(mask, dist, 1.0), min over the window"""
+    h, w, C = cur.shape
+    P = 2 * d + 1
+    ypad = torch.nn.functional.pad(prev, (0, 0, d, d, d, d), value=1e20)
+    lpad = torch.nn.functional.pad(lab.float(), (2 * d, 2 * d, 2 * d, 2 * d))
+    dists, labs = [], []
+    for dy in range(P):
+        for dx in range(P):
+            dists.append(((cur - ypad[dy:dy + h, dx:dx + w]) ** 2).sum(2))
+            labs.append(lpad[2 * dy:2 * dy + h, 2 * dx:2 * dx + w])
+    dist, labs = torch.stack(dists, 2), torch.stack(labs, 2)                               # [h, w, P*P]
+    ids = torch.arange(n_ids, device=cur.device).float()
+    masked = torch.where(labs[..., None] == ids, dist[..., None], torch.ones_like(dist[..., None]))
+    return masked.min(dim=2).values                                                        # [h, w, n_ids]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_local_no_downsample_gradients_fuzz_against_torch_autograd(ops, seed):
+    g = torch.Generator(device="cuda").manual_seed(200 + seed)
+    C, h, w, d, n_ids = [(8, 9, 12, 1, 2), (16, 14, 11, 3, 3), (5, 20, 21, 2, 4), (32, 13, 17, 4, 2)][seed]
+    prev = (torch.relu(torch.randn(C, h, w, generator=g, device="cuda")) * 0.5).requires_grad_(True)
+    cur = (torch.relu(torch.randn(C, h, w, generator=g, device="cuda")) * 0.5).requires_grad_(True)
+    lab = torch.randint(0, n_ids, (h, w), generator=g, device="cuda", dtype=torch.int32)
+    out = ops.local_match(prev.permute(1, 2, 0), cur.permute(1, 2, 0), lab, n_ids, d, downsample=False)
+    want = _torch_local_full_reference(prev.permute(1, 2, 0), cur.permute(1, 2, 0), lab, n_ids, d)
+    torch.testing.assert_close(out, want, rtol=1e-5, atol=2e-6)
+    wgt = torch.randn(out.shape, generator=g, device="cuda")
+    gp, gc = torch.autograd.grad((out * wgt).sum(), [prev, cur])
+    wp, wc = torch.autograd.grad((want * wgt).sum(), [prev, cur])
+    scale = max(float(wc.abs().max()), 1e-6)
+    torch.testing.assert_close(gp, wp, rtol=2e-4, atol=2e-5 * scale)
+    torch.testing.assert_close(gc, wc, rtol=2e-4, atol=2e-5 * scale)
