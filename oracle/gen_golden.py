@@ -435,6 +435,51 @@ def variant_grad_ds0():
     save("grad_ds0", **out)
 
 
+def variant_grad_step_alt():
+    """One training step through IntVOS.forward (train_stage1.py:126-156 shape, tiny heads, train() mode) in the configuration
+    OUTSIDE the defaults that round 5 added to the HIP path: k_nearest_neighbors = 3 and MODEL_LOCAL_DOWNSAMPLE False --
+    logits and parameter gradients of the reference's own run."""
+    torch, R = import_reference(["--TEST_MODE", "False", "--MODEL_SEMANTIC_EMBEDDING_DIM", "12",
+                                 "--MODEL_HEAD_EMBEDDING_DIM", "8", "--MODEL_ASPP_OUTDIM", "6",
+                                 "--MODEL_MAX_LOCAL_DISTANCE", "2", "--MODEL_LOCAL_DOWNSAMPLE", "False"])
+    import torch.nn as nn
+    torch.manual_seed(20200703)
+
+    class TinyExtractor(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = nn.Conv2d(3, 6, 3, stride=4, padding=1)
+            self.cls_conv = nn.Identity()
+            self.upsample4 = nn.Identity()
+
+        def forward(self, x):
+            return self.conv(x)
+
+    model = R.IntVOS(R.cfg, TinyExtractor())
+    model.train()
+    H, W = 40, 52
+    x3 = torch.randn(3, 3, H, W) * 0.5  # [ref; prev; cur] (small inputs: part of the raw local distances stay below 1.0)
+    nobj = 2
+    ref_lab = torch.randint(0, nobj + 1, (1, 1, H, W)).float()
+    prev_lab = torch.randint(0, nobj + 1, (1, 1, H, W)).float()
+    sd0 = {("sd::" + k): v.clone() for k, v in model.state_dict().items()}
+    dic = model.forward(x3, ref_lab, prev_lab, seq_names=["clip"], gt_ids=torch.Tensor([nobj]), k_nearest_neighbors=3,
+                        global_map_tmp_dic=None, local_map_dics=None, interaction_num=1, start_annotated_frame=0,
+                        frame_num=[2])
+    logits = dic["clip"]
+    wl = torch.randn(logits.shape)
+    (logits * wl).sum().backward()
+    names = ["feature_extracter.conv.weight", "embedding_conv.weight", "seperate_conv.weight",
+             "dynamic_seghead.layer1.conv1.weight", "dynamic_seghead.conv.weight"]
+    params = dict(model.named_parameters())
+    out = {}
+    for nme in names:
+        out["t_grad::" + nme] = params[nme].grad.clone()
+    out.update(t_x=x3, t_ref_lab=ref_lab, t_prev_lab=prev_lab, t_logits=logits.detach(), t_wl=wl, t_nobj=nobj, t_knn=3,
+               t_grad_names=np.array(names))
+    save("grad_step_alt", **out, **sd0)
+
+
 def variant_rough_roi():
     """The caller-side labelling rule of the first interaction round (test.py:229-230 -> rough_ROI, test.py:323-343): what the
     bank `prop_seghead` matches against really holds.  test.py itself cannot be imported here (davisinteractive, cv2, ... at
@@ -497,6 +542,7 @@ VARIANTS = {
     "rough_roi": variant_rough_roi,
     "grad_knn": variant_grad_knn,
     "grad_ds0": variant_grad_ds0,
+    "grad_step_alt": variant_grad_step_alt,
 }
 
 if __name__ == "__main__":

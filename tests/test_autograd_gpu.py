@@ -138,6 +138,33 @@ def test_training_step_through_forward_matches_reference(ops, g):
         np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4 * max(np.abs(want).max(), 1e-6))
 
 
+def test_training_step_outside_the_defaults_matches_reference(ops):
+    """the same step with k_nearest_neighbors = 3 and MODEL_LOCAL_DOWNSAMPLE False (r5: both raised before): logits and parameter
+    gradients of the reference's own run (tests/golden/grad_step_alt.npz)"""
+    from cvpr2020_manet_amd.config import make_cfg
+    from cvpr2020_manet_amd.networks import IntVOS as M
+    g = load_golden("grad_step_alt")
+    cfg = make_cfg(["--TEST_MODE", "False", "--MODEL_SEMANTIC_EMBEDDING_DIM", "12", "--MODEL_HEAD_EMBEDDING_DIM", "8",
+                    "--MODEL_ASPP_OUTDIM", "6", "--MODEL_MAX_LOCAL_DISTANCE", "2", "--MODEL_LOCAL_DOWNSAMPLE", "False"])
+    model = M.IntVOS(cfg, TinyExtractor())
+    sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd::")}
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    nobj, knn = int(g["t_nobj"]), int(g["t_knn"])
+    dic = model.forward(dev(g["t_x"]), dev(g["t_ref_lab"]), dev(g["t_prev_lab"]), seq_names=["clip"],
+                        gt_ids=torch.Tensor([nobj]), k_nearest_neighbors=knn, global_map_tmp_dic=None,
+                        local_map_dics=None, interaction_num=1, start_annotated_frame=0, frame_num=[2])
+    logits = dic["clip"]
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["t_logits"], rtol=1e-3, atol=1e-4)
+    (logits * dev(g["t_wl"])).sum().backward()
+    params = dict(model.named_parameters())
+    for name in g["t_grad_names"].tolist():
+        want = g["t_grad::" + name]
+        got = params[name].grad.cpu().numpy()
+        assert np.abs(got).max() > 0
+        np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4 * max(np.abs(want).max(), 1e-6))
+
+
 def _corr_reference(a, b, pad, K, md, s1, s2):
     """differentiable torch restatement of the correlation_package forward contract (correlation_cuda_kernel.cu:73-147)"""
     B, C, H, W = a.shape
