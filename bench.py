@@ -704,6 +704,14 @@ def e2e_block(device, args):
     out["bf16r_match_masks_equal_f32"] = bool(res["mask_digest"] == f32["mask_digest"])
     del clip
     torch.cuda.empty_cache()
+    # a whole interactive session as test.py runs it (8 rounds on one sequence: round 1 on the roi bank, rounds 2-8 on new strokes
+    # alone -- rough_ROI applies `if first_scribble` only, test.py:229 -- with the global / local memories carried over)
+    res, clip, final = pc.run_single(pc.parse_args(base + ["--bank", "roi", "--session", "8"]), device, pointwise="f32")
+    out["session"] = {k: res[k] for k in ("session_rounds", "session_ms_per_round", "session_frames_per_s", "session_mask_digest",
+                                          "session_repeatable")}
+    out["value_session_8_rounds"] = res["session_frames_per_s"]
+    del clip
+    torch.cuda.empty_cache()
     out["value_scribble_bank"] = out["banks"]["scribble"]["eager_frames_per_s"]
     out["value_bank_frames_5"] = out["banks"]["roi_T5"]["eager_frames_per_s"]
     out["value_full_bank_frames_5"] = out["banks"]["full_T5"]["eager_frames_per_s"]
@@ -829,7 +837,7 @@ def compact_line(full):
     e = full.get("e2e")
     if e:
         ek = ("value", "value_graph", "value_two_streams", "value_scribble_bank", "value_bank_frames_5",
-              "value_full_bank_frames_5", "value_bf16r_match", "bf16r_match_masks_equal_f32", "bank", "bank_rows",
+              "value_full_bank_frames_5", "value_session_8_rounds", "value_bf16r_match", "bf16r_match_masks_equal_f32", "bank", "bank_rows",
               "masks_equal_eager_graph_two_streams")
         ce = {k: e[k] for k in ek if k in e}
         w = e.get("workload") or ""

@@ -313,6 +313,49 @@ class Clip:
             return masks
         return torch.cat([masks[i][0] for i in range(self.F)], 0)
 
+    def session(self, n_rounds, timed=True):
+        """An interactive SESSION as test.py:100-310 runs it: `n_rounds` interaction rounds on one sequence with the memories
+        carried over.  Round 1: scribbles on the middle frame, `rough_ROI` bank (test.py:229-230).  Round r > 1: new scribbles on
+        another frame, the interaction head also sees the previous round's mask of that frame (first_inter=False,
+        test.py:200-208), the bank is the new strokes ALONE (rough_ROI applies `if first_scribble` only), the global maps are
+        min-merged with the earlier rounds' (IntVOS.py:615-622), the local maps compete by their distance to the annotated
+        frame (:638-661).  Returns (masks of the last round [F,H,W], [seconds per round])."""
+        model, cfg = self.model, self.cfg
+        gmap, lmaps = {}, ({}, {})
+        storage = torch.zeros((self.F, self.H, self.W), dtype=torch.int64, device=self.dev)
+        times = []
+        for r in range(1, n_rounds + 1):
+            start = self.start if r == 1 else (self.start + (r - 1) * (self.F // 3) + 1) % self.F
+            sc = self.scribble if r == 1 else torch.roll(self.scribble, shifts=(5 * r, 9 * r), dims=(2, 3))
+            if timed:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            ref = self.emb[start:start + 1]
+            prev_round = None if r == 1 else storage[start][None, None]
+            tmp, lmaps = model.int_seghead(ref_frame_embedding=ref, ref_scribble_label=sc, prev_round_label=prev_round,
+                                           global_map_tmp_dic=gmap, local_map_dics=lmaps, interaction_num=r, seq_names=[SEQ],
+                                           gt_ids=self.gt, frame_num=[start], first_inter=(r == 1))
+            ref_label = self.mask_step(tmp[SEQ]).unsqueeze(0)
+            storage[start] = ref_label[0, 0]
+            bank_label = rough_ROI(sc) if r == 1 else sc
+            for order in (range(start + 1, self.F), range(start - 1, -1, -1)):
+                prev_label, prev_emb = ref_label, ref
+                for ii in order:
+                    cur = self.emb[ii:ii + 1]
+                    tmp, gmap, lmaps = model.prop_seghead(ref, prev_emb, cur, bank_label, prev_label,
+                                                          normalize_nearest_neighbor_distances=True, use_local_map=True,
+                                                          seq_names=[SEQ], gt_ids=self.gt, k_nearest_neighbors=cfg.KNNS,
+                                                          global_map_tmp_dic=gmap, local_map_dics=lmaps, interaction_num=r,
+                                                          start_annotated_frame=start, frame_num=[ii],
+                                                          dynamic_seghead=model.dynamic_seghead)
+                    prev_label = self.mask_step(tmp[SEQ]).unsqueeze(0)
+                    prev_emb = cur
+                    storage[ii] = prev_label[0, 0]
+            if timed:
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+        return storage.clone(), times
+
     def one_round_two_streams(self):
         """The same round with the two independent halves of the chain -- forwards and backwards from the annotated frame -- on
         TWO HIP streams of this one GPU, issued alternately frame by frame: a propagated frame is ~20 launches of which a
@@ -465,6 +508,13 @@ def run_single(args, dev, pointwise=None, want_graph=False, want_stages=False, b
             tdt = (time.perf_counter() - t0) / args.rounds
             res.update({"two_streams_ms_per_round": tdt * 1e3, "two_streams_frames_per_s": (args.frames - 1) / tdt,
                         "two_streams_masks_equal_eager": bool(torch.equal(tfinal, final))})
+        if getattr(args, "session", 0):
+            clip.session(min(args.session, 2), timed=False)  # warm-up: both kinds of round
+            smask, times = clip.session(args.session)
+            again, _ = clip.session(args.session, timed=False)
+            res.update({"session_rounds": args.session, "session_ms_per_round": [t * 1e3 for t in times],
+                        "session_frames_per_s": args.session * (args.frames - 1) / sum(times),
+                        "session_mask_digest": mask_digest(smask), "session_repeatable": bool(torch.equal(smask, again))})
         if want_graph:
             ground = clip.graph_round_fn()
             ground()
@@ -600,6 +650,9 @@ def parse_args(argv=None):
     ap.add_argument("--bank-frames", type=int, default=1,
                     help="annotated frames stacked into the bank (5 = the metric's 5-frame memory)")
     ap.add_argument("--rounds", type=int, default=1, help="timed interaction rounds (after one warm-up round)")
+    ap.add_argument("--session", type=int, default=0,
+                    help="also run a whole interactive session of this many rounds (test.py:100-310: round 1 on the rough_ROI "
+                         "bank, later rounds on new strokes alone with the memories carried over); the reference runs 8")
     ap.add_argument("--two-streams", action="store_true",
                     help="also time the round with the forward and the backward half of the chain on two HIP streams")
     ap.add_argument("--stages", action="store_true", help="per-stage microseconds of a propagated frame (HIP events)")
@@ -655,6 +708,10 @@ def main():
                   "eager loop's; host work per frame: 1 graph launch + 5 small copies instead of one launch per kernel"
                   % (res["graph_ms_per_round"], res["graph_frames_per_s"], res["eager_frames_per_s"],
                      "identical to" if res["graph_masks_equal_eager"] else "DIFFER from"))
+        if args.session:
+            print("session of %d interaction rounds (round 1: rough_ROI bank, then strokes alone, memories carried over): %s ms per "
+                  "round, %.1f frames/s over the session" % (args.session, ", ".join("%.1f" % t for t in res["session_ms_per_round"]),
+                                                             res["session_frames_per_s"]))
         if args.two_streams:
             print("forward and backward halves of the chain on two HIP streams: %.1f ms per round, %.1f frames/s (one stream %.1f); "
                   "masks %s the one-stream loop's" % (res["two_streams_ms_per_round"], res["two_streams_frames_per_s"],

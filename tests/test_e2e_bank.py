@@ -93,3 +93,20 @@ def test_roi_bank_masks_follow_the_module_functions():
         want = (torch.sigmoid(want) - 0.5) * 2
     assert ids.tolist() == [0, 1, 2]
     torch.testing.assert_close(gmap[pc.SEQ][ii].reshape(-1), want.reshape(-1), rtol=0, atol=2e-7)
+
+
+@pytest.mark.gpu
+def test_session_of_several_rounds_is_repeatable_and_uses_both_banks():
+    """examples/propagate_clip.py --session: round 1 on the rough_ROI bank, later rounds on new strokes alone, memories carried over
+    (test.py:100-310).  The session is deterministic (two runs: the same masks), its first round costs more than the later ones
+    (17 000 bank rows against ~1 000), and a later round really depends on the memories (its masks differ from a fresh round's)."""
+    from examples import propagate_clip as pc
+    dev = torch.device("cuda", 0)
+    args = pc.parse_args(["--frames", "9", "--fused-mask-step", "--session", "3"])
+    res, clip, final = pc.run_single(args, dev)
+    assert res["session_rounds"] == 3 and res["session_repeatable"] is True and len(res["session_ms_per_round"]) == 3
+    assert res["session_ms_per_round"][0] > res["session_ms_per_round"][2]
+    with torch.no_grad():
+        m3, _ = clip.session(3, timed=False)
+        m1, _ = clip.session(1, timed=False)
+    assert tuple(m3.shape) == (9, 480, 854) and not torch.equal(m3, m1)
