@@ -95,6 +95,7 @@ constexpr int REFINE_DENSE_LANES = MANET_REFINE_DENSE_LANES;  // (64: off; smoot
 #define MANET_REFINE_RZ 4
 #endif
 constexpr int REFINE_RZ = MANET_REFINE_RZ;  // workgroups of the re-rank launch per bucket: each takes every 4th entry (the longest bucket is the launch's time)
+constexpr int ONE_ROUND_OK = 1 << 29;   // block_map flag (fp32 pipe kernel): the device may swap the host's splits for ONE round of long ones
 constexpr int RESCUE_LISTED = 1 << 30;  // block_map flag of the rescue launch: deal the workgroups to the LISTED tiles
 
 // Packed operand image of one row block: `units` 16-byte units per row, stored [unit][row][16 B].
@@ -901,8 +902,24 @@ constexpr int FILTER_TAIL_CUTS = MANET_FILTER_TAIL_CUTS;  // (1: bm == 3's map)
 __device__ __forceinline__ bool split_of_block(int b, int nQT, int S, int T, int block_map, int &qt, int &s, int &t0,
                                                int &t1)
 {
-    const int bm = block_map & 0xff, small_S = block_map >> 8;
-    if (T < S && small_S > 0) {
+    const int bm = block_map & 0xff, small_S = (block_map >> 8) & 0x1fff;
+    bool one_round = T < S && small_S > 0;
+    if (!one_round && (block_map & ONE_ROUND_OK) && small_S > 0 && small_S < S) {
+        // r5.  The host sizes S from the bank's UPPER-bound tile count (it cannot know how many rows are labelled without a
+        // sync) for many rounds of short splits; a workgroup's fixed cost (query operand, pipeline fill, closing atomics) is
+        // worth ~0.6 tile-times after the overlap of two workgroups per CU.  With the REAL tile count: cost of the host's
+        // choice = its rounds over the 512 slots (a last round at most half full counts half, as in pick_splits) x (tiles per
+        // split + 0.6) against ONE round of small_S = floor(512 / query tiles) long splits.  The reference driver's first-round
+        // bank (rough_ROI: ~17 000 rows = 268 tiles at 480p) ran 48 splits of 5.6 tiles: 673 us; one round of 5 x 54: 633.
+        // Banks above ~600 tiles keep the host's choice (a tie there, and the XCD-aware map).  Same bits either way.
+        const float rounds = (float)nQT * (float)S / 512.0f;
+        const float whole = floorf(rounds), frac = rounds - whole;
+        const float last = frac <= 0.0f ? 0.0f : (frac <= 0.5f ? 0.5f : 1.0f);
+        const float cost_host = (whole + last) * ((float)T / (float)S + 0.6f);
+        const float cost_one = ceilf((float)T / (float)small_S) + 0.6f;
+        one_round = cost_one < 0.97f * cost_host;
+    }
+    if (one_round) {
         const int S2 = small_S < T ? small_S : T;
         qt = b % nQT;
         s = b / nQT;
@@ -2874,8 +2891,9 @@ void launch_main_f32_pipe(const char *qpack, const char *bpack, const int *meta,
     (void)hipFuncSetAttribute((const void *)global_match_f32_pipe_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     manet_profile_record(st, true);
+    const int one_round = manet_tune_get(MANET_TUNE_ONE_ROUND, 0) == 1 ? 0 : ONE_ROUND_OK;  // (1: the host's splits always, A/B timing)
     hipLaunchKernelGGL((global_match_f32_pipe_kernel<KS>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack, bpack, meta,
-                       n_ids, nQT, S, N_pad, keys, block_map_arg(nQT, 512, S), (const unsigned *)nullptr, 0L);
+                       n_ids, nQT, S, N_pad, keys, block_map_arg(nQT, 512, S) | one_round, (const unsigned *)nullptr, 0L);
     manet_profile_record(st, false);
 }
 

@@ -320,3 +320,28 @@ def test_hip_graph_capture_of_a_propagated_frame(ops):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(g, eager_g) and torch.equal(l, eager_l)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [300, 6000, 17035, 25680])
+def test_device_side_split_decision_gives_the_same_bits(rows, monkeypatch):
+    """r5: for small / mid-size banks the fp32 kernel swaps the host's many short splits (sized from the bank's upper-bound tile
+    count) for ONE round of long ones (split_of_block); a minimum is order-independent: the results are the host-split run's bits"""
+    monkeypatch.setenv("MANET_TUNING", "1")
+    import torch
+    from cvpr2020_manet_amd import _lib, ops
+    lib = _lib.load()
+    torch.manual_seed(rows)
+    C, H, W = 100, 120, 214
+    q = torch.relu(torch.randn(H, W, C, device="cuda")) * 0.1
+    bank = torch.relu(torch.randn(H * W, C, device="cuda")) * 0.1
+    lab = torch.full((H * W,), -1, dtype=torch.int32, device="cuda")
+    idx = torch.randperm(H * W, device="cuda")[:rows]
+    lab[idx] = torch.randint(0, 3, (rows,), device="cuda", dtype=torch.int32)
+    pb = ops.PreparedBank(bank, lab, 3)
+    try:
+        assert lib.manet_tune_set(10, 1) == 0
+        host = pb.match(q, normalize=True)
+    finally:
+        lib.manet_tune_set(10, -2 ** 31)
+    assert torch.equal(pb.match(q, normalize=True), host)
