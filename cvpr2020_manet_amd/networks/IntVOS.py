@@ -305,26 +305,39 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         x = self.relu2(self.bn2(self.conv2(x)))
         return x
 
-    def forward_shared(self, shared, per_object, defer_relu=False):
+    def forward_shared(self, shared, per_object, defer_relu=False, memo=None):
         """The block applied to cat([shared repeated n times, per_object], 1) without building that tensor
         (IntVOS.py:665-670 repeats the C-channel embedding once per object): the depthwise stage and the
         1x1 stage are linear in the channel groups, so the shared group is processed once.
-        shared [1, Cs, h, w], per_object [n, Cp, h, w], Cs + Cp == in_dim."""
+        shared [1, Cs, h, w], per_object [n, Cp, h, w], Cs + Cp == in_dim.
+        memo (r5): a one-slot holder {"k": folded constants, "term": tensor} of the SHARED half's contribution
+        conv2'(dw(shared)) -- it depends on the frame's embedding and the layer's parameters only, not on objects, labels or
+        the interaction round, so a caller that sees the same frame again (every round of a session walks the same clip)
+        hands the holder back and the shared depthwise + 1x1 launches are skipped.  Valid while `k` is the SAME folded-constant
+        object (a parameter change re-folds and drops it)."""
         cs = shared.shape[1]
         k = self._folded(cs)
         scale, shift = k["scale1"], k["shift1"]
         w1, b1 = self.conv1.weight, self.conv1.bias
-        s1 = ops.dwconv7x7_bn_relu(shared, w1[:cs], b1[:cs], scale=scale[:cs], shift=shift[:cs])
         p1 = ops.dwconv7x7_bn_relu(per_object, w1[cs:], b1[cs:], scale=scale[cs:], shift=shift[cs:])
-        if "sw_object" in k and ops.conv1x1_split_ok(p1, self.conv2.out_channels):
+        split = "sw_object" in k and ops.conv1x1_split_ok(p1, self.conv2.out_channels)
+        mfma = not split and "w2t_object" in k and ops.conv1x1_mfma_ok(p1, self.conv2.out_channels)
+        term = None
+        if memo is not None and memo.get("k") is k and (split or mfma):
+            term = memo.get("term")
+        if term is None:
+            s1 = ops.dwconv7x7_bn_relu(shared, w1[:cs], b1[:cs], scale=scale[:cs], shift=shift[:cs])
+            if split:
+                term = ops.conv1x1_split(s1, k["sw_shared"], k["b2_zero"])
+            elif mfma:
+                term = ops.conv1x1_mfma(s1, k["w2t_shared"], k["b2_zero"])
+            if memo is not None and term is not None:
+                memo["k"], memo["term"] = k, term
+        if split:
             # the shared half once, then the per-object half with it added in the epilogue (no broadcast-add pass)
-            zero = k["b2_zero"]
-            return ops.conv1x1_split(p1, k["sw_object"], k["b2"], relu_out=not defer_relu,
-                                     add=ops.conv1x1_split(s1, k["sw_shared"], zero))
-        if "w2t_object" in k and ops.conv1x1_mfma_ok(p1, self.conv2.out_channels):  # the same form on the fp32 matrix pipe
-            zero = k["b2_zero"]
-            return ops.conv1x1_mfma(p1, k["w2t_object"], k["b2"], relu_out=not defer_relu,
-                                    add=ops.conv1x1_mfma(s1, k["w2t_shared"], zero))
+            return ops.conv1x1_split(p1, k["sw_object"], k["b2"], relu_out=not defer_relu, add=term)
+        if mfma:  # the same form on the fp32 matrix pipe
+            return ops.conv1x1_mfma(p1, k["w2t_object"], k["b2"], relu_out=not defer_relu, add=term)
         y = self._pointwise(p1, k, "object", True, False)
         y += self._pointwise(s1, k, "shared", False, False)  # broadcast over the objects
         return y if defer_relu else y.relu_()
@@ -361,21 +374,23 @@ class DynamicSegHead(nn.Module):  # reference IntVOS.py:509-525
             return self._tail(self.layer1(x))
         return self.conv(self.layer4(self.layer3(self.layer2(self.layer1(x)))))
 
-    def forward_shared(self, shared, per_object):
-        """forward(cat([shared.repeat(n,1,1,1), per_object], 1)) without materialising the input"""
-        return self._tail(self.layer1.forward_shared(shared, per_object))
+    def forward_shared(self, shared, per_object, memo=None):
+        """forward(cat([shared.repeat(n,1,1,1), per_object], 1)) without materialising the input; memo: see
+        _split_separable_conv2d.forward_shared"""
+        return self._tail(self.layer1.forward_shared(shared, per_object, memo=memo))
 
 
-def _run_head(head, embedding_chw, per_object):
+def _run_head(head, embedding_chw, per_object, memo=None):
     """head(cat([embedding repeated per object, per_object], 1)) (IntVOS.py:665-671, :741-758).  In
     inference on the GPU a DynamicSegHead takes the shared-embedding route (no repeat / cat of the C-channel
-    embedding, depthwise stage of those channels computed once); otherwise the reference's literal form."""
+    embedding, depthwise stage of those channels computed once); otherwise the reference's literal form.
+    memo: the frame's holder of layer 1's shared-half term (IntVOS._head_memo), or None."""
     n = per_object.shape[0]
     if embedding_chw.dtype != torch.float32:  # 2-byte embeddings (MODEL_EMB_DTYPE bf16): the head computes in fp32
         embedding_chw = embedding_chw.float()
     if (isinstance(head, DynamicSegHead) and not head.training and not torch.is_grad_enabled()
             and embedding_chw.is_cuda and embedding_chw.dtype == torch.float32):
-        return head.forward_shared(embedding_chw.unsqueeze(0), per_object)
+        return head.forward_shared(embedding_chw.unsqueeze(0), per_object, memo=memo)
     return head(torch.cat((embedding_chw.unsqueeze(0).repeat((n, 1, 1, 1)), per_object), 1))
 
 
@@ -551,6 +566,22 @@ class IntVOS(nn.Module):
             while len(self._frame_cache) > self._frame_cache_cap:
                 self._frame_cache.popitem(last=False)
         return frame, preset is not None
+
+    def _head_memo(self, emb_chw, head):
+        """Holder of `head`.layer1's shared-half term for this frame (r5), or None.  It lives on the frame's entry of the
+        frame cache -- same identity key (storage pointer, shape, strides, version counter), same lifetime, same opt-in: with
+        the default 8-frame cache a clip's frames are evicted before the next round comes back to them; a driver that took
+        `prepare_clip` / `extract_feature(packed=True)` keeps every frame and from the second round on skips two launches per
+        propagated frame (the shared depthwise + its 1x1: 35 us of a 1 260 us frame at 480p; 26 MB per 480p frame kept).
+        Nothing is kept inside a HIP-graph capture or for tensors without a version counter."""
+        if not self.cache_frames or torch.cuda.is_current_stream_capturing():
+            return None
+        key = self._frame_key(emb_chw, self._local_radius())
+        fr = self._frame_cache.get(key) if key is not None else None
+        if fr is None:
+            return None
+        memos = fr.__dict__.setdefault("head_memos", {})
+        return memos.setdefault(id(head), {})
 
     def prepare_clip(self, embeddings, batch=16):
         """Optional, for drivers that hold a clip's embeddings in one tensor (test.py:143-154 `embedding_memory`):
@@ -876,7 +907,8 @@ class IntVOS(nn.Module):
                 to_cat_previous_frame = to_cat_previous_frame.unsqueeze(-1).permute(2, 3, 0, 1).float()
                 to_cat_prev_frame_nn_feature_n = prev_frame_nn_features_n.squeeze(0).permute(2, 3, 0, 1)
                 per_object = torch.cat((to_cat_nn_feature_n, to_cat_prev_frame_nn_feature_n, to_cat_previous_frame), 1)
-            pred_ = _run_head(dynamic_seghead, current_frame_embedding[n], per_object)
+            pred_ = _run_head(dynamic_seghead, current_frame_embedding[n], per_object,
+                              memo=self._head_memo(current_frame_embedding[n], dynamic_seghead) if inference else None)
             dic_tmp[seq_names[n]] = pred_.permute(1, 0, 2, 3)
 
         if global_map_tmp_dic is None:
@@ -943,7 +975,9 @@ class IntVOS(nn.Module):
                 to_cat_prev_round_to_cat = torch.zeros_like(to_cat_scribble_mask_to_cat)
                 to_cat_prev_round_to_cat[0] = 1.0
             per_object = torch.cat((to_cat_scribble_mask_to_cat, to_cat_prev_round_to_cat), 1)
-            pred_ = _run_head(self.inter_seghead, ref_frame_embedding[n], per_object)
+            pred_ = _run_head(self.inter_seghead, ref_frame_embedding[n], per_object,
+                              memo=self._head_memo(ref_frame_embedding[n], self.inter_seghead)
+                              if (ref_frame_embedding.is_cuda and not torch.is_grad_enabled()) else None)
             dic_tmp[seq_names[n]] = pred_.permute(1, 0, 2, 3)
         if local_map_dics is None:
             return dic_tmp

@@ -110,3 +110,45 @@ def test_session_of_several_rounds_is_repeatable_and_uses_both_banks():
         m3, _ = clip.session(3, timed=False)
         m1, _ = clip.session(1, timed=False)
     assert tuple(m3.shape) == (9, 480, 854) and not torch.equal(m3, m1)
+
+
+@pytest.mark.gpu
+def test_shared_half_of_head_layer1_is_memoised_per_frame_and_follows_parameter_updates():
+    """r5: layer 1's shared-embedding half (depthwise of the 100 embedding channels + its 1x1) depends on the frame and the
+    layer's parameters only: kept on the frame's cache entry, reused by every later round, dropped when a parameter changes"""
+    from examples import propagate_clip as pc
+    from cvpr2020_manet_amd import ops
+    dev = torch.device("cuda", 0)
+    args = pc.parse_args(["--frames", "5", "--fused-mask-step", "--height", "240", "--width", "428"])
+    cfg, model = pc.build_model(dev, None, None, None)
+    with torch.no_grad():
+        emb = pc.synthetic_clip(model, dev, args.frames, args.height, args.width, args.objects, packed=True)
+        clip = pc.Clip(cfg, model, emb, args.height, args.width, args.objects)
+        lg1, lg2, lg3 = {}, {}, {}
+        clip.one_round(keep_logits=lg1)
+        memos = [fr.__dict__.get("head_memos") for fr in model._frame_cache.values()]
+        assert sum(1 for m in memos if m) == args.frames  # every frame carries a term (the annotated one the interaction head's)
+        calls = {"n": 0}
+        real = ops.dwconv7x7_bn_relu
+
+        def counting(x, *a, **k):
+            calls["n"] += int(x.shape[0] == 1 and x.shape[1] == 100)  # the shared-half depthwise launches
+            return real(x, *a, **k)
+        ops.dwconv7x7_bn_relu = counting
+        try:
+            clip.one_round(keep_logits=lg2)
+            assert calls["n"] == 0                                    # second round: all hits
+            for k in lg1:
+                assert torch.equal(lg1[k], lg2[k])
+            model.dynamic_seghead.layer1.conv2.weight.mul_(1.25)      # in place: the folded constants are rebuilt
+            clip.one_round(keep_logits=lg3)
+            assert calls["n"] == args.frames - 1                      # ... and every term with them
+        finally:
+            ops.dwconv7x7_bn_relu = real
+        fresh_cfg, fresh = pc.build_model(dev, None, None, None)
+        fresh.load_state_dict(model.state_dict())
+        clip2 = pc.Clip(fresh_cfg, fresh, emb, args.height, args.width, args.objects)
+        want = {}
+        clip2.one_round(keep_logits=want)
+        for k in want:
+            assert torch.equal(lg3[k], want[k])
