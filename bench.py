@@ -662,7 +662,7 @@ def e2e_block(device, args):
     memory (`value_bank_frames_5`: five annotated frames stacked, each through rough_ROI) beside it.  Head = the exact-fp32 1x1
     kernels (the module's default); the split-bf16 forms beside it with their max |logit| deviation from the fp32 head."""
     from examples import propagate_clip as pc
-    base = ["--frames", str(args.e2e_frames), "--fused-mask-step"]
+    base = ["--frames", str(args.e2e_frames), "--fused-mask-step", "--rounds", "3"]  # (3 timed rounds: an eager round is 40 ms)
     out = {"workload": "examples/propagate_clip.py: %d-frame synthetic 480x854 clip (grid 120x214), 2 objects, bank = 1 annotated frame "
                        "through rough_ROI (test.py:229-230), fp32 match + exact fp32 head, d=12, int_seghead + prop_seghead + "
                        "upsample/argmax per frame; encoder untimed" % args.e2e_frames,
