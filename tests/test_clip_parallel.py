@@ -178,3 +178,40 @@ def test_all_gather_clip_and_gather_frame_rows_gloo(world, F, bf16):
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(world))
     assert res == [(r, True) for r in range(world)]
+
+
+@pytest.mark.gpu
+def test_collectives_over_rccl_with_one_rank():
+    """The three collectives of the N-GPU flows on DEVICE tensors over the real backend ("nccl" = RCCL) with a single rank -- all a
+    1-GPU box can offer: process-group init with device_id, all_gather_into_tensor of byte slabs (bank + halo, clip), dist.gather /
+    all_gather of float rows, the device-event timing paths.  (N > 1 over RCCL needs a multi-GPU node: tools/preflight_multigpu.sh.)"""
+    import subprocess
+    import sys
+    code = r'''
+import os, torch, torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="%d", RANK="0", WORLD_SIZE="1")
+from cvpr2020_manet_amd import clip_parallel as cp
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+g = torch.Generator(device=dev).manual_seed(3)
+F, C, h, w = 6, 100, 24, 30
+emb = torch.relu(torch.randn(F, C, h, w, generator=g, device=dev))
+lab = torch.randint(-1, 3, (F, h, w), generator=g, device=dev, dtype=torch.int32)
+bank = [0, 3, 5]
+be, bl, halo = cp.exchange_bank_and_halo(emb, 0, bank, {f: lab[f] for f in bank}, F, ownership="round_robin", timing=True)
+assert torch.equal(be, emb[bank]) and torch.equal(bl, lab[bank]) and halo is None
+assert cp.LAST_EXCHANGE["backend"] == "nccl" and cp.LAST_EXCHANGE["allgather_clock"] == "device events" and cp.LAST_EXCHANGE["allgather_ms"] >= 0
+clip = cp.all_gather_clip(emb.bfloat16(), F)
+assert clip.dtype == torch.bfloat16 and torch.equal(clip, emb.bfloat16())
+rows = torch.randn(F, 77, generator=g, device=dev)
+for dst in (0, None):
+    got = cp.gather_frame_rows(rows, F, dst=dst, timing=True)
+    assert torch.equal(got, rows) and cp.LAST_GATHER["gather_clock"] == "device events" and cp.LAST_GATHER["backend"] == "nccl"
+dist.destroy_process_group()
+print("rccl one rank ok")
+''' % _free_port()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "rccl one rank ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
