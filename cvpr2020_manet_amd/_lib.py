@@ -54,6 +54,7 @@ SIGNATURES = {
     "manet_local_match_ex": (_i, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i, _vp, _i, _i, _i, _i, _i, _i, _vp,
                                   _vp, _sz, _vp]),
     "manet_global_match_arg_workspace_bytes": (_i, [_i64, _i64, _i, _i, _szp]),
+    "manet_head_layer1_object_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "manet_local_match_full_arg_f32": (_i, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp,
                                             _vp]),
     "manet_local_match_full_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

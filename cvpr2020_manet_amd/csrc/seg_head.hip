@@ -849,7 +849,94 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// DynamicSegHead layer 1, PER-OBJECT half, fused (r5): the head-input assembly (IntVOS.py:663-669) -> the depthwise 7x7 + bn1 + relu1 of
+// the three per-object channels (:491-493) -> their 1x1 (3 -> 256, bn2 folded, :494) + the shared-embedding half's term + relu2, ONE
+// launch instead of three (head_inputs_kernel 3 us + dwconv [n,3,h,w] 11 us, launch-sized + conv1x1_mfma K = 3 22 us at 480p):
+//   in_0 = global map of object o, in_1 = local map of o, in_2 = (label == o)                      (zero outside the image)
+//   d_c  = relu(fmaf(taps_c + b1[c], scale1[c], shift1[c])),  taps_c = the depthwise kernel's fmaf chain (ky outer, kx inner)
+//   out[o][co][p] = relu?((fmaf(w2[2][co], d_2, fmaf(w2[1][co], d_1, fmaf(w2[0][co], d_0, 0))) + b2[co]) + term[co][p])
+// -- operation for operation what dwconv7x7_bn_relu_kernel and conv1x1_mfma_kernel (a k-ascending fmaf chain from zero, bias, `add`,
+// ReLU) compute on head_inputs_kernel's channels: the same bits.  A stream: reads the term once per object (26 MB each, L2-shared
+// between the objects' workgroups of a tile), writes the [n,256,h,w] activation once.
+constexpr int L1_TH = 4, L1_TW = 32, L1_NT = L1_TH * L1_TW, L1_LW = L1_TW + 6 + 1;
+__global__ __launch_bounds__(L1_NT) void head_layer1_object_kernel(const float *__restrict__ gmap, const float *__restrict__ lmap,
+                                                                   const int *__restrict__ labels, int h, int w, int n_ids,
+                                                                   const float *__restrict__ w1, const float *__restrict__ b1,
+                                                                   const float *__restrict__ sc1, const float *__restrict__ sh1,
+                                                                   const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                   const float *__restrict__ term, int relu_out,
+                                                                   float *__restrict__ out)
+{
+    __shared__ float tin[3][L1_TH + 6][L1_LW];
+    __shared__ __attribute__((aligned(16))) float wtab[PW_CO][4];  // {w2[0][co], w2[1][co], w2[2][co], b2[co]}
+    const int tid = threadIdx.x, o = blockIdx.z;
+    const int x0 = blockIdx.x * L1_TW, y0 = blockIdx.y * L1_TH;
+    for (int i = tid; i < (L1_TH + 6) * (L1_TW + 6); i += L1_NT) {
+        const int r = i / (L1_TW + 6), c = i - r * (L1_TW + 6);
+        const int yy = y0 - 3 + r, xx = x0 - 3 + c;
+        float g = 0.0f, l = 0.0f, m = 0.0f;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+            const long p = (long)yy * w + xx;
+            g = gmap[p * n_ids + o];
+            l = lmap[p * n_ids + o];
+            m = labels[p] == o ? 1.0f : 0.0f;
+        }
+        tin[0][r][c] = g;
+        tin[1][r][c] = l;
+        tin[2][r][c] = m;
+    }
+    for (int i = tid; i < PW_CO; i += L1_NT) {
+        wtab[i][0] = w2[i];
+        wtab[i][1] = w2[PW_CO + i];
+        wtab[i][2] = w2[2 * PW_CO + i];
+        wtab[i][3] = b2[i];
+    }
+    __syncthreads();
+    const int ty = tid / L1_TW, tx = tid - ty * L1_TW;
+    float d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < DW_K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < DW_K; ++kx) acc = fmaf(tin[c][ty + ky][tx + kx], w1[c * DW_K * DW_K + ky * DW_K + kx], acc);
+        d[c] = fmaxf(fmaf(acc + (b1 ? b1[c] : 0.0f), sc1 ? sc1[c] : 1.0f, sh1 ? sh1[c] : 0.0f), 0.0f);
+    }
+    const int y = y0 + ty, x = x0 + tx;
+    if (y >= h || x >= w) return;
+    const long HW = (long)h * w, p = (long)y * w + x;
+    const float *tp = term + p;
+    float *dst = out + (long)o * PW_CO * HW + p;
+#pragma unroll 8
+    for (int co = 0; co < PW_CO; ++co) {
+        const f32x4 t = *(const f32x4 *)wtab[co];
+        float v = fmaf(t[2], d[2], fmaf(t[1], d[1], fmaf(t[0], d[0], 0.0f))) + t[3];
+        v += tp[(long)co * HW];
+        if (relu_out) v = fmaxf(v, 0.0f);
+        dst[(long)co * HW] = v;
+    }
+}
+
 }  // namespace
+
+/* DynamicSegHead layer 1, per-object half, fused (head_layer1_object_kernel): global_map / local_map [HW][n_ids] fp32, labels [HW]
+ * int32, the depthwise weights / bias / folded bn1 of the THREE per-object channels, w2t_object [3][256] + b2 [256] (bn2 folded),
+ * term [256][HW] = the shared-embedding half's contribution -> out [n_ids][256][HW]. */
+extern "C" int manet_head_layer1_object_f32(const float *global_map, const float *local_map, const int32_t *labels, int h, int w,
+                                            int n_ids, const float *dw_weight, const float *dw_bias, const float *bn_scale,
+                                            const float *bn_shift, const float *w2t_object, const float *b2, const float *term,
+                                            int relu_out, float *out, manet_stream_t stream)
+{
+    if (!global_map || !local_map || !labels || !dw_weight || !w2t_object || !b2 || !term || !out || h <= 0 || w <= 0 || n_ids <= 0 ||
+        n_ids > 65535)
+        return manet_set_error(MANET_E_INVALID, "bad arguments");
+    dim3 grid((unsigned)((w + L1_TW - 1) / L1_TW), (unsigned)((h + L1_TH - 1) / L1_TH), (unsigned)n_ids);
+    hipLaunchKernelGGL(head_layer1_object_kernel, grid, dim3(L1_NT), 0, (hipStream_t)stream, global_map, local_map, (const int *)labels,
+                       h, w, n_ids, dw_weight, dw_bias, bn_scale, bn_shift, w2t_object, b2, term, relu_out, out);
+    return manet_check_launch("manet_head_layer1_object_f32");
+}
 
 extern "C" int manet_relu_conv1x1_c1_f32(const float *in, int B, int C, long HW, const float *weight, const float *bias,
                                          int relu_in, float *out, manet_stream_t stream)

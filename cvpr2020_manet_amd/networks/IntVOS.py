@@ -343,6 +343,28 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         return y if defer_relu else y.relu_()
 
 
+def _layer1_fused(layer, shared, global_map, local_map, labels, n_ids, size, memo=None):
+    """`layer`.forward_shared on head_inputs(global_map, local_map, labels) in TWO launches less (r5): the shared-embedding half
+    as in forward_shared (memoised per frame), then ops.head_layer1_object -- input assembly + the per-object channels' depthwise
+    stage + their 1x1 + the shared term + ReLU in one launch.  Returns None when the layer is not on the exact-fp32 MFMA path (the
+    caller then takes the general route)."""
+    cs = shared.shape[1]
+    k = layer._folded(cs)
+    if k.get("mode") != "f32" or "w2t_object" not in k or layer.conv1.in_channels != cs + 3 or layer.conv2.out_channels != ops.PW_COUT:
+        return None
+    term = memo.get("term") if (memo is not None and memo.get("k") is k) else None
+    w1, b1 = layer.conv1.weight, layer.conv1.bias
+    if term is None:
+        s1 = ops.dwconv7x7_bn_relu(shared, w1[:cs], b1[:cs], scale=k["scale1"][:cs], shift=k["shift1"][:cs])
+        if not ops.conv1x1_mfma_ok(s1, layer.conv2.out_channels):
+            return None
+        term = ops.conv1x1_mfma(s1, k["w2t_shared"], k["b2_zero"])
+        if memo is not None:
+            memo["k"], memo["term"] = k, term
+    return ops.head_layer1_object(global_map, local_map, labels, n_ids, size, w1[cs:], None if b1 is None else b1[cs:],
+                                  k["scale1"][cs:], k["shift1"][cs:], k["w2t_object"], k["b2"], term, relu_out=True)
+
+
 class DynamicSegHead(nn.Module):  # reference IntVOS.py:509-525
     def __init__(self, in_dim=None, embed_dim=None, kernel_size=1):
         super().__init__()
@@ -896,9 +918,24 @@ class IntVOS(nn.Module):
                 local_map_dics = (local_map_tmp_dic, local_map_dist_dic)
 
             # ---- head input [n_ids, C+3, h, w] (:663-673)
-            if (inference and nn_features_n.is_cuda and nn_features_n.dtype == torch.float32
-                    and prev_frame_nn_features_n.dtype == torch.float32
-                    and nn_features_n.numel() == h * w * n_ids and prev_frame_nn_features_n.numel() == h * w * n_ids):
+            pred_ = None
+            native_maps = (inference and nn_features_n.is_cuda and nn_features_n.dtype == torch.float32
+                           and prev_frame_nn_features_n.dtype == torch.float32
+                           and nn_features_n.numel() == h * w * n_ids and prev_frame_nn_features_n.numel() == h * w * n_ids)
+            if (native_maps and isinstance(dynamic_seghead, DynamicSegHead) and not dynamic_seghead.training
+                    and dynamic_seghead.layer1.conv1.kernel_size == (7, 7) and (h * w) % 4 == 0):
+                # layer 1 straight from the two maps and the labels (r5): input assembly + per-object depthwise + its 1x1 + the
+                # (memoised) shared half + ReLU in one launch; layers 2-4 as ever
+                emb_f = current_frame_embedding[n]
+                emb_f = emb_f if emb_f.dtype == torch.float32 else emb_f.float()
+                x1 = _layer1_fused(dynamic_seghead.layer1, emb_f.unsqueeze(0), nn_features_n, prev_frame_nn_features_n,
+                                   seq_previous_frame_label, n_ids, (h, w),
+                                   memo=self._head_memo(current_frame_embedding[n], dynamic_seghead))
+                if x1 is not None:
+                    pred_ = dynamic_seghead._tail(x1)
+            if pred_ is not None:
+                pass
+            elif native_maps:
                 # the three per-object channels written by one launch (no arange / compare / permute / cat kernels)
                 per_object = ops.head_inputs(nn_features_n, prev_frame_nn_features_n, seq_previous_frame_label, n_ids, (h, w))
             else:
@@ -907,8 +944,9 @@ class IntVOS(nn.Module):
                 to_cat_previous_frame = to_cat_previous_frame.unsqueeze(-1).permute(2, 3, 0, 1).float()
                 to_cat_prev_frame_nn_feature_n = prev_frame_nn_features_n.squeeze(0).permute(2, 3, 0, 1)
                 per_object = torch.cat((to_cat_nn_feature_n, to_cat_prev_frame_nn_feature_n, to_cat_previous_frame), 1)
-            pred_ = _run_head(dynamic_seghead, current_frame_embedding[n], per_object,
-                              memo=self._head_memo(current_frame_embedding[n], dynamic_seghead) if inference else None)
+            if pred_ is None:
+                pred_ = _run_head(dynamic_seghead, current_frame_embedding[n], per_object,
+                                  memo=self._head_memo(current_frame_embedding[n], dynamic_seghead) if inference else None)
             dic_tmp[seq_names[n]] = pred_.permute(1, 0, 2, 3)
 
         if global_map_tmp_dic is None:

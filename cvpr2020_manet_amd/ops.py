@@ -681,6 +681,36 @@ def label_resize_nearest(mask, size):
     return out
 
 
+def head_layer1_object(global_map, local_map, labels, n_ids, size, dw_weight, dw_bias, bn_scale, bn_shift, w2t_object, b2, term,
+                       relu_out=True):
+    """DynamicSegHead layer 1, per-object half, in one launch (manet_head_layer1_object_f32): the per-object input channels
+    (IntVOS.py:663-669) -> depthwise 7x7 + bn1 + relu1 -> 1x1 (3 -> 256, bn2 folded) + `term` (the shared-embedding half,
+    [1, 256, h, w]) [+ relu2] -> [n_ids, 256, h, w].  The same bits as head_inputs + dwconv7x7_bn_relu + conv1x1_mfma(add=term)."""
+    _refuse_autograd("head_layer1_object", global_map, local_map, term)
+    lib = _lib.load()
+    _need_gpu(global_map, "global_map")
+    h, w = int(size[0]), int(size[1])
+    lab = labels.to(torch.int32).contiguous()
+    g, l = global_map.contiguous(), local_map.contiguous()
+    if g.dtype != torch.float32 or l.dtype != torch.float32 or g.numel() != h * w * n_ids or l.numel() != h * w * n_ids \
+            or lab.numel() != h * w:
+        raise ValueError("global_map / local_map must hold h*w*n_ids float32 values, labels h*w integers")
+    wd = dw_weight.detach().float().contiguous()
+    if wd.numel() != 3 * 49 or tuple(w2t_object.shape) != (3, PW_COUT) or term.numel() != PW_COUT * h * w:
+        raise ValueError("the fused layer takes three per-object channels, 7x7 taps, %d output channels" % PW_COUT)
+    opt = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
+    db, sc, sh = opt(dw_bias), opt(bn_scale), opt(bn_shift)
+    w2, bb, tm = w2t_object.contiguous(), b2.contiguous(), term.contiguous()
+    out = torch.empty((n_ids, PW_COUT, h, w), dtype=torch.float32, device=g.device)
+    with _on(g.device):
+        rc = lib.manet_head_layer1_object_f32(g.data_ptr(), l.data_ptr(), lab.data_ptr(), h, w, n_ids, wd.data_ptr(),
+                                              None if db is None else db.data_ptr(), None if sc is None else sc.data_ptr(),
+                                              None if sh is None else sh.data_ptr(), w2.data_ptr(), bb.data_ptr(), tm.data_ptr(),
+                                              int(bool(relu_out)), out.data_ptr(), _stream_ptr(g.device))
+    _lib.check(rc, "manet_head_layer1_object_f32")
+    return out
+
+
 def head_inputs(global_map, local_map, labels, n_ids, size):
     """The per-object channels of the head's input (IntVOS.py:663-669) in one launch:
     [n_ids, 3, h, w] = (global map of o, local map of o, labels == o), size = (h, w); global_map / local_map hold

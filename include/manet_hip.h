@@ -315,6 +315,15 @@ int manet_upsample_argmax(const float *logits, int n_ids, int h, int w, int H, i
  *     from global_map / local_map [HW][n_ids] fp32 and labels [HW] int32. */
 int manet_label_resize_nearest(const int64_t *mask_hw, int H, int W, int h, int w, int32_t *label_small_hw,
                                manet_stream_t stream);
+/* r5: DynamicSegHead layer 1, per-object half, in ONE launch (networks/IntVOS.py:663-669 input assembly -> :491-494 depthwise 7x7 +
+ * bn1 + relu1 and the 1x1 + bn2 of the three per-object channels -> + `term`, the shared-embedding half's [256][HW] contribution ->
+ * relu2): global_map / local_map [HW][n_ids], labels [HW] int32; dw_weight [3][49], dw_bias / bn_scale / bn_shift [3] (NULL: 0 / 1 / 0);
+ * w2t_object [3][256], b2 [256] (bn2 folded) -> out [n_ids][256][HW].  The same bits as manet_head_inputs_f32 +
+ * manet_dwconv7x7_bn_relu_f32 + manet_conv1x1_add_f32 on those channels. */
+int manet_head_layer1_object_f32(const float *global_map, const float *local_map, const int32_t *labels, int h, int w, int n_ids,
+                                 const float *dw_weight, const float *dw_bias, const float *bn_scale, const float *bn_shift,
+                                 const float *w2t_object, const float *b2, const float *term, int relu_out, float *out,
+                                 manet_stream_t stream);
 int manet_head_inputs_f32(const float *global_map, const float *local_map, const int32_t *labels, int64_t HW, int n_ids,
                           float *out, manet_stream_t stream);
 

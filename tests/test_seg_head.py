@@ -422,3 +422,35 @@ def test_three_piece_split_pointwise_is_fp32_class():
         print("head logits vs the fp32 head: three-piece %.3g, two-piece %.3g (scale %.3g)" % (d3, d2, scale))
         assert d3 <= 2e-6 * max(scale, 1.0) and d3 < d2
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 120, 214), (2, 24, 36), (5, 31, 44), (1, 8, 12)])
+def test_fused_layer1_object_half_equals_the_three_launch_route(shape):
+    """r5: head-input assembly + the per-object channels' depthwise 7x7 / bn1 / relu1 + their 1x1 / bn2 + the shared half's term +
+    relu2 in ONE launch (manet_head_layer1_object_f32) against head_inputs -> dwconv7x7_bn_relu -> conv1x1_mfma(add=term): the same
+    bits, ragged tile edges included; and against the literal module chain on the concatenated input"""
+    from cvpr2020_manet_amd import ops
+    from cvpr2020_manet_amd.networks import IntVOS as M
+    n_ids, h, w = shape
+    torch.manual_seed(h * w)
+    head = M.DynamicSegHead(in_dim=103, embed_dim=256).cuda().eval()
+    for m in head.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 2.0); m.weight.data.normal_(1, 0.2); m.bias.data.normal_(0, 0.2)
+    emb = torch.relu(torch.randn(1, 100, h, w, device="cuda")) * 0.3
+    gmap = torch.rand(h, w, n_ids, device="cuda")
+    lmap = torch.rand(h, w, n_ids, device="cuda")
+    lab = torch.randint(0, n_ids + 1, (h, w), device="cuda", dtype=torch.int32)  # (one label value matches no object)
+    with torch.no_grad():
+        fused = M._layer1_fused(head.layer1, emb, gmap, lmap, lab, n_ids, (h, w))
+        assert fused is not None and tuple(fused.shape) == (n_ids, 256, h, w)
+        per_object = ops.head_inputs(gmap, lmap, lab, n_ids, (h, w))
+        three = head.layer1.forward_shared(emb, per_object)
+        assert torch.equal(fused, three)
+        lit = head.layer1(torch.cat((emb.repeat(n_ids, 1, 1, 1), per_object), 1))  # the general fast path on the concatenated input
+        torch.testing.assert_close(fused, lit, rtol=2e-4, atol=2e-4)
+        memo = {}
+        a = M._layer1_fused(head.layer1, emb, gmap, lmap, lab, n_ids, (h, w), memo=memo)
+        b = M._layer1_fused(head.layer1, emb, gmap, lmap, lab, n_ids, (h, w), memo=memo)   # second call: the memoised term
+        assert torch.equal(a, fused) and torch.equal(b, fused) and memo["term"] is not None
