@@ -859,7 +859,13 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
 // -- operation for operation what dwconv7x7_bn_relu_kernel and conv1x1_mfma_kernel (a k-ascending fmaf chain from zero, bias, `add`,
 // ReLU) compute on head_inputs_kernel's channels: the same bits.  A stream: reads the term once per object (26 MB each, L2-shared
 // between the objects' workgroups of a tile), writes the [n,256,h,w] activation once.
-constexpr int L1_TH = 4, L1_TW = 32, L1_NT = L1_TH * L1_TW, L1_LW = L1_TW + 6 + 1;
+// A workgroup owns a 2 x 64 pixel tile for OB objects; its waves split the 256 output channels in L1_CW parts (each recomputes the
+// cheap depthwise stage from the shared LDS tile: 25 680 pixels are only 401 waves' worth of lanes) and keep L1_UNROLL term loads in
+// flight per lane (a lane's accesses are HW floats apart: the memory system sees a wave's 256-byte row segments only -- depth is
+// what fills the pipe).  OB = 1 up to three objects, 2 from four (the pair reads the term once): the sweep over
+// (rows, channel parts, objects) per workgroup is in docs/history/r05_experiments.md -- 32 us at 3 objects, 90 us at 720p x 6.
+constexpr int L1_TH = 2, L1_TW = 64, L1_CW = 2, L1_NT = L1_TH * L1_TW * L1_CW, L1_LW = L1_TW + 6 + 1, L1_UNROLL = 16;
+template <int L1_OB>
 __global__ __launch_bounds__(L1_NT) void head_layer1_object_kernel(const float *__restrict__ gmap, const float *__restrict__ lmap,
                                                                    const int *__restrict__ labels, int h, int w, int n_ids,
                                                                    const float *__restrict__ w1, const float *__restrict__ b1,
@@ -868,23 +874,25 @@ __global__ __launch_bounds__(L1_NT) void head_layer1_object_kernel(const float *
                                                                    const float *__restrict__ term, int relu_out,
                                                                    float *__restrict__ out)
 {
-    __shared__ float tin[3][L1_TH + 6][L1_LW];
+    __shared__ float tin[L1_OB][3][L1_TH + 6][L1_LW];
     __shared__ __attribute__((aligned(16))) float wtab[PW_CO][4];  // {w2[0][co], w2[1][co], w2[2][co], b2[co]}
-    const int tid = threadIdx.x, o = blockIdx.z;
+    const int tid = threadIdx.x, o0 = blockIdx.z * L1_OB;
+    const int nob = (n_ids - o0) < L1_OB ? (n_ids - o0) : L1_OB;  // objects of this workgroup (uniform)
     const int x0 = blockIdx.x * L1_TW, y0 = blockIdx.y * L1_TH;
     for (int i = tid; i < (L1_TH + 6) * (L1_TW + 6); i += L1_NT) {
         const int r = i / (L1_TW + 6), c = i - r * (L1_TW + 6);
         const int yy = y0 - 3 + r, xx = x0 - 3 + c;
-        float g = 0.0f, l = 0.0f, m = 0.0f;
-        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
-            const long p = (long)yy * w + xx;
-            g = gmap[p * n_ids + o];
-            l = lmap[p * n_ids + o];
-            m = labels[p] == o ? 1.0f : 0.0f;
+        const bool in = yy >= 0 && yy < h && xx >= 0 && xx < w;
+        const long p = in ? (long)yy * w + xx : 0;
+        const int lab = in ? labels[p] : -1;
+#pragma unroll
+        for (int j = 0; j < L1_OB; ++j) {
+            if (j < nob) {
+                tin[j][0][r][c] = in ? gmap[p * n_ids + o0 + j] : 0.0f;
+                tin[j][1][r][c] = in ? lmap[p * n_ids + o0 + j] : 0.0f;
+                tin[j][2][r][c] = (in && lab == o0 + j) ? 1.0f : 0.0f;
+            }
         }
-        tin[0][r][c] = g;
-        tin[1][r][c] = l;
-        tin[2][r][c] = m;
     }
     for (int i = tid; i < PW_CO; i += L1_NT) {
         wtab[i][0] = w2[i];
@@ -893,29 +901,45 @@ __global__ __launch_bounds__(L1_NT) void head_layer1_object_kernel(const float *
         wtab[i][3] = b2[i];
     }
     __syncthreads();
-    const int ty = tid / L1_TW, tx = tid - ty * L1_TW;
-    float d[3];
+    const int cw = tid / (L1_TH * L1_TW), pt = tid - cw * (L1_TH * L1_TW);  // channel quarter (= wave), pixel of the tile
+    const int ty = pt / L1_TW, tx = pt - ty * L1_TW;
+    float d[L1_OB][3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float acc = 0.0f;
+    for (int j = 0; j < L1_OB; ++j) {
 #pragma unroll
-        for (int ky = 0; ky < DW_K; ++ky)
+        for (int c = 0; c < 3; ++c) {
+            float acc = 0.0f;
+            if (j < nob) {
 #pragma unroll
-            for (int kx = 0; kx < DW_K; ++kx) acc = fmaf(tin[c][ty + ky][tx + kx], w1[c * DW_K * DW_K + ky * DW_K + kx], acc);
-        d[c] = fmaxf(fmaf(acc + (b1 ? b1[c] : 0.0f), sc1 ? sc1[c] : 1.0f, sh1 ? sh1[c] : 0.0f), 0.0f);
+                for (int ky = 0; ky < DW_K; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < DW_K; ++kx) acc = fmaf(tin[j][c][ty + ky][tx + kx], w1[c * DW_K * DW_K + ky * DW_K + kx], acc);
+            }
+            d[j][c] = fmaxf(fmaf(acc + (b1 ? b1[c] : 0.0f), sc1 ? sc1[c] : 1.0f, sh1 ? sh1[c] : 0.0f), 0.0f);
+        }
     }
     const int y = y0 + ty, x = x0 + tx;
     if (y >= h || x >= w) return;
     const long HW = (long)h * w, p = (long)y * w + x;
     const float *tp = term + p;
-    float *dst = out + (long)o * PW_CO * HW + p;
-#pragma unroll 8
-    for (int co = 0; co < PW_CO; ++co) {
-        const f32x4 t = *(const f32x4 *)wtab[co];
-        float v = fmaf(t[2], d[2], fmaf(t[1], d[1], fmaf(t[0], d[0], 0.0f))) + t[3];
-        v += tp[(long)co * HW];
-        if (relu_out) v = fmaxf(v, 0.0f);
-        dst[(long)co * HW] = v;
+    float *dst = out + (long)o0 * PW_CO * HW + p;
+    for (int c0 = cw * (PW_CO / L1_CW); c0 < (cw + 1) * (PW_CO / L1_CW); c0 += L1_UNROLL) {
+        float tv[L1_UNROLL];
+#pragma unroll
+        for (int u = 0; u < L1_UNROLL; ++u) tv[u] = tp[(long)(c0 + u) * HW];
+#pragma unroll
+        for (int u = 0; u < L1_UNROLL; ++u) {
+            const f32x4 t = *(const f32x4 *)wtab[c0 + u];
+#pragma unroll
+            for (int j = 0; j < L1_OB; ++j) {
+                if (j < nob) {
+                    float v = fmaf(t[2], d[j][2], fmaf(t[1], d[j][1], fmaf(t[0], d[j][0], 0.0f))) + t[3];
+                    v += tv[u];
+                    if (relu_out) v = fmaxf(v, 0.0f);
+                    dst[((long)j * PW_CO + c0 + u) * HW] = v;
+                }
+            }
+        }
     }
 }
 
@@ -932,8 +956,10 @@ extern "C" int manet_head_layer1_object_f32(const float *global_map, const float
     if (!global_map || !local_map || !labels || !dw_weight || !w2t_object || !b2 || !term || !out || h <= 0 || w <= 0 || n_ids <= 0 ||
         n_ids > 65535)
         return manet_set_error(MANET_E_INVALID, "bad arguments");
-    dim3 grid((unsigned)((w + L1_TW - 1) / L1_TW), (unsigned)((h + L1_TH - 1) / L1_TH), (unsigned)n_ids);
-    hipLaunchKernelGGL(head_layer1_object_kernel, grid, dim3(L1_NT), 0, (hipStream_t)stream, global_map, local_map, (const int *)labels,
+    const int ob = n_ids >= 4 ? 2 : 1;
+    auto kern = ob == 2 ? head_layer1_object_kernel<2> : head_layer1_object_kernel<1>;
+    dim3 grid((unsigned)((w + L1_TW - 1) / L1_TW), (unsigned)((h + L1_TH - 1) / L1_TH), (unsigned)((n_ids + ob - 1) / ob));
+    hipLaunchKernelGGL(kern, grid, dim3(L1_NT), 0, (hipStream_t)stream, global_map, local_map, (const int *)labels,
                        h, w, n_ids, dw_weight, dw_bias, bn_scale, bn_shift, w2t_object, b2, term, relu_out, out);
     return manet_check_launch("manet_head_layer1_object_f32");
 }

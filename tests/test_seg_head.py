@@ -425,7 +425,7 @@ def test_three_piece_split_pointwise_is_fp32_class():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(3, 120, 214), (2, 24, 36), (5, 31, 44), (1, 8, 12)])
+@pytest.mark.parametrize("shape", [(3, 120, 214), (2, 24, 36), (5, 31, 44), (1, 8, 12), (6, 20, 68), (4, 10, 130)])
 def test_fused_layer1_object_half_equals_the_three_launch_route(shape):
     """r5: head-input assembly + the per-object channels' depthwise 7x7 / bn1 / relu1 + their 1x1 / bn2 + the shared half's term +
     relu2 in ONE launch (manet_head_layer1_object_f32) against head_inputs -> dwconv7x7_bn_relu -> conv1x1_mfma(add=term): the same

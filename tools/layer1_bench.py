@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""DynamicSegHead layer 1 at [n_ids, 103 -> 256, 120, 214]: the fused per-object launch (ops.head_layer1_object) against the
+three-launch route (head_inputs -> depthwise of the 3 channels -> 1x1 K = 3 with the shared term added); the shared half is given
+(memoised per frame in the module).  Warm GPU, alternating, minimum of four means."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from cvpr2020_manet_amd import ops  # noqa: E402
+from cvpr2020_manet_amd.networks import IntVOS as M  # noqa: E402
+
+
+def mean_us(fn, n=100):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+torch.manual_seed(0)
+for n_ids, h, w in ((3, 120, 214), (2, 120, 214), (6, 180, 320)):
+    head = M.DynamicSegHead(in_dim=103, embed_dim=256).cuda().eval()
+    emb = torch.relu(torch.randn(1, 100, h, w, device="cuda")) * 0.3
+    gmap, lmap = torch.rand(h, w, n_ids, device="cuda"), torch.rand(h, w, n_ids, device="cuda")
+    lab = torch.randint(0, n_ids, (h, w), device="cuda", dtype=torch.int32)
+    with torch.no_grad():
+        memo = {}
+        M._layer1_fused(head.layer1, emb, gmap, lmap, lab, n_ids, (h, w), memo=memo)
+        l1, k = head.layer1, head.layer1._folded(100)
+        w1, b1 = l1.conv1.weight, l1.conv1.bias
+
+        def fused():
+            return M._layer1_fused(l1, emb, gmap, lmap, lab, n_ids, (h, w), memo=memo)
+
+        def three():
+            po = ops.head_inputs(gmap, lmap, lab, n_ids, (h, w))
+            p1 = ops.dwconv7x7_bn_relu(po, w1[100:], b1[100:], scale=k["scale1"][100:], shift=k["shift1"][100:])
+            return ops.conv1x1_mfma(p1, k["w2t_object"], k["b2"], relu_out=True, add=memo["term"])
+
+        assert torch.equal(fused(), three())
+        best = {"fused": 1e9, "three launches": 1e9}
+        mean_us(fused, 300)
+        for _ in range(4):
+            best["fused"] = min(best["fused"], mean_us(fused))
+            best["three launches"] = min(best["three launches"], mean_us(three))
+    mb = (n_ids * 256 * h * w * 4 + 256 * h * w * 4) / 1e6
+    print("[%d,103->256,%d,%d] (%.0f MB term + out): " % (n_ids, h, w, mb) + "; ".join("%s %.1f us" % kv for kv in best.items()))
