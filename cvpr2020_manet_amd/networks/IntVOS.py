@@ -518,15 +518,16 @@ class IntVOS(nn.Module):
         except RuntimeError:
             # inference tensors carry no version counter: nothing trustworthy to key on -- sort / pack afresh (into the
             # previous bank's workspace) on every call
-            bank = ops.PreparedBank(ref_emb_hwc, ref_lab_flat, n_ids, compute=self.compute,
-                                    reuse=hit[1] if hit is not None else None)
+            bank = ops.PreparedBank(ref_emb_hwc, ref_lab_flat() if callable(ref_lab_flat) else ref_lab_flat, n_ids,
+                                    compute=self.compute, reuse=hit[1] if hit is not None else None)
             self._bank_cache[seq_name] = (None, bank, ref_emb_chw, ref_label)
             return bank
         if hit is not None and hit[0] == key:
             self._bank_cache.move_to_end(seq_name)
             return hit[1]
-        bank = ops.PreparedBank(ref_emb_hwc, ref_lab_flat, n_ids, compute=self.compute,
-                                reuse=hit[1] if hit is not None else None)  # (the stale bank's workspace is taken over)
+        # (ref_lab_flat may be a callable: the caller converts the labels only when the bank really is rebuilt)
+        bank = ops.PreparedBank(ref_emb_hwc, ref_lab_flat() if callable(ref_lab_flat) else ref_lab_flat, n_ids,
+                                compute=self.compute, reuse=hit[1] if hit is not None else None)  # (the stale bank's workspace is taken over)
         # keep the keyed tensors alive so that their storage pointers cannot be recycled under the key
         self._bank_cache[seq_name] = (key, bank, ref_emb_chw, ref_label)
         self._bank_cache.move_to_end(seq_name)
@@ -780,11 +781,18 @@ class IntVOS(nn.Module):
         cfg = self.cfg
         dic_tmp = {}
         bs, c, h, w = current_frame_embedding.size()
-        if cfg.TEST_MODE:
-            scale_ref_scribble_label = ref_scribble_label.float()
-        else:
-            scale_ref_scribble_label = F.interpolate(ref_scribble_label.float(), size=(h, w), mode="nearest")
-        scale_ref_scribble_label = scale_ref_scribble_label.int()
+        scaled_ref = []
+
+        def scale_ref_scribble_label():
+            # on demand: a propagation loop passes the same annotated frame for a whole clip and the prepared bank is a cache
+            # hit -- the float -> int conversion of its labels (a launch per frame) is then never needed
+            if not scaled_ref:
+                if cfg.TEST_MODE:
+                    lab = ref_scribble_label.float()
+                else:
+                    lab = F.interpolate(ref_scribble_label.float(), size=(h, w), mode="nearest")
+                scaled_ref.append(lab.int())
+            return scaled_ref[0]
         if (bs == 1 and previous_frame_mask.is_cuda and not previous_frame_mask.is_floating_point()
                 and previous_frame_mask.numel() == previous_frame_mask.shape[-1] * previous_frame_mask.shape[-2]):
             scale_previous_frame_label = ops.label_resize_nearest(previous_frame_mask, (h, w))  # the same, one launch
@@ -795,7 +803,8 @@ class IntVOS(nn.Module):
             seq_current_frame_embedding = current_frame_embedding[n].permute(1, 2, 0)
             seq_ref_frame_embedding = ref_frame_embedding[n].permute(1, 2, 0)
             seq_prev_frame_embedding = previous_frame_embedding[n].permute(1, 2, 0)
-            seq_ref_scribble_label = scale_ref_scribble_label[n].permute(1, 2, 0)
+            def seq_ref_label_flat(n=n):
+                return scale_ref_scribble_label()[n].permute(1, 2, 0).reshape(-1)
             n_ids = _n_ids_from(gt_ids[n], None)
             ref_obj_ids = _obj_ids(n_ids, current_frame_embedding.device)
 
@@ -807,8 +816,9 @@ class IntVOS(nn.Module):
                         (MAX_CLIP_FRAMES, h, w, n_ids, 1), dtype=torch.float32,
                         device=current_frame_embedding.device)
                 mem = global_map_tmp_dic[seq_names[n]][frame_num[n]]  # contiguous slice, updated in place
-            ref_emb, ref_lab = seq_ref_frame_embedding, seq_ref_scribble_label.reshape(-1)
+            ref_emb, ref_lab = seq_ref_frame_embedding, seq_ref_label_flat  # (the labels: a callable until someone needs them)
             if k_nearest_neighbors > 1 and cfg.TEST_MODE:
+                ref_lab = ref_lab()
                 keep = ref_lab != -1
                 ref_emb, ref_lab = ref_emb.reshape(-1, c)[keep], ref_lab[keep]
             bank, fcur, lpre, preset_done = None, None, None, False
@@ -857,8 +867,8 @@ class IntVOS(nn.Module):
                 nn_features_n = bank.match(fcur, normalize=bool(normalize_nearest_neighbor_distances),
                                            mem=mem).view(1, h, w, n_ids, 1)
             else:
-                nn_features_n = ops.global_match(ref_emb, seq_current_frame_embedding, ref_lab, n_ids,
-                                                 k_nearest_neighbors=k_nearest_neighbors, compute=self.compute,
+                nn_features_n = ops.global_match(ref_emb, seq_current_frame_embedding, ref_lab() if callable(ref_lab) else ref_lab,
+                                                 n_ids, k_nearest_neighbors=k_nearest_neighbors, compute=self.compute,
                                                  normalize=bool(normalize_nearest_neighbor_distances),
                                                  mem=mem).view(1, h, w, n_ids, 1)
 
@@ -896,7 +906,10 @@ class IntVOS(nn.Module):
                 # (host mirror of the weights this module wrote into THIS table: the comparison a few lines down then needs no
                 # device read -- in the reference it is a device-to-host synchronisation per frame from the second round on)
                 mirror = self._mirror_of(seq_names[n], dist_tab)  # (validated BEFORE this call's own write)
-                dist_tab[frame_num[n]][interaction_num - 1] = weight
+                # (fill_, not `tab[i][j] = weight`: indexed assignment of a python number to a device tensor goes through a
+                # one-element HOST tensor and a blocking host-to-device copy -- the host then waits for the whole frame's queue,
+                # ~0.85 ms, and the device idles ~70 us per frame until the next launch arrives; fill_ is one async launch)
+                dist_tab[frame_num[n]][interaction_num - 1].fill_(weight)
                 fkey = int(frame_num[n])
                 if mirror is not None:
                     mirror[1] = dist_tab._version
@@ -997,7 +1010,7 @@ class IntVOS(nn.Module):
                         MAX_CLIP_FRAMES, MAX_INTERACTIONS, 1, 1, 1, 1)
                 dist_tab = local_map_dist_dic[seq_names[n]]
                 mirror = self._mirror_of(seq_names[n], dist_tab)
-                dist_tab[frame_num[n]][interaction_num - 1] = 0
+                dist_tab[frame_num[n]][interaction_num - 1].fill_(0)  # (async; see prop_seghead)
                 if mirror is not None:  # (this write is the module's own: the mirror follows it)
                     mirror[1] = dist_tab._version
                     mirror[2][(int(frame_num[n]), interaction_num - 1)] = 0.0
