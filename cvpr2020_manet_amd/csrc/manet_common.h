@@ -36,7 +36,7 @@ void manet_profile_record(hipStream_t st, bool start, int channel = 0);
 // tuning knobs (manet_tune_set; defaults are the shipped configuration)
 enum { MANET_TUNE_BLOCK_MAP = 0, MANET_TUNE_SPLITS = 1, MANET_TUNE_BF16_VARIANT = 2, MANET_TUNE_ABLATION = 3,
        MANET_TUNE_LOCAL_UNFUSED = 4, MANET_TUNE_F32_UNPIPED = 5, MANET_TUNE_FRAME_XC = 6, MANET_TUNE_REFINE_SUB = 7,
-       MANET_TUNE_CONV1X1 = 8 /* 1: the LDS-weights 1x1 kernel even where the resident-weights one applies */,
+       MANET_TUNE_CONV1X1 = 8 /* 1: the LDS-weights 1x1 kernel even where the resident-weights one applies; 2-4: forms of the latter (seg_head.hip) */,
        MANET_TUNE_RESCUE_SPLITS = 9 /* bank splits per listed tile of bf16r's rescue launch (experiments) */,
        MANET_TUNE_ONE_ROUND = 10 /* 1: the fp32 kernel keeps the host's split count whatever the bank's real size (A/B timing) */,
        MANET_TUNE_COUNT = 12 };

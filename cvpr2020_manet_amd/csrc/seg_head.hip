@@ -696,9 +696,15 @@ template <int RW_KC>
 __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__restrict__ in, long in_bs, int Cin, long HW,
                                                               const float *__restrict__ w2t, const float *__restrict__ b2,
                                                               int relu_out, float *__restrict__ out, int tpp, int total_tiles,
-                                                              int G, int abl)
+                                                              int G, int halves, int abl_arg)
 {
     // abl (-DMANET_ABLATION builds, timing only): 1 no output stores, 2 no barrier, 4 no DMA after the prologue, 8 no refills
+    // (a compile-time 0 otherwise: as a run-time value its tests put a scalar branch around every refill of the MFMA loop)
+#ifdef MANET_ABLATION
+    const int abl = abl_arg;
+#else
+    constexpr int abl = 0;
+#endif
     __shared__ __attribute__((aligned(1024))) float xbuf[RW_NB][RW_KC * RW_P];
     __shared__ float bsh[128];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kk = lane >> 5;
@@ -706,8 +712,15 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int half = j & 1, grp = xcd + 8 * (j >> 1);
     if (grp >= G) return;
-    const int t0 = (int)((long)grp * total_tiles / G), t1 = (int)((long)(grp + 1) * total_tiles / G);
-    if (t0 >= t1) return;
+    // A group's range is cut in HALF-tile units (r5): 804 tiles on 256 groups are 3 or 4 tiles each -- the launch takes four tile
+    // times for 3.14 of work; in halves the longest group has 3 1/2.  A range that starts / ends inside a tile computes only
+    // the pixels of one parity there (pixel block 1 at its start, 0 at its end; the tile's other block belongs to the neighbour
+    // group): the same staging, half the MFMAs, every output still the same two k-parity chains.
+    // (halves: the launcher's choice -- a half tile costs ~0.65 of a tile, worth it only where the longest group gets shorter)
+    const int u0 = halves ? (int)((long)grp * (2L * total_tiles) / G) : 2 * (int)((long)grp * total_tiles / G);
+    const int u1 = halves ? (int)((long)(grp + 1) * (2L * total_tiles) / G) : 2 * (int)((long)(grp + 1) * total_tiles / G);
+    const int t0 = u0 >> 1, t1 = (u1 + 1) >> 1;
+    if (u0 >= u1) return;
     const int co0 = half * 128 + wave * 32;
     if (tid < 128) bsh[tid] = b2[half * 128 + tid];
     // A operand: lane (co = l31, kk) holds w[2 s + kk][co0 + co] for every k-step s (zero past Cin)
@@ -785,7 +798,8 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
     }
     int st = 0;  // step number of (t, c); its stage was read into F during step st - 1, step st reads stage st + 1
     int cur_b = b0, cur_p = t0 - b0 * tpp;
-    for (int t = t0; t < t1; ++t) {
+    auto tile = [&](auto mode_) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_)::value;  // bit pb set: pixel block pb of the tile is this group's
         f32x16 acc[2][2];  // [pixel block][k-step parity]; a tile's first four MFMAs take C = 0 (no zeroing pass)
         const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -797,10 +811,10 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
                 for (int s = 0; s < RW_KC / 2; s += 2) {
                     const int ks = c * (RW_KC / 2) + s, f = s % FH;
                     const bool first = c == 0 && s == 0;  // (compile-time: both loops are unrolled)
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], F0[f], first ? zero16 : acc[0][0], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], F1[f], first ? zero16 : acc[1][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks + 1], F0[f + 1], first ? zero16 : acc[0][1], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks + 1], F1[f + 1], first ? zero16 : acc[1][1], 0, 0, 0);
+                    if constexpr ((MODE & 1) != 0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], F0[f], first ? zero16 : acc[0][0], 0, 0, 0);
+                    if constexpr ((MODE & 2) != 0) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], F1[f], first ? zero16 : acc[1][0], 0, 0, 0);
+                    if constexpr ((MODE & 1) != 0) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks + 1], F0[f + 1], first ? zero16 : acc[0][1], 0, 0, 0);
+                    if constexpr ((MODE & 2) != 0) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks + 1], F1[f + 1], first ? zero16 : acc[1][1], 0, 0, 0);
                     if (!(abl & 8)) {
                         // k-steps s + 8, s + 9 of this stage, or of the next stage's first eight (a stale read behind the last step)
                         const float *X = s + FH < RW_KC / 2 ? Xc + 2 * (s + FH) * RW_P : Xn + 2 * (s + FH - RW_KC / 2) * RW_P;
@@ -810,7 +824,7 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
                         F0[f + 1] = vb[0];
                         F1[f + 1] = vb[1];
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x008, MODE == 3 ? 4 : 2, 0);  // the MFMAs
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // the refill (one ds_read2_b64) right behind them
                 }
                 rw_wait_vmcnt((RW_KC / 16) * (issued - 1 - (st + 2)));  // step st + 2 has landed: only the steps behind it may be out
@@ -830,9 +844,16 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2);
                     const float bb = bsh[wave * 32 + row + 4 * kk];
-                    f32x2 v = {(acc[0][0][r] + acc[0][1][r]) + bb, (acc[1][0][r] + acc[1][1][r]) + bb};
-                    if (relu_out) v = __builtin_elementwise_max(v, f32x2{0.0f, 0.0f});
-                    if (!(abl & 1)) *(f32x2 *)((dst + (long)row * HW) + voff) = v;
+                    if constexpr (MODE == 3) {
+                        f32x2 v = {(acc[0][0][r] + acc[0][1][r]) + bb, (acc[1][0][r] + acc[1][1][r]) + bb};
+                        if (relu_out) v = __builtin_elementwise_max(v, f32x2{0.0f, 0.0f});
+                        if (!(abl & 1)) *(f32x2 *)((dst + (long)row * HW) + voff) = v;
+                    } else {
+                        constexpr int pb = MODE == 1 ? 0 : 1;
+                        float v = (acc[pb][0][r] + acc[pb][1][r]) + bb;
+                        if (relu_out) v = fmaxf(v, 0.0f);
+                        if (!(abl & 1)) (dst + (long)row * HW)[voff + pb] = v;
+                    }
                 }
             }
             if (++cur_p == tpp) {
@@ -846,6 +867,14 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
             // vmcnt(0) at the end of every tile: both waves of a SIMD reach that point together (all workgroups run in step), so
             // the matrix pipe idled for a store round trip per tile: 101.4 -> 96.6 us at [3,256,120,214].
         }
+    };
+    for (int t = t0; t < t1; ++t) {
+        if (t == t0 && (u0 & 1))  // (uniform; a range is at least two units long: never both ends in one tile)
+            tile(std::integral_constant<int, 2>{});
+        else if (t == t1 - 1 && (u1 & 1))
+            tile(std::integral_constant<int, 1>{});
+        else
+            tile(std::integral_constant<int, 3>{});
     }
 }
 
@@ -1075,12 +1104,19 @@ static int conv1x1_f32_impl(const float *in, int64_t in_batch_stride, int B, int
 #else
         const int rw_abl = 0;
 #endif
-        if (Cin % 64 == 0 && manet_tune_get(MANET_TUNE_CONV1X1, 0) != 2)  // (2: 32-channel stages everywhere, A/B timing)
+        // ranges in half-tile units where that shortens the longest group by half a tile of at most ten (804 tiles on 256 groups:
+        // 4 -> 3 1/2; 1 206: 5 either way, and two half tiles per group would only cost)
+        const long per_whole = (total + G - 1) / G, per_half = (2 * total + G - 1) / G;
+        int halves = (per_half < 2 * per_whole && per_whole <= 10) ? 1 : 0;
+        const int tune = manet_tune_get(MANET_TUNE_CONV1X1, 0);
+        if (tune == 3) halves = 0;  // (3 / 4: whole tiles / half-tile units everywhere, A/B timing and tests)
+        if (tune == 4) halves = total >= G ? 1 : 0;
+        if (Cin % 64 == 0 && tune != 2)  // (2: 32-channel stages everywhere, A/B timing)
             hipLaunchKernelGGL(conv1x1_rw_kernel<64>, dim3(blocks), dim3(RW_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin,
-                               (long)HW, w2t, b2, relu_out, out, tpp, (int)total, G, rw_abl);
+                               (long)HW, w2t, b2, relu_out, out, tpp, (int)total, G, halves, rw_abl);
         else
             hipLaunchKernelGGL(conv1x1_rw_kernel<32>, dim3(blocks), dim3(RW_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin,
-                               (long)HW, w2t, b2, relu_out, out, tpp, (int)total, G, rw_abl);
+                               (long)HW, w2t, b2, relu_out, out, tpp, (int)total, G, halves, rw_abl);
         return manet_check_launch("manet_conv1x1_f32 (resident weights)");
     }
     dim3 grid((unsigned)((HW + PW_P - 1) / PW_P), (unsigned)B);

@@ -509,7 +509,8 @@ int manet_profile_begin(int max_launches);
  *         counters of the listing path printed after each filter launch),
  * key 4 = 1: the r1 three-launch local match, key 5 = un-pipelined fp32 kernel, key 6 = frame-prepare channel block,
  * key 7 = pre-pass sampling of MANET_COMPUTE_BF16_REFINE (every value-th bank tile), key 8 = 1: the LDS-weights fp32 1x1
- * kernel everywhere, key 9 = bank splits per listed tile of MANET_COMPUTE_BF16_REFINE's rescue launch, key 10 = 1: the fp32 kernel
+ * kernel everywhere (2: the resident-weights kernel with 32-channel stages, 3 / 4: its pixel ranges in whole tiles / half-tile
+ * units whatever the launch size), key 9 = bank splits per listed tile of MANET_COMPUTE_BF16_REFINE's rescue launch, key 10 = 1: the fp32 kernel
  * keeps the host's split count whatever the bank's real size (see split_of_block in csrc/global_match.hip).
  * Keys 2, 3, 5, 6 select kernels that only -DMANET_ABLATION builds contain and are refused otherwise.
  * No knob changes a workspace layout. */

@@ -334,7 +334,8 @@ def test_resident_weights_1x1_kernel_against_the_lds_weights_kernel():
     g = torch.Generator(device="cuda").manual_seed(11)
     try:
         for (B, cin, h, w, relu) in ((3, 256, 120, 214, False), (2, 256, 30, 54, True), (1, 32, 4, 16, False), (3, 64, 21, 36, True),
-                                     (1, 128, 9, 12, False), (2, 96, 7, 20, True), (1, 256, 1, 4, False)):
+                                     (1, 128, 9, 12, False), (2, 96, 7, 20, True), (1, 256, 1, 4, False), (2, 256, 120, 214, True),
+                                     (4, 64, 120, 214, False), (5, 32, 67, 92, True)):
             x = torch.randn(B, cin, h, w, generator=g, device="cuda")
             w2t = torch.randn(cin, 256, generator=g, device="cuda") * 0.1
             b2 = torch.randn(256, generator=g, device="cuda")
@@ -348,6 +349,13 @@ def test_resident_weights_1x1_kernel_against_the_lds_weights_kernel():
             assert float((got - want).abs().max()) <= 4e-7 * scale, (B, cin, h, w)
             ref = torch.nn.functional.conv2d(x, w2t.t().reshape(256, cin, 1, 1).contiguous(), b2)
             torch.testing.assert_close(got, ref.relu() if relu else ref, rtol=2e-4, atol=2e-4)
+            # r5: a group's range is cut in half-tile units (a tile at a range boundary is computed by two workgroups, one pixel
+            # parity each); an output's bits do not depend on where the cuts fall -- one image alone is cut elsewhere
+            for b in range(B if B > 1 else 0):
+                assert torch.equal(ops.conv1x1_mfma(x[b:b + 1].contiguous(), w2t, b2, relu_out=relu)[0], got[b]), (B, cin, h, w, b)
+            for form in (3, 4):  # whole tiles / half-tile units whatever the launcher would choose
+                _lib.check(lib.manet_tune_set(8, form), "manet_tune_set")
+                assert torch.equal(ops.conv1x1_mfma(x, w2t, b2, relu_out=relu), got), (B, cin, h, w, form)
     finally:
         lib.manet_tune_set(8, -2 ** 31)
 
