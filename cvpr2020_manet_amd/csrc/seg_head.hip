@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(co
     // rectifies and stores.  Written as one loop, hipcc sinks each load into the branch of its select and waits
     // vmcnt(0) there: 15 serial L2 round trips per thread (r2 trace: this, not the 392 FMAs, was the kernel's time).
     f32x2 ld[KI][3];
-    unsigned off[KI][3];  // element offsets inside a plane (the same for every batch item)
+    unsigned off[KI][3];  // BYTE offsets inside a plane (the same for every batch item)
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
         const int i = tid + 256 * k;
@@ -77,12 +77,14 @@ __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(co
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
             const int yc = min(max(y0 - DW_R + 2 * p + e, 0), h - 1);
-            off[k][e] = (unsigned)(yc * w + min(max(xx, 0), FAST ? w - 2 : w - 1));
+            off[k][e] = 4u * (unsigned)(yc * w + min(max(xx, 0), FAST ? w - 2 : w - 1));
         }
     }
     auto issue_loads = [&](int b) __attribute__((always_inline)) {
-        // (unsigned element offsets: the loads take the scalar-base + 32-bit-offset form, no 64-bit address VALU)
-        const float *src = in + ((long)b * C + c) * plane;
+        // (unsigned BYTE offsets on a uniform base: the loads take the scalar-base + 32-bit-offset form.  r2-r4 kept element
+        // offsets: times 4 they need 33 bits, so hipcc widened each to a 64-bit VGPR pair and added the base with a
+        // v_lshl_add_u64 per load and item -- 15 pairs of registers and 15 64-bit adds per item)
+        const char *src = (const char *)(in + ((long)b * C + c) * plane);
 #pragma unroll
         for (int k = 0; k < KI; ++k) {
             const int i = tid + 256 * k;
@@ -94,8 +96,8 @@ __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(co
                 } else if (FAST) {
                     ld[k][e] = *(const f32x2 *)(src + off[k][e]);
                 } else {
-                    ld[k][e][0] = src[off[k][e]];
-                    ld[k][e][1] = src[(unsigned)(off[k][e] - (unsigned)min(max(xx, 0), w - 1) + (unsigned)min(max(xx + 1, 0), w - 1))];
+                    ld[k][e][0] = *(const float *)(src + off[k][e]);
+                    ld[k][e][1] = *(const float *)(src + (unsigned)(off[k][e] - 4u * (unsigned)min(max(xx, 0), w - 1) + 4u * (unsigned)min(max(xx + 1, 0), w - 1)));
                 }
             }
         }
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(co
             for (int e = 0; e < 2; ++e) {
                 const int y = y0 + 2 * t + e;
                 if (y >= h) continue;
-                float *dst = out + ((long)b * C + c) * plane + (unsigned)(y * w + x);
+                float *dst = (float *)((char *)(out + ((long)b * C + c) * plane) + 4u * (unsigned)(y * w + x));
                 float r[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
