@@ -701,6 +701,14 @@ def head_layer1_object(global_map, local_map, labels, n_ids, size, dw_weight, dw
     opt = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
     db, sc, sh = opt(dw_bias), opt(bn_scale), opt(bn_shift)
     w2, bb, tm = w2t_object.contiguous(), b2.contiguous(), term.contiguous()
+    for name, t in (("local_map", l), ("labels", lab), ("dw_weight", wd), ("dw_bias", db), ("bn_scale", sc), ("bn_shift", sh),
+                    ("w2t_object", w2), ("b2", bb), ("term", tm)):
+        if t is not None and t.device != g.device:
+            raise ValueError("%s is on %s, global_map on %s" % (name, t.device, g.device))
+    if w2.dtype != torch.float32 or bb.dtype != torch.float32 or tm.dtype != torch.float32 or bb.numel() != PW_COUT:
+        raise ValueError("w2t_object [3, %d], b2 [%d] and term must be float32" % (PW_COUT, PW_COUT))
+    if n_ids < 1:
+        raise ValueError("n_ids must be positive")
     out = torch.empty((n_ids, PW_COUT, h, w), dtype=torch.float32, device=g.device)
     with _on(g.device):
         rc = lib.manet_head_layer1_object_f32(g.data_ptr(), l.data_ptr(), lab.data_ptr(), h, w, n_ids, wd.data_ptr(),

@@ -363,7 +363,7 @@ def test_resident_weights_1x1_kernel_against_the_lds_weights_kernel():
 @pytest.mark.gpu
 def test_fuzz_head_and_mask_step_kernels():
     """tools/fuzz_head.py: random shapes through the depthwise kernel, both 1x1 kernels (any Cin, add term, fused output layer),
-    head input assembly, label resize and upsample + argmax against torch (5 100 cases ran clean when it was written)"""
+    head input assembly, the fused layer-1 launch, the resident-weights kernel on half-tile-cut planes, label resize and upsample + argmax against torch (5 100 cases ran clean when it was written, 2 500 with the r5 kinds)"""
     from tools import fuzz_head
     assert fuzz_head.run(200, 20200614) == 0
 
@@ -462,3 +462,30 @@ def test_fused_layer1_object_half_equals_the_three_launch_route(shape):
         a = M._layer1_fused(head.layer1, emb, gmap, lmap, lab, n_ids, (h, w), memo=memo)
         b = M._layer1_fused(head.layer1, emb, gmap, lmap, lab, n_ids, (h, w), memo=memo)   # second call: the memoised term
         assert torch.equal(a, fused) and torch.equal(b, fused) and memo["term"] is not None
+
+
+@pytest.mark.gpu
+def test_fused_layer1_refuses_what_it_cannot_take():
+    """ops.head_layer1_object: operands on another device, a term of the wrong size or type, tensors that require grad -- errors,
+    not launches"""
+    from cvpr2020_manet_amd import ops
+    h, w, n = 8, 12, 2
+    dev = torch.device("cuda", 0)
+    g, l = torch.rand(h, w, n, device=dev), torch.rand(h, w, n, device=dev)
+    lab = torch.zeros(h, w, dtype=torch.int32, device=dev)
+    wd, w2, b2 = torch.randn(3, 1, 7, 7, device=dev), torch.randn(3, 256, device=dev), torch.randn(256, device=dev)
+    term = torch.randn(1, 256, h, w, device=dev)
+    ok = ops.head_layer1_object(g, l, lab, n, (h, w), wd, None, None, None, w2, b2, term)
+    assert tuple(ok.shape) == (n, 256, h, w)
+    with pytest.raises(ValueError):
+        ops.head_layer1_object(g, l.cpu(), lab, n, (h, w), wd, None, None, None, w2, b2, term)
+    with pytest.raises(ValueError):
+        ops.head_layer1_object(g, l, lab, n, (h, w), wd, None, None, None, w2, b2, term[:, :128])
+    with pytest.raises(ValueError):
+        ops.head_layer1_object(g, l, lab, n, (h, w), wd, None, None, None, w2.double(), b2, term)
+    with pytest.raises(ValueError):
+        ops.head_layer1_object(g, l, lab[:4], n, (h, w), wd, None, None, None, w2, b2, term)
+    with pytest.raises(ValueError):
+        ops.head_layer1_object(g, l, lab, n, (h, w), wd[:2], None, None, None, w2, b2, term)
+    with pytest.raises(RuntimeError):
+        ops.head_layer1_object(g.requires_grad_(), l, lab, n, (h, w), wd, None, None, None, w2, b2, term)

@@ -30,7 +30,7 @@ def run(cases, seed, verbose=False):
 
     with torch.no_grad():
         for _ in range(cases):
-            kind = ri(0, 5)
+            kind = ri(0, 7)
             if kind == 0:  # depthwise 7x7 + BN + ReLU
                 B, C, h, w = ri(1, 4), ri(1, 40), ri(1, 70), ri(1, 80)
                 x = rn(B, C, h, w)
@@ -77,6 +77,31 @@ def run(cases, seed, verbose=False):
                 # ties / near-ties may flip with the interpolation's rounding: compare the chosen logits, not the indices
                 chosen = torch.gather(up, 1, got.long().view(1, 1, H, W)).view(-1)
                 check("upsample_argmax", chosen, up.max(1).values.view(-1), 0, 2e-5, (n, h, w, H, W))
+            elif kind == 6:  # r5: layer 1's per-object half in one launch against the torch chain on the assembled channels
+                n_ids, h, w = ri(1, 6), ri(1, 70), 4 * ri(1, 35)
+                gm, lm = torch.rand(h, w, n_ids, generator=gd, device=dev), torch.rand(h, w, n_ids, generator=gd, device=dev)
+                lab = torch.randint(-1, n_ids + 1, (h, w), generator=gd, device=dev, dtype=torch.int32)
+                wd, bd = rn(3, 1, 7, 7) * 0.2, (rn(3) if ri(0, 1) else None)
+                sc, sh = rn(3).abs() + 0.5, rn(3)
+                w2, b2, term = rn(3, 256) * 0.3, rn(256), rn(1, 256, h, w)
+                relu = bool(ri(0, 1))
+                got = ops.head_layer1_object(gm, lm, lab, n_ids, (h, w), wd, bd, sc, sh, w2, b2, term, relu_out=relu)
+                ids = torch.arange(n_ids, device=dev).view(n_ids, 1, 1)
+                x = torch.stack((gm.permute(2, 0, 1), lm.permute(2, 0, 1), (lab.unsqueeze(0) == ids).float()), 1)
+                y = torch.relu(F.conv2d(x, wd, bd, padding=3, groups=3) * sc.view(1, 3, 1, 1) + sh.view(1, 3, 1, 1))
+                want = F.conv2d(y, w2.t().reshape(256, 3, 1, 1).contiguous(), b2) + term
+                check("layer1_object", got, torch.relu(want) if relu else want, 1e-4, 1e-4, (n_ids, h, w, relu))
+            elif kind == 7:  # r5: the resident-weights 1x1 kernel on planes large enough for ranges cut in half-tile units
+                B, cin = ri(1, 5), [32, 64, 96, 128, 256][ri(0, 4)]
+                h, w = ri(50, 130), 4 * ri(20, 55)
+                x = rn(B, cin, h, w)
+                w2t, b2 = rn(cin, 256) * 0.1, rn(256)
+                relu = bool(ri(0, 1))
+                want = F.conv2d(x, w2t.t().reshape(256, cin, 1, 1).contiguous(), b2)
+                got = ops.conv1x1_mfma(x, w2t, b2, relu_out=relu)
+                check("pw_rw", got, torch.relu(want) if relu else want, 2e-4, 2e-4, (B, cin, h, w, relu))
+                one = ops.conv1x1_mfma(x[B - 1:].contiguous(), w2t, b2, relu_out=relu)  # (cut elsewhere: the same bits)
+                check("pw_rw cut", got[B - 1:], one, 0, 0, (B, cin, h, w, relu))
             else:  # head inputs
                 n_ids, h, w = ri(1, 6), ri(1, 40), ri(1, 50)
                 gm, lm = torch.rand(1, h, w, n_ids, 1, generator=gd, device=dev), torch.rand(1, h, w, n_ids, 1, generator=gd, device=dev)
