@@ -49,16 +49,24 @@ __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(co
                                                                    const float *__restrict__ bias,
                                                                    const float *__restrict__ scale,
                                                                    const float *__restrict__ shift,
-                                                                   float *__restrict__ out, int per_item)
+                                                                   float *__restrict__ out, int per_item, int ntx, int nty)
 {
     constexpr bool relu_in = RELU_IN, relu = RELU;
+    // XCD-aware block map (r5): block L runs on XCD L % 8; all tiles of a plane go to ONE XCD (plane z = 8 g + L % 8), so the halo
+    // rows / columns two neighbouring tiles share are hits in that XCD's L2 and the cache lines a tile boundary cuts (rows are
+    // 856 bytes at 480p: no tile edge is line-aligned) are completed in one L2 before they are written back.  r2-r4: a 3-D grid,
+    // tile index fastest -- the eight tiles of a plane sat on eight XCDs.
+    const int xcd_ = blockIdx.x & 7, j_ = blockIdx.x >> 3, ntile_ = ntx * nty;
+    const int tile_ = j_ % ntile_, bz = (j_ / ntile_) * 8 + xcd_;
+    const int bx = tile_ % ntx, by = tile_ / ntx;
+    if (bz >= (per_item ? B * C : C)) return;
     // E: element (r, col) at ((r >> 1) * LW + col) * 2 + (r & 1), r = row - (y0 - 3); O: the same for r - 1
     __shared__ __attribute__((aligned(16))) float tile[2 * DW_IMG];
     // per_item (r4): few channels (layer 1's 3 per-object ones: 24 workgroups walking 3 items each = 3 serial round trips on a
     // tenth of the chip) -- a workgroup per (tile, channel, batch item) instead of the batch walk
-    const int c = per_item ? (int)(blockIdx.z % (unsigned)C) : (int)blockIdx.z;
-    const int b_first = per_item ? (int)(blockIdx.z / (unsigned)C) : 0, b_end = per_item ? b_first + 1 : B;
-    const int x0 = blockIdx.x * DW_TX, y0 = blockIdx.y * DW_TY;
+    const int c = per_item ? bz % C : bz;
+    const int b_first = per_item ? bz / C : 0, b_end = per_item ? b_first + 1 : B;
+    const int x0 = bx * DW_TX, y0 = by * DW_TY;
     const long plane = (long)h * w;
     const int tid = threadIdx.x;
     // staging item = (row pair p, column pair q): rows 2p, 2p+1, 2p+2 of the tile, two columns -- one b128 store into E
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(co
                 rv[e][1] = (yok && xx + 1 >= 0 && xx + 1 < w) ? ld[k][e][1] : 0.0f;
                 if (relu_in) rv[e] = __builtin_elementwise_max(rv[e], f32x2{0.0f, 0.0f});
             }
-            if (iok) {
+            if (iok && !((ABL & 8) && b > b_first)) {  // (ABL 8, timing only: the tile is staged for the first item alone)
                 float *d = tile + (p * DW_LW + 2 * q) * 2;
                 *(f32x4 *)d = f32x4{rv[0][0], rv[1][0], rv[0][1], rv[1][1]};
                 *(f32x4 *)(d + DW_IMG) = f32x4{rv[1][0], rv[2][0], rv[1][1], rv[2][1]};
@@ -138,6 +146,7 @@ __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(co
         if (b + 1 < b_end) issue_loads(b + 1);  // in flight under this item's arithmetic
         if (t < DW_TY / 2) {
             f32x2 acc[8];
+            f32x2 wkeep[16];  // (ABL 4 only)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = f32x2{0.0f, 0.0f};
 #pragma unroll
@@ -149,11 +158,20 @@ __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(co
                 // holds all the reads in flight and the register count halves the occupancy)
                 asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])::"memory");
                 f32x2 win[16];
+                if (!(ABL & 4) || ky == 0) {  // (ABL 4, timing only: the window is read for kernel row 0 alone)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const f32x4 u = *(const f32x4 *)(row + 4 * i);
-                    win[2 * i] = f32x2{u[0], u[1]};
-                    win[2 * i + 1] = f32x2{u[2], u[3]};
+                    for (int i = 0; i < 8; ++i) {
+                        const f32x4 u = *(const f32x4 *)(row + 4 * i);
+                        win[2 * i] = f32x2{u[0], u[1]};
+                        win[2 * i + 1] = f32x2{u[2], u[3]};
+                    }
+                    if (ABL & 4) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) wkeep[i] = win[i];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) win[i] = wkeep[i];
                 }
 #pragma unroll
                 for (int kx = 0; kx < DW_K; ++kx) {
@@ -175,6 +193,7 @@ __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(co
                     const float o = fmaf(acc[j][e] + bc, sc, sh);
                     r[j] = relu ? fmaxf(o, 0.0f) : o;
                 }
+                if ((ABL & 16) && r[0] != 12345.678f) continue;  // (ABL 16, timing only: no output stores)
                 if (FAST && x + 7 < w) {  // w even, plane 8-byte aligned: float2 stores are always aligned
 #pragma unroll
                     for (int j = 0; j < 8; j += 2) *(f32x2 *)(dst + j) = f32x2{r[j], r[j + 1]};
@@ -1021,13 +1040,16 @@ extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, 
     if (!in || !weight || !out || B <= 0 || C <= 0 || h <= 0 || w <= 0 || (long)B * C > 65535)
         return manet_set_error(MANET_E_INVALID, "bad arguments (B*C must be <= 65535)");
     if (C > 65535) return manet_set_error(MANET_E_INVALID, "C must be <= 65535");
-    dim3 grid((unsigned)((w + DW_TX - 1) / DW_TX), (unsigned)((h + DW_TY - 1) / DW_TY), (unsigned)C);
+    const int ntx = (w + DW_TX - 1) / DW_TX, nty = (h + DW_TY - 1) / DW_TY;
     // the batch walk pays when every CU has workgroups to overlap; below two workgroups per CU the items go into the grid
-    const int per_item = (B > 1 && (long)grid.x * grid.y * C < 512) ? 1 : 0;
-    if (per_item) grid.z = (unsigned)(B * C);
+    const int per_item = (B > 1 && (long)ntx * nty * C < 512) ? 1 : 0;
+    const long planes = per_item ? (long)B * C : C;
+    const long nblocks = 8L * ntx * nty * ((planes + 7) / 8);  // (planes in groups of eight: one per XCD)
+    if (nblocks > 0x7fffffffL) return manet_set_error(MANET_E_INVALID, "too many tiles for one launch");
+    dim3 grid((unsigned)nblocks);
 #define DW_LAUNCH2(F_, RI_, R_, A_)                                                                                    \
     hipLaunchKernelGGL((dwconv7x7_bn_relu_kernel<F_, RI_, R_, A_>), grid, dim3(256), 0, (hipStream_t)stream, in, B, C, h, w, weight, \
-                       bias, bn_scale, bn_shift, out, per_item)
+                       bias, bn_scale, bn_shift, out, per_item, ntx, nty)
 #define DW_LAUNCH(F_, A_)                                                                                              \
     do {                                                                                                               \
         if (relu_in && relu) DW_LAUNCH2(F_, true, true, A_);                                                           \
@@ -1041,6 +1063,13 @@ extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, 
         case 1: DW_LAUNCH(true, 1); break;
         case 2: DW_LAUNCH(true, 2); break;
         case 3: DW_LAUNCH(true, 3); break;
+        case 4: DW_LAUNCH(true, 4); break;
+        case 8: DW_LAUNCH(true, 8); break;
+        case 12: DW_LAUNCH(true, 12); break;
+        case 14: DW_LAUNCH(true, 14); break;
+        case 16: DW_LAUNCH(true, 16); break;
+        case 18: DW_LAUNCH(true, 18); break;
+        case 30: DW_LAUNCH(true, 30); break;
         default: DW_LAUNCH(true, 0);
         }
 #else
