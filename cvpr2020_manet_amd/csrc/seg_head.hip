@@ -922,13 +922,19 @@ __global__ __launch_bounds__(L1_NT) void head_layer1_object_kernel(const float *
                                                                    const float *__restrict__ sc1, const float *__restrict__ sh1,
                                                                    const float *__restrict__ w2, const float *__restrict__ b2,
                                                                    const float *__restrict__ term, int relu_out,
-                                                                   float *__restrict__ out)
+                                                                   float *__restrict__ out, int ntx, int ntiles, int chunk)
 {
     __shared__ float tin[L1_OB][3][L1_TH + 6][L1_LW];
     __shared__ __attribute__((aligned(16))) float wtab[PW_CO][4];  // {w2[0][co], w2[1][co], w2[2][co], b2[co]}
-    const int tid = threadIdx.x, o0 = blockIdx.z * L1_OB;
+    // XCD-aware block map: block L runs on XCD L % 8; each XCD owns a contiguous band of `chunk` tiles (row-major) for every object
+    // group -- the cache lines a tile edge cuts (a tile row is 256 bytes at an arbitrary 8-byte alignment) are completed in ONE L2,
+    // and the objects' workgroups of a tile find the term there.
+    const int xcd_ = blockIdx.x & 7, j_ = blockIdx.x >> 3;
+    const int t_ = xcd_ * chunk + j_ % chunk, bz = j_ / chunk;
+    if (t_ >= ntiles) return;
+    const int tid = threadIdx.x, o0 = bz * L1_OB;
     const int nob = (n_ids - o0) < L1_OB ? (n_ids - o0) : L1_OB;  // objects of this workgroup (uniform)
-    const int x0 = blockIdx.x * L1_TW, y0 = blockIdx.y * L1_TH;
+    const int x0 = (t_ % ntx) * L1_TW, y0 = (t_ / ntx) * L1_TH;
     for (int i = tid; i < (L1_TH + 6) * (L1_TW + 6); i += L1_NT) {
         const int r = i / (L1_TW + 6), c = i - r * (L1_TW + 6);
         const int yy = y0 - 3 + r, xx = x0 - 3 + c;
@@ -1008,9 +1014,10 @@ extern "C" int manet_head_layer1_object_f32(const float *global_map, const float
         return manet_set_error(MANET_E_INVALID, "bad arguments");
     const int ob = n_ids >= 4 ? 2 : 1;
     auto kern = ob == 2 ? head_layer1_object_kernel<2> : head_layer1_object_kernel<1>;
-    dim3 grid((unsigned)((w + L1_TW - 1) / L1_TW), (unsigned)((h + L1_TH - 1) / L1_TH), (unsigned)((n_ids + ob - 1) / ob));
+    const int ntx = (w + L1_TW - 1) / L1_TW, ntiles = ntx * ((h + L1_TH - 1) / L1_TH), chunk = (ntiles + 7) / 8;
+    dim3 grid((unsigned)(8 * chunk * ((n_ids + ob - 1) / ob)));
     hipLaunchKernelGGL(kern, grid, dim3(L1_NT), 0, (hipStream_t)stream, global_map, local_map, (const int *)labels,
-                       h, w, n_ids, dw_weight, dw_bias, bn_scale, bn_shift, w2t_object, b2, term, relu_out, out);
+                       h, w, n_ids, dw_weight, dw_bias, bn_scale, bn_shift, w2t_object, b2, term, relu_out, out, ntx, ntiles, chunk);
     return manet_check_launch("manet_head_layer1_object_f32");
 }
 
