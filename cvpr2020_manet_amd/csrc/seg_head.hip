@@ -112,7 +112,11 @@ __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(co
     };
     const float *wk = weight + (long)c * DW_K * DW_K;
     const float bc = bias ? bias[c] : 0.0f, sc = scale ? scale[c] : 1.0f, sh = shift ? shift[c] : 0.0f;
-    const int t = tid >> 3, tg = tid & 7;  // output row pair (2t, 2t+1), group of 8 columns
+    // r5: a thread owns FOUR rows x FOUR columns (r2-r4: two rows x eight): its two output row pairs A = (4t, 4t+1) and
+    // B = (4t+2, 4t+3) share seven of the nine input row-pair lines they need, so each line is read once and used for both (27
+    // ds_read_b128 per item instead of 56), and a store instruction's 16 lanes of a row write 256 contiguous bytes (the eight-column
+    // form stored 16-byte pieces 32 bytes apart, twice)
+    const int t = tid >> 4, tg = tid & 15;  // output rows 4t .. 4t+3, columns 4 tg .. 4 tg + 3
     issue_loads(b_first);
     for (int b = b_first; b < b_end; ++b) {
 #pragma unroll
@@ -144,62 +148,64 @@ __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(co
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (b + 1 < b_end) issue_loads(b + 1);  // in flight under this item's arithmetic
-        if (t < DW_TY / 2) {
-            f32x2 acc[8];
-            f32x2 wkeep[16];  // (ABL 4 only)
+        if (t < DW_TY / 4) {
+            f32x2 accA[4], accB[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = f32x2{0.0f, 0.0f};
+            for (int j = 0; j < 4; ++j) accA[j] = accB[j] = f32x2{0.0f, 0.0f};
 #pragma unroll
-            for (int ky = 0; ky < ((ABL & 1) ? 1 : DW_K); ++ky) {
-                // input rows (2t + ky, 2t + ky + 1): pair t + ky/2 of E (ky even) or pair t + (ky-1)/2 of O (ky odd); output
-                // column 8 tg + j, tap kx reads LDS column 8 tg + j + kx + 1 (LDS column 0 is image column x0 - 4)
-                const float *row = tile + ((ky & 1) ? DW_IMG : 0) + ((t + (ky >> 1)) * DW_LW + 8 * tg) * 2;
-                // (ties the reads of this kernel row behind the previous row's arithmetic: the fully unrolled loop otherwise
-                // holds all the reads in flight and the register count halves the occupancy)
-                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])::"memory");
-                f32x2 win[16];
-                if (!(ABL & 4) || ky == 0) {  // (ABL 4, timing only: the window is read for kernel row 0 alone)
+            for (int m = 0; m < ((ABL & 1) ? 1 : DW_K + 2); ++m) {
+                // line m = input rows (4t + m, 4t + m + 1): pair 2t + m/2 of E (m even) or pair 2t + (m-1)/2 of O (m odd); it is
+                // kernel row m of output pair A and kernel row m - 2 of pair B.  Output column 4 tg + j, tap kx reads LDS column
+                // 4 tg + j + kx + 1 (LDS column 0 is image column x0 - 4): columns 4 tg .. 4 tg + 11 = three aligned b128
+                const float *row = tile + ((m & 1) ? DW_IMG : 0) + ((2 * t + (m >> 1)) * DW_LW + 4 * tg) * 2;
+                // (ties the reads of this line behind the previous line's arithmetic: the fully unrolled loop otherwise holds all
+                // the reads in flight and the register count halves the occupancy)
+                asm volatile("" : "+v"(accA[0]), "+v"(accA[1]), "+v"(accA[2]), "+v"(accA[3]), "+v"(accB[0]), "+v"(accB[1]), "+v"(accB[2]), "+v"(accB[3])::"memory");
+                f32x2 win[12];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const f32x4 u = *(const f32x4 *)(row + 4 * i);
-                        win[2 * i] = f32x2{u[0], u[1]};
-                        win[2 * i + 1] = f32x2{u[2], u[3]};
-                    }
-                    if (ABL & 4) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) wkeep[i] = win[i];
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) win[i] = wkeep[i];
+                for (int i = 0; i < 6; ++i) {
+                    const f32x4 u = *(const f32x4 *)(row + 4 * i);
+                    win[2 * i] = f32x2{u[0], u[1]};
+                    win[2 * i + 1] = f32x2{u[2], u[3]};
                 }
+                if (m < DW_K) {
 #pragma unroll
-                for (int kx = 0; kx < DW_K; ++kx) {
-                    const float wv = wk[ky * DW_K + kx];
-                    const f32x2 w2 = {wv, wv};
+                    for (int kx = 0; kx < DW_K; ++kx) {
+                        const float wv = wk[m * DW_K + kx];
+                        const f32x2 w2 = {wv, wv};
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = __builtin_elementwise_fma(win[kx + j + 1], w2, acc[j]);
+                        for (int j = 0; j < 4; ++j) accA[j] = __builtin_elementwise_fma(win[kx + j + 1], w2, accA[j]);
+                    }
+                }
+                if (m >= 2) {
+#pragma unroll
+                    for (int kx = 0; kx < DW_K; ++kx) {
+                        const float wv = wk[(m - 2) * DW_K + kx];
+                        const f32x2 w2 = {wv, wv};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) accB[j] = __builtin_elementwise_fma(win[kx + j + 1], w2, accB[j]);
+                    }
                 }
             }
-            const int x = x0 + 8 * tg;
+            const int x = x0 + 4 * tg;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int y = y0 + 2 * t + e;
+            for (int e = 0; e < 4; ++e) {
+                const int y = y0 + 4 * t + e;
                 if (y >= h) continue;
                 float *dst = (float *)((char *)(out + ((long)b * C + c) * plane) + 4u * (unsigned)(y * w + x));
-                float r[8];
+                float r[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float o = fmaf(acc[j][e] + bc, sc, sh);
+                for (int j = 0; j < 4; ++j) {
+                    const float o = fmaf((e < 2 ? accA[j][e] : accB[j][e - 2]) + bc, sc, sh);
                     r[j] = relu ? fmaxf(o, 0.0f) : o;
                 }
                 if ((ABL & 16) && r[0] != 12345.678f) continue;  // (ABL 16, timing only: no output stores)
-                if (FAST && x + 7 < w) {  // w even, plane 8-byte aligned: float2 stores are always aligned
+                if (FAST && x + 3 < w) {  // w even, plane 8-byte aligned: float2 stores are always aligned
 #pragma unroll
-                    for (int j = 0; j < 8; j += 2) *(f32x2 *)(dst + j) = f32x2{r[j], r[j + 1]};
+                    for (int j = 0; j < 4; j += 2) *(f32x2 *)(dst + j) = f32x2{r[j], r[j + 1]};
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
+                    for (int j = 0; j < 4; ++j)
                         if (x + j < w) dst[j] = r[j];
                 }
             }
