@@ -915,12 +915,14 @@ __global__ __launch_bounds__(RW_NT, 2) void conv1x1_rw_kernel(const float *__res
 // -- operation for operation what dwconv7x7_bn_relu_kernel and conv1x1_mfma_kernel (a k-ascending fmaf chain from zero, bias, `add`,
 // ReLU) compute on head_inputs_kernel's channels: the same bits.  A stream: reads the term once per object (26 MB each, L2-shared
 // between the objects' workgroups of a tile), writes the [n,256,h,w] activation once.
-// A workgroup owns a 2 x 64 pixel tile for OB objects; its waves split the 256 output channels in L1_CW parts (each recomputes the
-// cheap depthwise stage from the shared LDS tile: 25 680 pixels are only 401 waves' worth of lanes) and keep L1_UNROLL term loads in
-// flight per lane (a lane's accesses are HW floats apart: the memory system sees a wave's 256-byte row segments only -- depth is
-// what fills the pipe).  OB = 1 up to three objects, 2 from four (the pair reads the term once): the sweep over
-// (rows, channel parts, objects) per workgroup is in docs/history/r05_experiments.md -- 32 us at 3 objects, 90 us at 720p x 6.
-constexpr int L1_TH = 2, L1_TW = 64, L1_CW = 2, L1_NT = L1_TH * L1_TW * L1_CW, L1_LW = L1_TW + 6 + 1, L1_UNROLL = 16;
+// A workgroup owns a 2 x 64 pixel tile for OB objects; its waves split the 256 output channels in L1_CW parts (25 680 pixels are only
+// 401 waves' worth of lanes).  The depthwise stage runs ONCE per tile -- channel c by the threads of part c % L1_CW -- and reaches the
+// other parts through LDS; then every thread streams its 64 channels, L1_UNROLL term loads in flight per lane (a lane's accesses are
+// HW floats apart: the memory system sees a wave's 256-byte row segments only).  OB = 1 up to three objects, 2 from four.
+// Timed by rocprofv3 on rotating buffers (nothing in the 256 MB memory-side cache; a python loop around the op is host-bound at
+// ~30 us and hid this): 2 parts, each recomputing the depthwise stage, 16 loads in flight 40.9 us at 3 objects / 33.1 at 2; this form
+// 37.3 / 26.4; a framework broadcast-add moving the same bytes 28.7 (docs/history/r05_experiments.md).
+constexpr int L1_TH = 2, L1_TW = 64, L1_CW = 4, L1_NT = L1_TH * L1_TW * L1_CW, L1_LW = L1_TW + 6 + 1, L1_UNROLL = 8;
 template <int L1_OB>
 __global__ __launch_bounds__(L1_NT) void head_layer1_object_kernel(const float *__restrict__ gmap, const float *__restrict__ lmap,
                                                                    const int *__restrict__ labels, int h, int w, int n_ids,
@@ -965,11 +967,13 @@ __global__ __launch_bounds__(L1_NT) void head_layer1_object_kernel(const float *
     __syncthreads();
     const int cw = tid / (L1_TH * L1_TW), pt = tid - cw * (L1_TH * L1_TW);  // channel quarter (= wave), pixel of the tile
     const int ty = pt / L1_TW, tx = pt - ty * L1_TW;
-    float d[L1_OB][3];
+    // the depthwise stage ONCE per tile: channel c by the threads of channel part c % L1_CW, shared through LDS
+    __shared__ float dsh[L1_OB][3][L1_TH * L1_TW];
 #pragma unroll
     for (int j = 0; j < L1_OB; ++j) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+            if (c % L1_CW != cw) continue;  // (uniform per wave)
             float acc = 0.0f;
             if (j < nob) {
 #pragma unroll
@@ -977,9 +981,15 @@ __global__ __launch_bounds__(L1_NT) void head_layer1_object_kernel(const float *
 #pragma unroll
                     for (int kx = 0; kx < DW_K; ++kx) acc = fmaf(tin[j][c][ty + ky][tx + kx], w1[c * DW_K * DW_K + ky * DW_K + kx], acc);
             }
-            d[j][c] = fmaxf(fmaf(acc + (b1 ? b1[c] : 0.0f), sc1 ? sc1[c] : 1.0f, sh1 ? sh1[c] : 0.0f), 0.0f);
+            dsh[j][c][pt] = fmaxf(fmaf(acc + (b1 ? b1[c] : 0.0f), sc1 ? sc1[c] : 1.0f, sh1 ? sh1[c] : 0.0f), 0.0f);
         }
     }
+    __syncthreads();
+    float d[L1_OB][3];
+#pragma unroll
+    for (int j = 0; j < L1_OB; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d[j][c] = dsh[j][c][pt];
     const int y = y0 + ty, x = x0 + tx;
     if (y >= h || x >= w) return;
     const long HW = (long)h * w, p = (long)y * w + x;
