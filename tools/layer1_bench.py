@@ -34,15 +34,23 @@ for n_ids, h, w in ((3, 120, 214), (2, 120, 214), (6, 180, 320)):
         l1, k = head.layer1, head.layer1._folded(100)
         w1, b1 = l1.conv1.weight, l1.conv1.bias
 
+        # (the op itself on rotating term buffers: `_layer1_fused` costs the host ~30 us per call in a python loop -- longer than
+        # the kernel -- and a single hot term sits in the memory-side cache; for exact kernel times run this script under
+        # `rocprofv3 --kernel-trace --stats`)
+        terms = [memo["term"].clone() for _ in range(10)]
+        args = (w1[100:], b1[100:], k["scale1"][100:], k["shift1"][100:], k["w2t_object"], k["b2"])
+        turn = [0]
+
         def fused():
-            return M._layer1_fused(l1, emb, gmap, lmap, lab, n_ids, (h, w), memo=memo)
+            turn[0] += 1
+            return ops.head_layer1_object(gmap, lmap, lab, n_ids, (h, w), *args, terms[turn[0] % 10], relu_out=True)
 
         def three():
             po = ops.head_inputs(gmap, lmap, lab, n_ids, (h, w))
             p1 = ops.dwconv7x7_bn_relu(po, w1[100:], b1[100:], scale=k["scale1"][100:], shift=k["shift1"][100:])
             return ops.conv1x1_mfma(p1, k["w2t_object"], k["b2"], relu_out=True, add=memo["term"])
 
-        assert torch.equal(fused(), three())
+        assert torch.equal(fused(), three()) and torch.equal(M._layer1_fused(l1, emb, gmap, lmap, lab, n_ids, (h, w), memo=memo), three())
         best = {"fused": 1e9, "three launches": 1e9}
         mean_us(fused, 300)
         for _ in range(4):
