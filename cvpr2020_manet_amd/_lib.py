@@ -75,6 +75,7 @@ SIGNATURES = {
     "manet_conv1x1_head_f32": (_i, [_vp, _i64, _i, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "manet_conv1x1_add_f32": (_i, [_vp, _i64, _i, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "manet_label_resize_nearest": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "manet_frame_begin": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i64, ctypes.c_float, _vp, ctypes.c_float, _vp]),
     "manet_head_inputs_f32": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
     "manet_conv1x1_x3_weight_bytes": (_i64, [_i]),
     "manet_conv1x1_x3_pack": (_i, [_vp, _i, _i, _vp, _vp]),

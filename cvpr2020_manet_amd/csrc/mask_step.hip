@@ -89,6 +89,23 @@ __global__ __launch_bounds__(256) void label_resize_kernel(const long long *__re
     small[i] = (int)mask[(long)Y * W + X];
 }
 
+// manet_frame_begin: the label resize + the two small fills a propagated frame needs before its matches, one launch
+__global__ __launch_bounds__(256) void frame_begin_kernel(const long long *__restrict__ mask, int H, int W, int h, int w,
+                                                          int *__restrict__ small, float *__restrict__ fill, long fill_n, float fill_v,
+                                                          float *__restrict__ scalar_dst, float scalar_v)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && scalar_dst) *scalar_dst = scalar_v;
+    if (i < fill_n) fill[i] = fill_v;
+    if (i >= (long)h * w) return;
+    const int y = (int)(i / w), x = (int)(i - (long)y * w);
+    const float sy = (float)H / (float)h, sx = (float)W / (float)w;  // as label_resize_kernel
+    int Y = (int)floorf((float)y * sy), X = (int)floorf((float)x * sx);
+    if (Y > H - 1) Y = H - 1;
+    if (X > W - 1) X = W - 1;
+    small[i] = (int)mask[(long)Y * W + X];
+}
+
 // the per-object channels of the head's input (IntVOS.py:663-669): out[o] = (global map of o, local map of o, label == o)
 __global__ __launch_bounds__(256) void head_inputs_kernel(const float *__restrict__ gmap, const float *__restrict__ lmap,
                                                           const int *__restrict__ labels, long HW, int n_ids,
@@ -114,6 +131,18 @@ extern "C" int manet_label_resize_nearest(const int64_t *mask_hw, int H, int W, 
     hipLaunchKernelGGL(label_resize_kernel, dim3((unsigned)(((long)h * w + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const long long *)mask_hw, H, W, h, w, (int *)label_small_hw);
     return manet_check_launch("manet_label_resize_nearest");
+}
+
+extern "C" int manet_frame_begin(const int64_t *mask_hw, int H, int W, int h, int w, int32_t *label_small_hw, float *fill,
+                                 int64_t fill_n, float fill_value, float *scalar_dst, float scalar_value, manet_stream_t stream)
+{
+    if (!mask_hw || !label_small_hw || h <= 0 || w <= 0 || H <= 0 || W <= 0 || fill_n < 0 || (fill_n > 0 && !fill))
+        return manet_set_error(MANET_E_INVALID, "bad arguments");
+    const long n = (long)h * w > fill_n ? (long)h * w : (long)fill_n;
+    hipLaunchKernelGGL(frame_begin_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long *)mask_hw, H, W, h, w, (int *)label_small_hw, fill, (long)fill_n, fill_value, scalar_dst,
+                       scalar_value);
+    return manet_check_launch("manet_frame_begin");
 }
 
 extern "C" int manet_head_inputs_f32(const float *global_map, const float *local_map, const int32_t *labels, int64_t HW,

@@ -795,7 +795,9 @@ class IntVOS(nn.Module):
             return scaled_ref[0]
         if (bs == 1 and previous_frame_mask.is_cuda and not previous_frame_mask.is_floating_point()
                 and previous_frame_mask.numel() == previous_frame_mask.shape[-1] * previous_frame_mask.shape[-2]):
-            scale_previous_frame_label = ops.label_resize_nearest(previous_frame_mask, (h, w))  # the same, one launch
+            # the same in one launch -- issued inside the loop below (ops.frame_begin), where it can carry the frame's two small
+            # device writes along: the local map's pre-set and the distance weight (r5; each was a ~5 us launch of its own)
+            scale_previous_frame_label = None
         else:
             scale_previous_frame_label = F.interpolate(previous_frame_mask.float(), size=(h, w), mode="nearest").int()
         for n in range(bs):
@@ -860,6 +862,22 @@ class IntVOS(nn.Module):
                     lpre = torch.empty((h, w, n_ids), dtype=torch.float32, device=current_frame_embedding.device)
                 fcur, preset_done = self._prepared_frame(current_frame_embedding[n],
                                                          preset=lpre if self._local_radius() >= 11 else None)
+            weight_written = False
+            if scale_previous_frame_label is None:  # (bs == 1: the fast label resize, deferred to here)
+                fill_t, w_dst, w_val = None, None, 0.0
+                if (fused_local and lpre is not None and self._local_radius() >= 11 and not preset_done
+                        and lpre.dtype == torch.float32 and lpre.is_contiguous()):
+                    fill_t = lpre
+                if fused_local and local_map_dics is not None and seq_names[n] in local_map_dics[1]:
+                    tab_w = local_map_dics[1][seq_names[n]]
+                    fn_, in_ = int(frame_num[n]), int(interaction_num) - 1
+                    if (tab_w.dtype == torch.float32 and tab_w.is_cuda and tab_w.dim() == 2 and tab_w.is_contiguous()
+                            and 0 <= fn_ < tab_w.shape[0] and 0 <= in_ < tab_w.shape[1] and fn_ != start_annotated_frame):
+                        w_dst, w_val = tab_w[fn_][in_], 1.0 / abs(fn_ - start_annotated_frame)
+                scale_previous_frame_label = ops.frame_begin(previous_frame_mask, (h, w), fill=fill_t, fill_value=1.0,
+                                                             scalar_dst=w_dst, scalar_value=w_val)
+                preset_done = preset_done or fill_t is not None
+                weight_written = w_dst is not None
             if pre is not None:  # computed ahead of the chain (global_maps): out == mem after the fused min-merge
                 mem.view(-1).copy_(pre.reshape(-1))
                 nn_features_n = mem.view(1, h, w, n_ids, 1).clone()
@@ -909,7 +927,8 @@ class IntVOS(nn.Module):
                 # (fill_, not `tab[i][j] = weight`: indexed assignment of a python number to a device tensor goes through a
                 # one-element HOST tensor and a blocking host-to-device copy -- the host then waits for the whole frame's queue,
                 # ~0.85 ms, and the device idles ~70 us per frame until the next launch arrives; fill_ is one async launch)
-                dist_tab[frame_num[n]][interaction_num - 1].fill_(weight)
+                if not weight_written:  # (else: it rode in ops.frame_begin's launch -- a raw write, the version counter stands)
+                    dist_tab[frame_num[n]][interaction_num - 1].fill_(weight)
                 fkey = int(frame_num[n])
                 if mirror is not None:
                     mirror[1] = dist_tab._version

@@ -681,6 +681,30 @@ def label_resize_nearest(mask, size):
     return out
 
 
+def frame_begin(mask, size, fill=None, fill_value=1.0, scalar_dst=None, scalar_value=0.0):
+    """label_resize_nearest(mask, size) plus up to two small device writes in the SAME launch (manet_frame_begin): `fill` (a
+    contiguous float32 tensor) := fill_value -- the local map's slot pre-set for the wide windows -- and the one-element float32
+    tensor `scalar_dst` := scalar_value -- the frame's distance weight in the caller's table (IntVOS.py:641).  Each was a ~5 us
+    launch of its own in a propagated frame.  Returns the int32 [1, 1, h, w] label."""
+    lib = _lib.load()
+    _need_gpu(mask, "mask")
+    if mask.is_floating_point() or mask.numel() != mask.shape[-1] * mask.shape[-2]:
+        raise ValueError("mask must be ONE integer image [.., H, W]")
+    m = mask.to(torch.int64).contiguous()
+    H, W = int(m.shape[-2]), int(m.shape[-1])
+    h, w = int(size[0]), int(size[1])
+    for name, t, n in (("fill", fill, None), ("scalar_dst", scalar_dst, 1)):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.device != m.device or (n is not None and t.numel() != n)):
+            raise ValueError("%s must be a contiguous float32 tensor on the mask's device%s" % (name, "" if n is None else " with one element"))
+    out = torch.empty((1, 1, h, w), dtype=torch.int32, device=m.device)
+    with _on(m.device):
+        rc = lib.manet_frame_begin(m.data_ptr(), H, W, h, w, out.data_ptr(), None if fill is None else fill.data_ptr(),
+                                   0 if fill is None else fill.numel(), float(fill_value),
+                                   None if scalar_dst is None else scalar_dst.data_ptr(), float(scalar_value), _stream_ptr(m.device))
+    _lib.check(rc, "manet_frame_begin")
+    return out
+
+
 def head_layer1_object(global_map, local_map, labels, n_ids, size, dw_weight, dw_bias, bn_scale, bn_shift, w2t_object, b2, term,
                        relu_out=True):
     """DynamicSegHead layer 1, per-object half, in one launch (manet_head_layer1_object_f32): the per-object input channels

@@ -172,7 +172,7 @@ class StageTimer:
               "conv1x1_mfma": "head: conv1x1_mfma_kernel", "relu_conv1x1_c1": "head: relu_conv1x1_c1_kernel",
               "local_match_frames": "local match: local_fused_kernel", "prepare_frames": "frame_prepare_kernel",
               "head_inputs": "head_inputs_kernel", "head_layer1_object": "head: head_layer1_object_kernel", "upsample_argmax": "mask step: upsample_argmax_kernel",
-              "label_resize_nearest": "label_resize_kernel"}
+              "label_resize_nearest": "label_resize_kernel", "frame_begin": "frame_begin_kernel (label resize + local-map pre-set + weight)"}
 
     def __init__(self):
         self.records = []

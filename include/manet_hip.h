@@ -315,6 +315,13 @@ int manet_upsample_argmax(const float *logits, int n_ids, int h, int w, int H, i
  *     from global_map / local_map [HW][n_ids] fp32 and labels [HW] int32. */
 int manet_label_resize_nearest(const int64_t *mask_hw, int H, int W, int h, int w, int32_t *label_small_hw,
                                manet_stream_t stream);
+/* r5: manet_label_resize_nearest plus the two small device writes a propagated frame makes before its matches, in the same launch
+ * (each was a ~5 us launch of its own): `fill` [fill_n] = fill_value (the local map's slot pre-set to 1.0 for the wide windows
+ * whose workgroups meet by atomic min, networks/IntVOS.py:627-634 / manet_local_match_frames' `out_is_preset`) and
+ * *scalar_dst = scalar_value (the frame's distance weight in the caller's table, networks/IntVOS.py:641).  fill_n = 0 and
+ * scalar_dst = NULL leave either out. */
+int manet_frame_begin(const int64_t *mask_hw, int H, int W, int h, int w, int32_t *label_small_hw, float *fill, int64_t fill_n,
+                      float fill_value, float *scalar_dst, float scalar_value, manet_stream_t stream);
 /* r5: DynamicSegHead layer 1, per-object half, in ONE launch (networks/IntVOS.py:663-669 input assembly -> :491-494 depthwise 7x7 +
  * bn1 + relu1 and the 1x1 + bn2 of the three per-object channels -> + `term`, the shared-embedding half's [256][HW] contribution ->
  * relu2): global_map / local_map [HW][n_ids], labels [HW] int32; dw_weight [3][49], dw_bias / bn_scale / bn_shift [3] (NULL: 0 / 1 / 0);

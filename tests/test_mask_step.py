@@ -82,3 +82,32 @@ def test_label_resize_and_head_inputs_match_the_framework_ops():
         ops.label_resize_nearest(torch.zeros(1, 1, 4, 4, device="cuda"), (2, 2))  # floating-point mask
     with pytest.raises(ValueError):
         ops.head_inputs(torch.zeros(5, device="cuda"), torch.zeros(5, device="cuda"), torch.zeros(2, 2, device="cuda"), 2, (2, 2))
+
+
+@pytest.mark.gpu
+def test_frame_begin_is_the_label_resize_plus_two_fills():
+    """r5 manet_frame_begin: label_resize_nearest + the local map's pre-set + the distance weight (IntVOS.py:641) in ONE launch --
+    the label equals the stand-alone op's, the fill and the scalar land where they should (and nowhere else), either may be absent;
+    refusals for tensors it cannot write"""
+    import torch
+    from cvpr2020_manet_amd import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(3)
+    for (H, W, h, w, nfill) in ((480, 854, 120, 214, 120 * 214 * 3), (37, 53, 9, 14, 5), (64, 64, 16, 16, 16 * 16 * 9), (480, 854, 120, 214, 0)):
+        mask = torch.randint(0, 5, (1, 1, H, W), generator=g, device=dev)
+        want = ops.label_resize_nearest(mask, (h, w))
+        buf = torch.full((nfill + 7,), -3.0, device=dev)
+        tab = torch.zeros(6, 9, device=dev)
+        got = ops.frame_begin(mask, (h, w), fill=buf[3:3 + nfill] if nfill else None, fill_value=1.0, scalar_dst=tab[4][2], scalar_value=1.0 / 3.0)
+        assert torch.equal(got, want)
+        assert bool((buf[3:3 + nfill] == 1.0).all()) and bool((buf[:3] == -3.0).all()) and bool((buf[3 + nfill:] == -3.0).all())
+        assert float(tab[4][2]) == float(torch.tensor(1.0 / 3.0, dtype=torch.float32)) and int((tab != 0).sum()) == 1
+        assert torch.equal(ops.frame_begin(mask, (h, w)), want)  # neither extra
+    with pytest.raises(ValueError):
+        ops.frame_begin(mask, (h, w), fill=torch.zeros(4, dtype=torch.float64, device=dev))
+    with pytest.raises(ValueError):
+        ops.frame_begin(mask, (h, w), scalar_dst=torch.zeros(2, device=dev))
+    with pytest.raises(ValueError):
+        ops.frame_begin(mask, (h, w), fill=torch.zeros(4, 4, device=dev)[:, 1])
+    with pytest.raises(ValueError):
+        ops.frame_begin(mask.float(), (h, w))
