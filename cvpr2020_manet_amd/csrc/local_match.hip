@@ -397,9 +397,15 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
                                                                const float *__restrict__ prevp, int WS, long PS,
                                                                const int *__restrict__ labels, int h, int w, int C,
                                                                int n_ids, float *__restrict__ out,
-                                                               const int *__restrict__ tab, int abl, int ntx, int nty,
+                                                               const int *__restrict__ tab, int abl_arg, int ntx, int nty,
                                                                int rw, int rh)
 {
+    // (the ablation switch is a compile-time 0 outside -DMANET_ABLATION builds: no run-time tests in the loops)
+#ifdef MANET_ABLATION
+    const int abl = abl_arg;
+#else
+    constexpr int abl = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int P = 2 * D + 1, NT = lf_nt(D), ND = lf_nd(D), NDG = lf_ndg(D), SY = lf_sy(D), TY = SY - 1;
     constexpr int TX = LF_SX - 1, CW = lf_cw(D), YR = lf_yr(D), CC = lf_cc(D), COLS = lf_cols(D), NG = LF_SX / COLS;
