@@ -690,7 +690,7 @@ class IntVOS(nn.Module):
             # the embedding layer's epilogue fused with the frame prepare (ops.embed_finish): bn2 + relu2 + the storage cast +
             # the operands of every frame of the batch in ONE launch behind the framework's 1x1 GEMM -- the embedding is
             # written once and never re-read for packing (r3: three elementwise passes, then manet_frame_prepare's re-read)
-            y = self.embedding_conv(self.relu1(self.bn1(self.seperate_conv(x))))
+            y = self.embedding_conv(self._separate_conv_bn_relu(x))
             scale, shift = ops.fold_bn(self.bn2)
             d = self._local_radius()
             emb, frames = ops.embed_finish(y, scale, shift, relu=True, emb_dtype=self.emb_dtype, compute=self.compute,
@@ -713,6 +713,29 @@ class IntVOS(nn.Module):
         if packed:
             x = self.prepare_clip(x, batch=max(1, x.shape[0]))
         return x
+
+    def _separate_conv_bn_relu(self, x):
+        """relu1(bn1(seperate_conv(x))) of the embedding head (IntVOS.py:537-539: depthwise 3x3 + BatchNorm + ReLU) in ONE launch
+        of the head's depthwise kernel (r5): the 3x3 taps sit in the middle of a 7x7 kernel of zeros -- fmaf(x, 0, acc) = acc, the
+        nine real taps in the order a 3x3 loop visits them, bn1 folded as in the head.  The framework runs the three modules as
+        three launches (208 us per 480p frame against 40; a non-finite activation next to a zero tap becomes NaN here: Inf * 0).
+        Falls back to the module sequence for anything else than a 3x3 / stride 1 / padding 1 depthwise layer on fp32 CUDA input."""
+        conv, bn = self.seperate_conv, self.bn1
+        ok = (x.is_cuda and x.dtype == torch.float32 and not self.training and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+              and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == conv.in_channels == conv.out_channels
+              and conv.weight.dtype == torch.float32 and isinstance(bn, nn.BatchNorm2d) and bn.track_running_stats)
+        if not ok:
+            return self.relu1(bn(conv(x)))
+        try:
+            key = (conv.weight._version, conv.weight.data_ptr(), conv.weight.device)
+        except RuntimeError:
+            key = None
+        hit = self.__dict__.get("_sep7")
+        if hit is None or key is None or hit[0] != key:
+            w7 = torch.zeros((conv.out_channels, 1, 7, 7), dtype=torch.float32, device=conv.weight.device)
+            w7[:, :, 2:5, 2:5] = conv.weight.detach()
+            hit = self.__dict__["_sep7"] = (key, w7)
+        return ops.dwconv7x7_bn_relu(x.contiguous(), hit[1], conv.bias, bn=bn, relu=True)
 
     def prepare_bank(self, ref_frame_embedding, ref_scribble_label, seq_name, gt_id):
         """Sort / pack the annotated frame's memory bank NOW, on the current stream (this implementation only): what the first
