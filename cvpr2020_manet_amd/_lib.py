@@ -93,6 +93,9 @@ SIGNATURES = {
                                  ctypes.c_uint32, _vp]),
     "manet_embed_finish": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "manet_local_match_frames": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "manet_local_volume_bytes": (_i, [_i, _i, _i, ctypes.POINTER(ctypes.c_size_t)]),
+    "manet_local_volume_frames": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "manet_local_match_volume": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "manet_profile_read": (_i, [_i, ctypes.POINTER(ctypes.c_float), _i, _ip]),
     "manet_correlation_backward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "manet_correlation_backward_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

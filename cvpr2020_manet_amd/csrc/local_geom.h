@@ -86,12 +86,17 @@ __host__ __device__ constexpr int lf_lab_cols(int d) { return 2 * (LF_SX - 1) + 
 __host__ __device__ constexpr int lf_vs(int d) { return 4 * (((2 * d + 1 + 3) / 4) | 1); }
 __host__ __device__ constexpr int lf_npix(int d) { return (2 * (lf_sy(d) - 1) + 4) * (2 * (LF_SX - 1) + 4); }  // pixels of a tile, upper bound
 constexpr int LF_NIP = 8;  // object ids per pass of the per-pixel phase
+// LDS of the per-pixel phase alone (the kernel's LF_VOL_IN mode: the volume image arrives from memory)
+__host__ __device__ constexpr size_t lf_lds_vol_bytes(int d)
+{
+    return (size_t)lf_nd(d) * lf_sy(d) * LF_SX * lf_vs(d) * 4 + (((size_t)lf_lab_rows(d) * lf_lab_cols(d) + 15) & ~(size_t)15) +
+           (size_t)lf_npix(d) * (LF_NIP + 1) * 4 +                        // per-(id, pixel) minima + the "no id" row
+           (size_t)(2 * (lf_sy(d) - 1) + 4 + 2 * (LF_SX - 1) + 4) * 16;  // bilinear row / column tables
+}
 __host__ __device__ constexpr size_t lf_lds_bytes(int d)
 {
     size_t stage = 2 * (size_t)lf_stage_floats(d) * 4;
-    size_t vol = (size_t)lf_nd(d) * lf_sy(d) * LF_SX * lf_vs(d) * 4 + (((size_t)lf_lab_rows(d) * lf_lab_cols(d) + 15) & ~(size_t)15) +
-                 (size_t)lf_npix(d) * (LF_NIP + 1) * 4 +                        // per-(id, pixel) minima + the "no id" row
-                 (size_t)(2 * (lf_sy(d) - 1) + 4 + 2 * (LF_SX - 1) + 4) * 16;  // bilinear row / column tables
+    size_t vol = lf_lds_vol_bytes(d);
     return stage > vol ? stage : vol;
 }
 // padded pooled plane [HPAD][WS]: image pixel (py, px) at (d + py, d + px)

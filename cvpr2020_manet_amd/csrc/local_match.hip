@@ -392,14 +392,36 @@ extern "C" int manet_dbg_read(unsigned long long *host, size_t n) { return (int)
 #else
 #define LF_T(k)
 #endif
-template <int D>
-__global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__restrict__ curp,
-                                                               const float *__restrict__ prevp, int WS, long PS,
+// MODE (r6): the window distances depend on the two EMBEDDINGS only (IntVOS.py:266-296), the masked minimum (:398-432) on the
+// previous frame's labels -- and a clip's embeddings never change between the interaction rounds of a session (test.py:137-154
+// extracts them once per sequence).  LF_VOL_OUT: phase 1 alone, for a BATCH of frame pairs in one launch (blockIdx.y = pair): each
+// workgroup's normalised volume image -- the exact LDS image phase 2 reads, [ND][SY * 16][VS] floats -- goes to memory.  LF_VOL_IN:
+// phase 2 alone on such an image (one LDS-DMA stream instead of the channel stages): what the sequential chain runs from a
+// clip's second round on.  LF_FUSED: both in one launch, the volume never in memory (r1-r5).  Same arithmetic, same bits.
+constexpr int LF_FUSED = 0, LF_VOL_OUT = 1, LF_VOL_IN = 2;
+constexpr int LF_BATCH = 32;  // frame pairs per LF_VOL_OUT launch (their pointers travel as a kernel argument)
+struct LfBatch {
+    const float *cur[LF_BATCH], *prev[LF_BATCH];
+    float *vol[LF_BATCH];
+};
+// floats of one workgroup's volume image in memory: the LDS image padded to whole 1 KiB LDS-DMA pieces
+__host__ __device__ constexpr int lf_img_floats(int d) { return (lf_nd(d) * lf_sy(d) * LF_SX * lf_vs(d) + 255) / 256 * 256; }
+template <int D, int MODE>
+__global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__restrict__ curp_arg,
+                                                               const float *__restrict__ prevp_arg, int WS, long PS,
                                                                const int *__restrict__ labels, int h, int w, int C,
                                                                int n_ids, float *__restrict__ out,
                                                                const int *__restrict__ tab, int abl_arg, int ntx, int nty,
-                                                               int rw, int rh)
+                                                               int rw, int rh, float *__restrict__ vol_arg,
+                                                               const typename std::conditional<MODE == LF_VOL_OUT, LfBatch, int>::type batch)
 {
+    const float *curp = curp_arg, *prevp = prevp_arg;
+    float *vol = vol_arg;
+    if constexpr (MODE == LF_VOL_OUT) {
+        curp = batch.cur[blockIdx.y];
+        prevp = batch.prev[blockIdx.y];
+        vol = batch.vol[blockIdx.y];
+    }
     // (the ablation switch is a compile-time 0 outside -DMANET_ABLATION builds: no run-time tests in the loops)
 #ifdef MANET_ABLATION
     const int abl = abl_arg;
@@ -430,6 +452,7 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     if (tix >= ntx || tiy >= nty) return;  // (the regions' padding)
     const int a = tiy * TY, b0 = tix * TX;  // pooled origin of S
     const int dy0 = tiz * ND;               // first window row of this workgroup
+    float *vimg = MODE == LF_FUSED ? nullptr : vol + (long)((tiz * nty + tiy) * ntx + tix) * lf_img_floats(D);
 
     // ---- phase 1: distances on S for window rows dy0 .. dy0+ND-1 ---------------------------------
     // Staging by LDS-DMA (lds_dma16: 64 lanes x 16 bytes land in 1 KiB of LDS, no VGPR hop, no ds_write): a stage is
@@ -575,9 +598,11 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         }
     }
     };
-    stage_dma(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (MODE != LF_VOL_IN) {
+        stage_dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     LF_T(1)
     // full-resolution pixels of this tile: rows with i0(y) in [a, a+TY), columns with j0(x) in [b0, b0+TX) -- the
     // pooling pass left the ranges in `tab`
@@ -600,24 +625,36 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         const int yc = yy < 0 ? 0 : (yy < h ? yy : h - 1), xc = xx < 0 ? 0 : (xx < w ? xx : w - 1);
         int idx = yc * w + xc;
         asm volatile("" : "+v"(idx));  // the compiler must not turn the clamp back into a branch around the load:
-        const int v = labels[idx];     // unconditional loads issue back to back, a branchy one waits vmcnt(0) each time
+        int v = 0;                     // unconditional loads issue back to back, a branchy one waits vmcnt(0) each time
+        if constexpr (MODE != LF_VOL_OUT) v = labels[idx];
         labr[k] = (yy == yc && xx == xc && !(abl & 8)) ? v : 0;
+    }
+    if constexpr (MODE == LF_VOL_IN) {
+        // the whole volume image of this (tile, window-row group): one linear LDS-DMA stream, issued behind the label loads
+        constexpr int IMG_PIECES = lf_img_floats(D) / 256;
+#pragma unroll
+        for (int k = 0; k < (IMG_PIECES + NWV - 1) / NWV; ++k) {
+            const int pc = k * NWV + wave;
+            if (pc < IMG_PIECES) lds_dma16(vimg + (pc * 64 + lane) * 4, smem_base + (unsigned)pc * 1024u);
+        }
     }
     // stage s is in LDS buffer s & 1.  The DMA of stage s + 1 into the other buffer (free: its last readers passed the
     // barrier) is issued first and runs under the arithmetic of stage s; the wave waits for its own pieces (vmcnt --
     // the DMA is hidden from the compiler's counters, this is the only wait on it) and the barrier publishes them.
-    for (int c0 = 0, st_i = 0; c0 < ((abl & 16) ? 0 : C); c0 += CC, ++st_i) {
-        if (c0 + CC < C) stage_dma(c0 + CC, (st_i & 1) ^ 1);
-        compute(st_i & 1, (C - c0) < CC ? (C - c0) : CC);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    if constexpr (MODE != LF_VOL_IN) {
+        for (int c0 = 0, st_i = 0; c0 < ((abl & 16) ? 0 : C); c0 += CC, ++st_i) {
+            if (c0 + CC < C) stage_dma(c0 + CC, (st_i & 1) ^ 1);
+            compute(st_i & 1, (C - c0) < CC ? (C - c0) : CC);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 
     LF_T(2)
     constexpr int VS = lf_vs(D), NPS = lf_npix(D);
     float *V = smem;                                                 // [ND][SY * 16][VS]
     unsigned char *L = (unsigned char *)(V + ND * SY * LF_SX * VS);  // [lab_rows][lab_cols], 255 = matches no id
-    if (active) {
+    if (MODE != LF_VOL_IN && active) {
         float *vp0 = V + ((dyi * SY + ry) * LF_SX + COLS * g) * VS + dx_lo;
 #pragma unroll
         for (int j = 0; j < COLS; ++j) {
@@ -637,6 +674,18 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         }
     }
     LF_T(3)
+    if constexpr (MODE == LF_VOL_OUT) {
+        // the image as phase 2 reads it, to memory in one linear pass (entries no thread wrote -- the cells' padding past the
+        // window width, window rows past 2d+1 in the last group -- travel along and are never used)
+        __syncthreads();
+        constexpr int IMG4 = ND * SY * LF_SX * VS / 4;
+        for (int i = tid; i < IMG4; i += NT) ((f32x4 *)vimg)[i] = ((const f32x4 *)V)[i];
+        return;
+    }
+    if constexpr (MODE == LF_VOL_IN) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the image have landed ...
+        __syncthreads();                                   // ... everyone's have (the tail of the last piece overlaps L: written below)
+    }
 #pragma unroll
     for (int k = 0; k < KL; ++k) {
         const int e = tid + NT * k;
@@ -727,19 +776,30 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     }
 }
 
-template <int D>
+template <int D, int MODE = LF_FUSED>
 static void launch_fused_d(hipStream_t st, const float *ap, const float *bp, const PoolPad &G, const int *labels, int h,
-                           int w, int C, int n_ids, float *out, const int *tab)
+                           int w, int C, int n_ids, float *out, const int *tab, float *vol = nullptr,
+                           const LfBatch *batch = nullptr, int n_pairs = 1)
 {
     constexpr int TY = lf_sy(D) - 1, TX = LF_SX - 1;
     // i0 runs over 0..hp-1 (the last value only for the last row); tiles cover all of them
     const int ntx = (G.wp + TX - 1) / TX, nty = (G.hp + TY - 1) / TY;
     const int rw = (ntx + 3) / 4, rh = (nty + 1) / 2;  // tiles per XCD region (4 x 2 regions)
-    dim3 grid((unsigned)(8 * rw * rh * lf_ndg(D)));
-    const size_t lds = lf_lds_bytes(D);
-    (void)hipFuncSetAttribute((const void *)local_fused_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(local_fused_kernel<D>, grid, dim3(lf_nt(D)), lds, st, ap, bp, G.WS, G.plane, labels, h, w, C, n_ids,
-                       out, tab, manet_tune_get(MANET_TUNE_ABLATION, 0), ntx, nty, rw, rh);
+    dim3 grid((unsigned)(8 * rw * rh * lf_ndg(D)), (unsigned)(MODE == LF_VOL_OUT ? n_pairs : 1));
+    const size_t lds = MODE == LF_VOL_IN ? lf_lds_vol_bytes(D) : lf_lds_bytes(D);
+    (void)hipFuncSetAttribute((const void *)local_fused_kernel<D, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if constexpr (MODE == LF_VOL_OUT)
+        hipLaunchKernelGGL((local_fused_kernel<D, MODE>), grid, dim3(lf_nt(D)), lds, st, ap, bp, G.WS, G.plane, labels, h, w, C, n_ids,
+                           out, tab, manet_tune_get(MANET_TUNE_ABLATION, 0), ntx, nty, rw, rh, vol, *batch);
+    else
+        hipLaunchKernelGGL((local_fused_kernel<D, MODE>), grid, dim3(lf_nt(D)), lds, st, ap, bp, G.WS, G.plane, labels, h, w, C, n_ids,
+                           out, tab, manet_tune_get(MANET_TUNE_ABLATION, 0), ntx, nty, rw, rh, vol, 0);
+}
+// workgroups (= volume images) of one frame pair
+static long lf_images(int h, int w, int d)
+{
+    const int hp = h / 2, wp = w / 2, TY = lf_sy(d) - 1, TX = LF_SX - 1;
+    return (long)((wp + TX - 1) / TX) * ((hp + TY - 1) / TY) * lf_ndg(d);
 }
 
 __global__ void fill_f32_kernel(float *__restrict__ p, float v, long n)
@@ -1127,6 +1187,92 @@ int manet_local_match_frames(const void *prev_frame_ws, const void *cur_frame_ws
 #undef MANET_LF_CASE
     manet_profile_record(st, false, 1);
     return manet_check_launch("manet_local_match_frames");
+}
+
+/* r6: the label-independent half of the local match, kept per frame pair (see local_fused_kernel's MODE).
+ * manet_local_volume_bytes: bytes of one frame pair's normalised window-distance volume, stored as the per-workgroup LDS images
+ * of the per-pixel phase (1.5x the bare (2d+1)^2 x h/2 x w/2 floats at d=12: tile aprons, 16-byte cell padding). */
+int manet_local_volume_bytes(int h, int w, int max_distance, size_t *bytes)
+{
+    if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
+    int rc = check_local(h, w, 1, max_distance, 1);
+    if (rc) return rc;
+    *bytes = (size_t)lf_images(h, w, max_distance) * lf_img_floats(max_distance) * sizeof(float);
+    return MANET_OK;
+}
+
+/* phase 1 (IntVOS.py:266-296) of n_pairs frame pairs, ceil(n_pairs / 32) launches: pair i = (prev_frame_ws[i], cur_frame_ws[i]),
+ * two prepared frames (manet_frame_prepare) -> volumes[i] (manet_local_volume_bytes each, 16-byte aligned).  The three tables are
+ * HOST arrays of device pointers. */
+int manet_local_volume_frames(const void *const *prev_frame_ws, const void *const *cur_frame_ws, float *const *volumes, int n_pairs,
+                              int h, int w, int C, int compute, int max_distance, manet_stream_t stream)
+{
+    int rc = check_local(h, w, C, max_distance, 1);
+    if (rc) return rc;
+    if (n_pairs < 0 || (n_pairs > 0 && (!prev_frame_ws || !cur_frame_ws || !volumes)))
+        return manet_set_error(MANET_E_INVALID, "bad arguments");
+    const ManetFrameLayout F = manet_frame_layout(h, w, C, compute, max_distance);
+    hipStream_t st = (hipStream_t)stream;
+    PoolPad G;
+    G.hp = F.hp; G.wp = F.wp; G.HPAD = F.HPAD; G.WS = F.WS; G.plane = F.PS;
+    for (int i0 = 0; i0 < n_pairs; i0 += LF_BATCH) {
+        const int n = (n_pairs - i0) < LF_BATCH ? (n_pairs - i0) : LF_BATCH;
+        LfBatch B;
+        for (int i = 0; i < LF_BATCH; ++i) {
+            const int j = i0 + (i < n ? i : 0);
+            if (!prev_frame_ws[j] || !cur_frame_ws[j] || !volumes[j] || ((size_t)volumes[j] & 15))
+                return manet_set_error(MANET_E_INVALID, "pair %d: null frame / volume pointer, or a volume not 16-byte aligned", j);
+            B.cur[i] = (const float *)((const char *)cur_frame_ws[j] + F.off_plane);
+            B.prev[i] = (const float *)((const char *)prev_frame_ws[j] + F.off_plane);
+            B.vol[i] = volumes[j];
+        }
+        const int *tab = (const int *)((const char *)cur_frame_ws[i0] + F.off_tab);  // (the same table for every frame of a geometry)
+#define MANET_LF_CASE(D_) case D_: launch_fused_d<D_, LF_VOL_OUT>(st, nullptr, nullptr, G, nullptr, h, w, C, 1, nullptr, tab, nullptr, &B, n); break;
+        switch (max_distance) {
+            MANET_LF_CASE(0) MANET_LF_CASE(1) MANET_LF_CASE(2) MANET_LF_CASE(3) MANET_LF_CASE(4) MANET_LF_CASE(5)
+            MANET_LF_CASE(6) MANET_LF_CASE(7) MANET_LF_CASE(8) MANET_LF_CASE(9) MANET_LF_CASE(10) MANET_LF_CASE(11)
+            MANET_LF_CASE(12)
+        default: break;
+        }
+#undef MANET_LF_CASE
+    }
+    return manet_check_launch("manet_local_volume_frames");
+}
+
+/* phase 2 (IntVOS.py:398-432) on a stored volume: bilinear taps + stride-2 label gather + masked minimum -> out [h][w][n_ids]; the
+ * same bits as manet_local_match_frames on the pair the volume was made from.  cur_frame_ws: the current frame's prepared
+ * workspace (its tile table). */
+int manet_local_match_volume(const float *volume, const void *cur_frame_ws, const int32_t *prev_labels, int h, int w, int C,
+                             int compute, int n_ids, int max_distance, float *out, int out_is_preset, manet_stream_t stream)
+{
+    int rc = check_local(h, w, C, max_distance, 1);
+    if (rc) return rc;
+    if (n_ids <= 0 || n_ids > MANET_MAX_IDS)
+        return manet_set_error(MANET_E_INVALID, "n_ids=%d (supported 1..%d)", n_ids, MANET_MAX_IDS);
+    if (!volume || !cur_frame_ws || !prev_labels || !out || ((size_t)volume & 15))
+        return manet_set_error(MANET_E_INVALID, "null pointer (or a volume not 16-byte aligned)");
+    const ManetFrameLayout F = manet_frame_layout(h, w, C, compute, max_distance);
+    hipStream_t st = (hipStream_t)stream;
+    PoolPad G;
+    G.hp = F.hp; G.wp = F.wp; G.HPAD = F.HPAD; G.WS = F.WS; G.plane = F.PS;
+    const int *tab = (const int *)((const char *)cur_frame_ws + F.off_tab);
+    manet_profile_record(st, true, 1);
+    if (lf_ndg(max_distance) > 1 && !out_is_preset) {  // partial minima of several workgroups per tile meet by atomicMin
+        const long n_out = (long)h * w * n_ids;
+        unsigned blocks = (unsigned)((n_out + 255) / 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(fill_f32_kernel, dim3(blocks), dim3(256), 0, st, out, 1.0f, n_out);
+    }
+#define MANET_LF_CASE(D_) case D_: launch_fused_d<D_, LF_VOL_IN>(st, nullptr, nullptr, G, prev_labels, h, w, C, n_ids, out, tab, (float *)volume); break;
+    switch (max_distance) {
+        MANET_LF_CASE(0) MANET_LF_CASE(1) MANET_LF_CASE(2) MANET_LF_CASE(3) MANET_LF_CASE(4) MANET_LF_CASE(5)
+        MANET_LF_CASE(6) MANET_LF_CASE(7) MANET_LF_CASE(8) MANET_LF_CASE(9) MANET_LF_CASE(10) MANET_LF_CASE(11)
+        MANET_LF_CASE(12)
+    default: break;
+    }
+#undef MANET_LF_CASE
+    manet_profile_record(st, false, 1);
+    return manet_check_launch("manet_local_match_volume");
 }
 
 /* training path: downsample configuration only (the reference's live default, config.py:49) */

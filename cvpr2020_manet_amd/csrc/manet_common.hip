@@ -41,7 +41,32 @@ void manet_profile_record(hipStream_t st, bool start, int channel)
 
 static int g_tune[MANET_TUNE_COUNT] = {0};
 static bool g_tune_set[MANET_TUNE_COUNT] = {false};
-int manet_tune_get(int key, int dflt) { return (key >= 0 && key < MANET_TUNE_COUNT && g_tune_set[key]) ? g_tune[key] : dflt; }
+// experiments without touching a caller's code: MANET_TUNING=1 MANET_TUNE_INIT="11=128,12=17" sets knobs at the first read
+static std::once_flag g_tune_env_once;
+static void tune_env_init()
+{
+    const char *opt = getenv("MANET_TUNING"), *init = getenv("MANET_TUNE_INIT");
+    if (!opt || opt[0] != '1' || !init) return;
+    for (const char *p = init; *p;) {
+        char *end = nullptr;
+        const long key = strtol(p, &end, 10);
+        if (end == p || *end != '=') break;
+        p = end + 1;
+        const long val = strtol(p, &end, 10);
+        if (end == p) break;
+        if (key >= 0 && key < MANET_TUNE_COUNT) {
+            g_tune[key] = (int)val;
+            g_tune_set[key] = true;
+        }
+        p = (*end == ',' || *end == ';') ? end + 1 : end;
+        if (*end != ',' && *end != ';') break;
+    }
+}
+int manet_tune_get(int key, int dflt)
+{
+    std::call_once(g_tune_env_once, tune_env_init);
+    return (key >= 0 && key < MANET_TUNE_COUNT && g_tune_set[key]) ? g_tune[key] : dflt;
+}
 
 extern "C" {
 

@@ -1151,7 +1151,9 @@ static int conv1x1_f32_impl(const float *in, int64_t in_batch_stride, int B, int
         const int tpp = (int)((HW + RW_P - 1) / RW_P);
         const long total = (long)tpp * B;
         int G = 256;  // pixel-range groups: one per CU; each is served by two workgroups (the output-channel halves)
+        if (manet_tune_get(MANET_TUNE_RW_GROUPS, 0) > 0) G = manet_tune_get(MANET_TUNE_RW_GROUPS, 0);
         if (total < G) G = (int)total;
+        const size_t rw_pad = (size_t)manet_tune_get(MANET_TUNE_RW_LDS_PAD, 0) * 1024;
         const unsigned blocks = (unsigned)(((G + 7) / 8) * 16);
 #ifdef MANET_ABLATION
         const int rw_abl = manet_tune_get(MANET_TUNE_ABLATION, 0);
@@ -1166,10 +1168,10 @@ static int conv1x1_f32_impl(const float *in, int64_t in_batch_stride, int B, int
         if (tune == 3) halves = 0;  // (3 / 4: whole tiles / half-tile units everywhere, A/B timing and tests)
         if (tune == 4) halves = total >= G ? 1 : 0;
         if (Cin % 64 == 0 && tune != 2)  // (2: 32-channel stages everywhere, A/B timing)
-            hipLaunchKernelGGL(conv1x1_rw_kernel<64>, dim3(blocks), dim3(RW_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin,
+            hipLaunchKernelGGL(conv1x1_rw_kernel<64>, dim3(blocks), dim3(RW_NT), rw_pad, (hipStream_t)stream, in, (long)in_batch_stride, Cin,
                                (long)HW, w2t, b2, relu_out, out, tpp, (int)total, G, halves, rw_abl);
         else
-            hipLaunchKernelGGL(conv1x1_rw_kernel<32>, dim3(blocks), dim3(RW_NT), 0, (hipStream_t)stream, in, (long)in_batch_stride, Cin,
+            hipLaunchKernelGGL(conv1x1_rw_kernel<32>, dim3(blocks), dim3(RW_NT), rw_pad, (hipStream_t)stream, in, (long)in_batch_stride, Cin,
                                (long)HW, w2t, b2, relu_out, out, tpp, (int)total, G, halves, rw_abl);
         return manet_check_launch("manet_conv1x1_f32 (resident weights)");
     }

@@ -436,6 +436,8 @@ DEFAULT_CACHED_FRAMES = 8   # ... and what it keeps unless the driver prepared a
                             # extract_feature(packed=True)): test.py:259's cur -> prev hand-over, the annotated frames of a few
                             # rounds (136 MB at 480p; r3 kept up to 216 frames of every tensor that ever came by: ADVICE r3)
 MAX_CACHED_BANKS = 2        # prepared memory banks kept per model (one per sequence name)
+DEFAULT_LOCAL_VOLUME_CACHE_MB = 8192  # stored local-match volumes (prepare_local_volumes): 25.8 MB per 480p frame pair at d = 12,
+                                      # two directions x (F - 1) pairs per clip (5.1 GB for 100 frames); LRU beyond the cap
 _EMB_DTYPES = {"f32": torch.float32, "fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
                "bfloat16": torch.bfloat16, torch.float32: torch.float32, torch.bfloat16: torch.bfloat16}
 
@@ -494,6 +496,10 @@ class IntVOS(nn.Module):
                                            #              {(frame, round): weight}]: _mirror_of
         self._bank_cache = OrderedDict()   # seq_name -> (identity key, ops.PreparedBank, keyed tensors): _prepared_bank
         self._frame_cache = OrderedDict()  # identity key of a [C,h,w] embedding -> ops.PreparedFrame: _prepared_frame
+        self._vol_cache = OrderedDict()    # (key of the previous frame, key of the current frame) -> [volume, keep-alive tensors]
+        self._vol_cache_bytes = 0
+        self.local_volume_cache_bytes = int(getattr(cfg, "MODEL_LOCAL_VOLUME_CACHE_MB", DEFAULT_LOCAL_VOLUME_CACHE_MB)) << 20
+        self.local_volume_lazy = bool(getattr(cfg, "MODEL_LOCAL_VOLUME_LAZY", False))
         self.dynamic_seghead = DynamicSegHead()  # propagation head
         if cfg.MODEL_USEIntSeg:
             self.inter_seghead = IntSegHead(in_dim=cfg.MODEL_SEMANTIC_EMBEDDING_DIM + 3)
@@ -630,6 +636,90 @@ class IntVOS(nn.Module):
             self._frame_cache.popitem(last=False)
         return embeddings
 
+    # ---- stored local-match volumes (r6): the label-independent half of IntVOS.py:345-434, once per frame pair -----------
+    def prepare_local_volumes(self, embeddings, pairs="both", batch=32):
+        """Optional, for drivers that hold a clip's embeddings (test.py:143-154 `embedding_memory`) and walk the clip more than
+        once (every interaction round does: test.py:237-259, :276-295).  The window distances of the local match
+        (local_pairwise_distances2, IntVOS.py:266-296) depend on the two embeddings only -- not on labels, objects or the round:
+        they are computed HERE, `batch` frame pairs per launch, and kept; `prop_seghead` then runs only the label-dependent tail
+        (IntVOS.py:398-432) for a pair it finds (ops.local_match_volume: 18 us instead of 49 at 480p, d = 12; the same bits).
+        `embeddings`: [F, C, h, w] (or anything indexable by frame giving [C, h, w] views whose identity `prop_seghead` will see
+        again); `pairs`: "both" = (t-1 -> t) and (t+1 -> t) for every t -- the forward and the backward propagation, "forward",
+        "backward", or a list of (previous frame index, current frame index).  Kept until `invalidate_caches()`, LRU beyond
+        `local_volume_cache_bytes`.  Returns the number of pairs now cached from this call."""
+        d = self._local_radius()
+        F_ = int(embeddings.shape[0])
+        if d < 0 or F_ == 0 or not self.cache_frames or self.training or torch.cuda.is_current_stream_capturing():
+            return 0
+        if isinstance(pairs, str):
+            fwd = [(t - 1, t) for t in range(1, F_)]
+            bwd = [(t + 1, t) for t in range(F_ - 2, -1, -1)]
+            pairs = {"both": fwd + bwd, "forward": fwd, "backward": bwd}[pairs]
+        todo, hits, seen = [], 0, set()
+        for (ip, ic) in pairs:
+            ep, ec = embeddings[int(ip)], embeddings[int(ic)]
+            if not ec.is_cuda or (torch.is_grad_enabled() and (ep.requires_grad or ec.requires_grad)):
+                return 0
+            kp, kc = self._frame_key(ep, d), self._frame_key(ec, d)
+            if kp is None or kc is None:  # inference tensors: nothing to key on
+                return 0
+            if (kp, kc) in self._vol_cache:
+                self._vol_cache.move_to_end((kp, kc))
+                hits += 1
+            elif (kp, kc) not in seen:
+                seen.add((kp, kc))
+                todo.append((kp, kc, ep, ec))
+        if not todo:
+            return hits
+        h, w = todo[0][3].shape[-2:]
+        per = ops.local_volume_bytes(int(h), int(w), d)
+        todo = todo[:max(0, self.local_volume_cache_bytes // per)]  # what does not fit the cap stays on the fused kernel
+        for i0 in range(0, len(todo), batch):
+            part = todo[i0:i0 + batch]
+            prevs = [self._prepared_frame(ep)[0] for (_, _, ep, _) in part]
+            curs = [self._prepared_frame(ec)[0] for (_, _, _, ec) in part]
+            vols = ops.local_volumes(prevs, curs)
+            for j, (kp, kc, ep, ec) in enumerate(part):
+                self._vol_store((kp, kc), vols[j], ep, ec)
+        return hits + len(todo)
+
+    def invalidate_local_volumes(self):
+        self._vol_cache.clear()
+        self._vol_cache_bytes = 0
+
+    def local_volume_bytes_cached(self):
+        return self._vol_cache_bytes
+
+    def _vol_store(self, key, vol, ep, ec):
+        # (the keys hold storage pointers: the embeddings stay alive with the entry)
+        self._vol_cache[key] = [vol, ep, ec]
+        self._vol_cache_bytes += vol.numel() * 4
+        while self._vol_cache_bytes > self.local_volume_cache_bytes and len(self._vol_cache) > 1:
+            _, old = self._vol_cache.popitem(last=False)
+            self._vol_cache_bytes -= old[0].numel() * 4
+
+    def _local_volume(self, prev_chw, cur_chw, fcur=None):
+        """the stored volume of (previous frame, current frame), or None (then the fused kernel runs).  With
+        `local_volume_lazy` a miss computes and keeps the pair's volume (one un-batched launch: 39 us at 480p, d = 12 -- slower
+        than the fused kernel the first time, faster from the pair's second use on)."""
+        if (not self._vol_cache and not self.local_volume_lazy) or torch.cuda.is_current_stream_capturing():
+            return None
+        d = self._local_radius()
+        kp, kc = self._frame_key(prev_chw, d), self._frame_key(cur_chw, d)
+        if kp is None or kc is None:
+            return None
+        hit = self._vol_cache.get((kp, kc))
+        if hit is not None:
+            self._vol_cache.move_to_end((kp, kc))
+            return hit[0]
+        if not self.local_volume_lazy or not self.cache_frames:
+            return None
+        fprev = self._prepared_frame(prev_chw)[0]
+        fcur = fcur if fcur is not None else self._prepared_frame(cur_chw)[0]
+        vol = ops.local_volumes([fprev], [fcur])[0]
+        self._vol_store((kp, kc), vol, prev_chw, cur_chw)
+        return vol
+
     def invalidate_caches(self):
         """Drop the prepared banks / frames and the heads' folded BatchNorm constants.  Called by train(),
         load_state_dict() and _apply() (device / dtype moves); call it yourself after writing to a parameter or an
@@ -637,6 +727,7 @@ class IntVOS(nn.Module):
         the identity keys can see."""
         self._bank_cache.clear()
         self._frame_cache.clear()
+        self.invalidate_local_volumes()
         self._dist_mirror.clear()
         self._frame_cache_cap = DEFAULT_CACHED_FRAMES
         for m in self.modules():
@@ -916,11 +1007,18 @@ class IntVOS(nn.Module):
             # ---- local map
             seq_previous_frame_label = scale_previous_frame_label[n].permute(1, 2, 0)
             if fused_local:
-                # the previous frame was the current frame of the last step (test.py:259): its plane is cached
-                fprev, _ = self._prepared_frame(previous_frame_embedding[n])
-                prev_frame_nn_features_n = ops.local_match_frames(
-                    fprev, fcur, seq_previous_frame_label, n_ids, out=lpre,
-                    out_is_preset=preset_done).view(1, h, w, n_ids, 1)
+                vol = self._local_volume(previous_frame_embedding[n], current_frame_embedding[n], fcur)
+                if vol is not None:
+                    # the pair's window distances are stored (prepare_local_volumes): only the label-dependent tail runs
+                    prev_frame_nn_features_n = ops.local_match_volume(
+                        vol, fcur, seq_previous_frame_label, n_ids, out=lpre,
+                        out_is_preset=preset_done).view(1, h, w, n_ids, 1)
+                else:
+                    # the previous frame was the current frame of the last step (test.py:259): its plane is cached
+                    fprev, _ = self._prepared_frame(previous_frame_embedding[n])
+                    prev_frame_nn_features_n = ops.local_match_frames(
+                        fprev, fcur, seq_previous_frame_label, n_ids, out=lpre,
+                        out_is_preset=preset_done).view(1, h, w, n_ids, 1)
             elif use_local_map:
                 prev_frame_nn_features_n = local_previous_frame_nearest_neighbor_features_per_object(
                     prev_frame_embedding=seq_prev_frame_embedding, query_embedding=seq_current_frame_embedding,
@@ -1030,7 +1128,11 @@ class IntVOS(nn.Module):
             if (ref_frame_embedding.is_cuda and self._local_radius() >= 0
                     and not (torch.is_grad_enabled() and ref_frame_embedding.requires_grad)):
                 fref, _ = self._prepared_frame(ref_frame_embedding[n])
-                nn_features_n = ops.local_match_frames(fref, fref, seq_ref_scribble_label, n_ids).view(1, h, w, n_ids, 1)
+                vol = self._local_volume(ref_frame_embedding[n], ref_frame_embedding[n], fref)
+                if vol is not None:
+                    nn_features_n = ops.local_match_volume(vol, fref, seq_ref_scribble_label, n_ids).view(1, h, w, n_ids, 1)
+                else:
+                    nn_features_n = ops.local_match_frames(fref, fref, seq_ref_scribble_label, n_ids).view(1, h, w, n_ids, 1)
             else:
                 nn_features_n = local_previous_frame_nearest_neighbor_features_per_object(
                     prev_frame_embedding=seq_ref_frame_embedding, query_embedding=seq_ref_frame_embedding,

@@ -506,6 +506,74 @@ def local_match_frames(prev_frame, cur_frame, prev_frame_labels, n_ids, out=None
     return out.view(b.h, b.w, n_ids)
 
 
+def local_volume_bytes(h, w, max_distance):
+    """bytes of one frame pair's stored window-distance volume (manet_local_volume_bytes)"""
+    import ctypes
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(_lib.load().manet_local_volume_bytes(h, w, max_distance, ctypes.byref(nbytes)), "manet_local_volume_bytes")
+    return nbytes.value
+
+
+def local_volumes(prev_frames, cur_frames, out=None):
+    """The label-independent half of the local match (IntVOS.py:266-296: pooled frames -> (2d+1)^2 window distances ->
+    (sigmoid - 0.5) * 2) for a BATCH of frame pairs (prev_frames[i], cur_frames[i]) -- lists of PreparedFrames of one geometry --
+    in ceil(n / 32) launches.  Returns a float32 tensor [n, floats per volume]; row i feeds local_match_volume.  `out`: an
+    optional contiguous float32 tensor of that shape to write into."""
+    import ctypes
+    lib = _lib.load()
+    n = len(cur_frames)
+    if len(prev_frames) != n:
+        raise ValueError("prev_frames and cur_frames must pair up")
+    if n == 0:
+        return torch.empty((0, 0), dtype=torch.float32)
+    b = cur_frames[0]
+    for a in list(prev_frames) + list(cur_frames):
+        if (a.h, a.w, a.C, _image_kind(a.compute), a.max_distance, a.device) != (b.h, b.w, b.C, _image_kind(b.compute),
+                                                                               b.max_distance, b.device):
+            raise ValueError("the frames were prepared for different shapes / arithmetic / window radius / devices")
+    if b.max_distance < 0:
+        raise ValueError("the frames were prepared without a pooled plane (max_distance < 0)")
+    per = local_volume_bytes(b.h, b.w, b.max_distance) // 4
+    if out is None:
+        out = torch.empty((n, per), dtype=torch.float32, device=b.device)
+    elif out.dtype != torch.float32 or not out.is_contiguous() or tuple(out.shape) != (n, per) or out.device != b.device:
+        raise ValueError("out must be a contiguous float32 [%d, %d] tensor on the frames' device" % (n, per))
+    arr = ctypes.c_void_p * n
+    pv = arr(*[f.ws.data_ptr() for f in prev_frames])
+    cv = arr(*[f.ws.data_ptr() for f in cur_frames])
+    vv = arr(*[out[i].data_ptr() for i in range(n)])
+    with _on(b.device):
+        rc = lib.manet_local_volume_frames(pv, cv, vv, n, b.h, b.w, b.C, b.compute, b.max_distance, _stream_ptr(b.device))
+    _lib.check(rc, "manet_local_volume_frames")
+    return out
+
+
+def local_match_volume(volume, cur_frame, prev_frame_labels, n_ids, out=None, out_is_preset=False):
+    """The label-dependent tail of the local match (IntVOS.py:398-432) on a stored volume (one row of local_volumes) -> [h, w,
+    n_ids]; bit-identical to local_match_frames(prev_frame, cur_frame, ...) on the pair the volume was made from."""
+    lib = _lib.load()
+    b = cur_frame
+    if b.max_distance < 0:
+        raise ValueError("the frame was prepared without a pooled plane (max_distance < 0)")
+    if (volume.dtype != torch.float32 or not volume.is_contiguous() or volume.device != b.device
+            or volume.numel() * 4 != local_volume_bytes(b.h, b.w, b.max_distance)):
+        raise ValueError("volume must be one contiguous float32 row of local_volumes() for this frame geometry")
+    lab = _labels(prev_frame_labels, "prev_frame_labels")
+    if lab.numel() != b.h * b.w:
+        raise ValueError("prev_frame_labels must have height*width entries")
+    dev = b.device
+    if out is None:
+        out = torch.empty((b.h, b.w, n_ids), dtype=torch.float32, device=dev)
+        out_is_preset = False
+    elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != b.h * b.w * n_ids:
+        raise ValueError("out must be a contiguous float32 tensor of h*w*n_ids elements")
+    with _on(dev):
+        rc = lib.manet_local_match_volume(volume.data_ptr(), b.ws.data_ptr(), lab.data_ptr(), b.h, b.w, b.C, b.compute, n_ids,
+                                          b.max_distance, out.data_ptr(), int(bool(out_is_preset)), _stream_ptr(dev))
+    _lib.check(rc, "manet_local_match_volume")
+    return out.view(b.h, b.w, n_ids)
+
+
 def normalize_merge_(x, mem=None, normalize=True):
     """In place: x = (sigmoid(x)-0.5)*2 if normalize; if mem: x = mem = min(x, mem)
     (IntVOS.py:611-612, :620-622, :718-723)."""

@@ -171,6 +171,7 @@ class StageTimer:
     STAGES = {"dwconv7x7_bn_relu": "head: dwconv7x7_bn_relu_kernel", "conv1x1_split": "head: conv1x1_x3_kernel",
               "conv1x1_mfma": "head: conv1x1_mfma_kernel", "relu_conv1x1_c1": "head: relu_conv1x1_c1_kernel",
               "local_match_frames": "local match: local_fused_kernel", "prepare_frames": "frame_prepare_kernel",
+              "local_match_volume": "local match on a stored volume: local_fused_kernel<D, 2>",
               "head_inputs": "head_inputs_kernel", "head_layer1_object": "head: head_layer1_object_kernel", "upsample_argmax": "mask step: upsample_argmax_kernel",
               "label_resize_nearest": "label_resize_kernel", "frame_begin": "frame_begin_kernel (label resize + local-map pre-set + weight)"}
 
@@ -486,6 +487,20 @@ def run_single(args, dev, pointwise=None, want_graph=False, want_stages=False, b
         emb = synthetic_clip(model, dev, args.frames, args.height, args.width, args.objects, packed=not args.no_packed)
         if args.prepare_clip and not isinstance(emb, BatchedClip):
             emb = model.prepare_clip(emb)
+        # the label-independent half of every frame pair's local match, once per clip (model.prepare_local_volumes): the
+        # window distances depend on the embeddings alone and every interaction round walks the clip again.  Timed on its own --
+        # it is matching work, not encoder work: `eager_frames_per_s` is a round with the volumes (and the head's memoised
+        # shared half) in place, i.e. any round but a sequence's first; `first_round_frames_per_s` charges this call to one round
+        vol_ms, vol_pairs = 0.0, 0
+        if not getattr(args, "no_local_volumes", False):
+            if args.frames > 2:  # (untimed: workspace growth and code-object load of the batched launch)
+                model.prepare_local_volumes(emb, pairs=[(0, 1)])
+                model.invalidate_local_volumes()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            vol_pairs = model.prepare_local_volumes(emb)
+            torch.cuda.synchronize()
+            vol_ms = (time.perf_counter() - t0) * 1e3
         clip = Clip(cfg, model, emb, args.height, args.width, args.objects, fused_mask_step=args.fused_mask_step,
                     bank=bank if bank is not None else args.bank,
                     bank_frames=bank_frames if bank_frames is not None else args.bank_frames)
@@ -493,6 +508,8 @@ def run_single(args, dev, pointwise=None, want_graph=False, want_stages=False, b
         res = {"frames": args.frames, "grid": [clip.eh, clip.ew], "objects": args.objects, "pointwise": model.pointwise,
                "compute": model.compute, "bank": clip.bank, "bank_frames": clip.bank_frames, "bank_rows": clip.bank_rows,
                "eager_ms_per_round": dt * 1e3, "eager_frames_per_s": (args.frames - 1) / dt,
+               "local_volumes": {"pairs": vol_pairs, "ms": vol_ms, "MB": model.local_volume_bytes_cached() / 1e6},
+               "first_round_frames_per_s": (args.frames - 1) / (dt + vol_ms * 1e-3),
                "mask_digest": mask_digest(final)}
         if want_stages:
             with StageTimer() as st:
@@ -512,8 +529,10 @@ def run_single(args, dev, pointwise=None, want_graph=False, want_stages=False, b
             clip.session(min(args.session, 2), timed=False)  # warm-up: both kinds of round
             smask, times = clip.session(args.session)
             again, _ = clip.session(args.session, timed=False)
+            # (the volumes are part of the session's matching work: their one-off cost is charged to it)
             res.update({"session_rounds": args.session, "session_ms_per_round": [t * 1e3 for t in times],
-                        "session_frames_per_s": args.session * (args.frames - 1) / sum(times),
+                        "session_frames_per_s": args.session * (args.frames - 1) / (sum(times) + vol_ms * 1e-3),
+                        "session_frames_per_s_rounds_alone": args.session * (args.frames - 1) / sum(times),
                         "session_mask_digest": mask_digest(smask), "session_repeatable": bool(torch.equal(smask, again))})
         if want_graph:
             ground = clip.graph_round_fn()
@@ -654,6 +673,9 @@ def parse_args(argv=None):
     ap.add_argument("--session", type=int, default=0,
                     help="also run a whole interactive session of this many rounds (test.py:100-310: round 1 on the rough_ROI "
                          "bank, later rounds on new strokes alone with the memories carried over); the reference runs 8")
+    ap.add_argument("--no-local-volumes", action="store_true",
+                    help="do not store the frame pairs' window-distance volumes up front (model.prepare_local_volumes): every "
+                         "propagated frame then runs the fused local kernel, as r1-r5")
     ap.add_argument("--two-streams", action="store_true",
                     help="also time the round with the forward and the backward half of the chain on two HIP streams")
     ap.add_argument("--stages", action="store_true", help="per-stage microseconds of a propagated frame (HIP events)")

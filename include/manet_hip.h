@@ -275,6 +275,24 @@ int manet_local_match_frames(const void *prev_frame_ws, const void *cur_frame_ws
                              int h, int w, int C, int compute, int n_ids, int max_distance, float *out,
                              int out_is_preset, manet_stream_t stream);
 
+/* The label-INDEPENDENT half of the local match, kept per frame pair (r6).  The window distances of
+ * local_pairwise_distances2 (IntVOS.py:266-296: pooled frames -> (2d+1)^2 squared distances -> (sigmoid - 0.5) * 2) depend on
+ * the two embeddings only, and a clip's embeddings are extracted once per sequence (test.py:137-154) while every interaction round
+ * walks the clip again (test.py:237-259, :276-295): the volume of a frame pair is computed once -- many pairs per launch
+ * (manet_local_volume_frames: 32 pairs per launch, several waves of workgroups) -- and the per-frame sequential chain then runs
+ * only the label-dependent tail (IntVOS.py:398-432: stride-2 label unfold, where(mask, d, 1), min over the window:
+ * manet_local_match_volume).  A volume is stored as the fused kernel's per-workgroup LDS images (tile aprons and 16-byte cell padding
+ * included: manet_local_volume_bytes, 25.8 MB per 480p frame pair at d = 12).  Same arithmetic as manet_local_match_frames: the same bits.
+ *   prev_frame_ws / cur_frame_ws / volumes   HOST arrays of n_pairs DEVICE pointers (prepared frames of one geometry; volumes 16-byte
+ *                                            aligned, manet_local_volume_bytes each)
+ *   manet_local_match_volume                 `cur_frame_ws` = the current frame's prepared workspace (its tile table); `out` as in
+ *                                            manet_local_match_frames (out_is_preset for max_distance >= 11). */
+int manet_local_volume_bytes(int h, int w, int max_distance, size_t *bytes);
+int manet_local_volume_frames(const void *const *prev_frame_ws, const void *const *cur_frame_ws, float *const *volumes,
+                              int n_pairs, int h, int w, int C, int compute, int max_distance, manet_stream_t stream);
+int manet_local_match_volume(const float *volume, const void *cur_frame_ws, const int32_t *prev_labels, int h, int w, int C,
+                             int compute, int n_ids, int max_distance, float *out, int out_is_preset, manet_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* correlation_package forward (correlation_cuda.cc:10-87).
  *   in1, in2 [B][C][H][W] fp32 contiguous; out [B][(2r+1)^2][outH][outW] fp32 contiguous with

@@ -152,3 +152,71 @@ def test_shared_half_of_head_layer1_is_memoised_per_frame_and_follows_parameter_
         clip2.one_round(keep_logits=want)
         for k in want:
             assert torch.equal(lg3[k], want[k])
+
+
+@pytest.mark.gpu
+def test_stored_local_volumes_give_the_fused_kernels_masks_and_follow_the_embeddings():
+    """r6: model.prepare_local_volumes keeps every frame pair's window distances (the label-independent half of the local match);
+    prop_seghead then launches only the label-dependent tail.  Same logits bit for bit, in a one-round loop and over a session of
+    several rounds (new labels per round on the same volumes); a frame whose embedding is rewritten in place falls back to the
+    fused kernel (its identity key changed) instead of reading a stale volume; the byte cap bounds the cache."""
+    from examples import propagate_clip as pc
+    from cvpr2020_manet_amd import ops
+    dev = torch.device("cuda", 0)
+    args = pc.parse_args(["--frames", "7", "--fused-mask-step", "--height", "240", "--width", "428"])
+    cfg, model = pc.build_model(dev, None, None, None)
+    with torch.no_grad():
+        emb = pc.synthetic_clip(model, dev, args.frames, args.height, args.width, args.objects, packed=True)
+        clip = pc.Clip(cfg, model, emb, args.height, args.width, args.objects)
+        want, got = {}, {}
+        m_want = clip.one_round(keep_logits=want)
+        s_want, _ = clip.session(3, timed=False)
+        assert model.local_volume_bytes_cached() == 0
+        n = model.prepare_local_volumes(emb)
+        assert n == 2 * (args.frames - 1)
+        per = ops.local_volume_bytes(clip.eh, clip.ew, cfg.MODEL_MAX_LOCAL_DISTANCE)
+        assert model.local_volume_bytes_cached() == n * per
+        assert model.prepare_local_volumes(emb) == n and model.local_volume_bytes_cached() == n * per  # all hits, nothing added
+        calls = {"fused": 0, "vol": 0}
+        real_f, real_v = ops.local_match_frames, ops.local_match_volume
+
+        def count_f(*a, **k):
+            calls["fused"] += 1
+            return real_f(*a, **k)
+
+        def count_v(*a, **k):
+            calls["vol"] += 1
+            return real_v(*a, **k)
+        ops.local_match_frames, ops.local_match_volume = count_f, count_v
+        try:
+            m_got = clip.one_round(keep_logits=got)
+            assert calls["vol"] == args.frames - 1 and calls["fused"] == 1  # (the annotated frame against itself: int_seghead)
+            assert torch.equal(m_got, m_want)
+            for k in want:
+                assert torch.equal(got[k], want[k])
+            s_got, _ = clip.session(3, timed=False)
+            assert torch.equal(s_got, s_want)
+            # an embedding rewritten in place: the clip tensor's version counter moves (views share it), every pair of the clip
+            # misses and runs the fused kernel on the new contents -- never a stale volume
+            calls["fused"] = calls["vol"] = 0
+            emb[2].mul_(1.0)
+            clip.one_round()
+            assert calls["fused"] == args.frames and calls["vol"] == 0
+        finally:
+            ops.local_match_frames, ops.local_match_volume = real_f, real_v
+        # the byte cap: room for three volumes
+        model.invalidate_local_volumes()
+        model.local_volume_cache_bytes = 3 * per + 100
+        assert model.prepare_local_volumes(emb) == 3 and model.local_volume_bytes_cached() == 3 * per
+        assert torch.equal(clip.one_round(), clip.one_round())
+        # lazy mode: a miss computes and keeps the pair's volume
+        model.invalidate_local_volumes()
+        model.local_volume_cache_bytes = 1 << 40
+        model.local_volume_lazy = True
+        emb2 = pc.synthetic_clip(model, dev, args.frames, args.height, args.width, args.objects, packed=True)
+        clip2 = pc.Clip(cfg, model, emb2, args.height, args.width, args.objects)
+        lazy1 = clip2.one_round()
+        assert model.local_volume_bytes_cached() == (args.frames - 1 + 1) * per  # every propagated pair + the annotated frame's own
+        assert torch.equal(clip2.one_round(), lazy1) and torch.equal(lazy1, m_want)
+        model.invalidate_caches()
+        assert model.local_volume_bytes_cached() == 0

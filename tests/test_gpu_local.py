@@ -232,3 +232,64 @@ def test_full_size_local_cfg5_grid(ops, oracle):
     finally:
         _lib.check(lib.manet_tune_set(4, 0), "manet_tune_set")
     assert torch.equal(got, unfused)
+
+
+@pytest.mark.parametrize("d", range(13))
+def test_stored_volume_path_every_window_size(ops, oracle, d):
+    """r6: phase 1 (window distances, label-independent) batched into stored volumes, phase 2 (label gather + masked min) on a
+    stored volume -- every instantiation d = 0..12, ragged grids, more ids than one per-pixel pass holds, fp32 and 2-byte
+    embeddings: bit for bit the fused kernel's result (which the test above ties to the oracle), and against the oracle itself."""
+    rng = np.random.default_rng(6200 + d)
+    for (C, h, w, n_ids, dtype) in ((58, 53, 71, 11, torch.float32), (7, 9, 100, 2, torch.float32),
+                                    (33, 30, 54, 3, torch.bfloat16)):
+        embs = torch.from_numpy((np.maximum(rng.standard_normal((4, C, h, w)), 0) * 0.2).astype(np.float32)).cuda().to(dtype)
+        labs = torch.from_numpy(rng.integers(-1, n_ids + 1, size=(4, h, w)).astype(np.int32)).cuda()
+        frames = ops.prepare_frames(embs, compute="f32", max_distance=d)
+        # forward pairs (t-1 -> t), backward pairs (t+1 -> t), a frame against itself (int_seghead, IntVOS.py:709-711)
+        pairs = [(0, 1), (1, 2), (2, 3), (3, 2), (2, 1), (1, 0), (2, 2)]
+        vols = ops.local_volumes([frames[a] for a, _ in pairs], [frames[b] for _, b in pairs])
+        assert vols.shape[0] == len(pairs) and vols.shape[1] * 4 == ops.local_volume_bytes(h, w, d)
+        for i, (a, b) in enumerate(pairs):
+            want = ops.local_match_frames(frames[a], frames[b], labs[a], n_ids)
+            got = ops.local_match_volume(vols[i], frames[b], labs[a], n_ids)
+            assert torch.equal(got, want), (d, a, b)
+            # a pre-set output buffer, as prop_seghead hands it over
+            pre = torch.ones((h, w, n_ids), dtype=torch.float32, device="cuda")
+            got2 = ops.local_match_volume(vols[i], frames[b], labs[a], n_ids, out=pre, out_is_preset=True)
+            assert torch.equal(got2, want)
+        a, b = pairs[0]
+        e = embs.float().cpu().numpy()
+        ref = oracle.local_match(np.transpose(e[a], (1, 2, 0)), np.transpose(e[b], (1, 2, 0)),
+                                 labs[a].cpu().numpy().reshape(h, w, 1), n_ids, d, downsample=True).reshape(h, w, n_ids)
+        np.testing.assert_allclose(ops.local_match_volume(vols[0], frames[b], labs[a], n_ids).cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+
+
+def test_stored_volumes_more_pairs_than_one_launch(ops):
+    """70 frame pairs = three launches of the batched phase-1 kernel (32 pairs each); every volume equals the one made alone;
+    the labels change between uses of a volume (interaction rounds), the volume does not."""
+    torch.manual_seed(66)
+    C, h, w, d, n_ids = 24, 22, 38, 12, 3
+    embs = torch.relu(torch.randn(36, C, h, w, device="cuda")) * 0.2
+    frames = ops.prepare_frames(embs, compute="f32", max_distance=d)
+    pairs = [(t - 1, t) for t in range(1, 36)] + [(t + 1, t) for t in range(35)]
+    vols = ops.local_volumes([frames[a] for a, _ in pairs], [frames[b] for _, b in pairs])
+    for i in (0, 31, 32, 63, 64, 69):
+        a, b = pairs[i]
+        alone = ops.local_volumes([frames[a]], [frames[b]])
+        for rnd in range(2):
+            lab = torch.randint(0, n_ids, (h, w), dtype=torch.int32, device="cuda")
+            want = ops.local_match_frames(frames[a], frames[b], lab, n_ids)
+            assert torch.equal(ops.local_match_volume(vols[i], frames[b], lab, n_ids), want)
+            assert torch.equal(ops.local_match_volume(alone[0], frames[b], lab, n_ids), want)
+
+
+def test_stored_volume_full_size_480p(ops):
+    """BASELINE cfg2's grid at the reference's default window (120x214, C=100, d=12, 3 ids): bit-equal to the fused kernel"""
+    torch.manual_seed(20200614 + 2)
+    C, h, w, d, n_ids = 100, 120, 214, 12, 3
+    embs = torch.relu(torch.randn(2, C, h, w, device="cuda")) * 0.1
+    lab = torch.randint(0, n_ids, (h, w), dtype=torch.int32, device="cuda")
+    frames = ops.prepare_frames(embs, compute="f32", max_distance=d)
+    vols = ops.local_volumes([frames[0]], [frames[1]])
+    assert vols.numel() * 4 == ops.local_volume_bytes(h, w, d) == 240 * 107520
+    assert torch.equal(ops.local_match_volume(vols[0], frames[1], lab, n_ids), ops.local_match_frames(frames[0], frames[1], lab, n_ids))
