@@ -532,6 +532,13 @@ def bf16_parity(wl, bank_rows, bank_lab, budget_s=4.0):
                         "argmin_id_flip_fraction": flips}
         out["unrounded_fp32_inputs"] = un
         out["meets_1e-3"] = {m: bool(v["err_vs_fp32_oracle_normalised_max"] <= 1e-3) for m, v in un.items()}
+        # the same frames with the embeddings three times as large (scale 0.3 instead of SURVEY 8d's 0.1), plain
+        # bf16 against the fp32 KERNEL (bit-exact against the oracle) on the whole frame: where plain bf16 leaves the 1e-3 bar
+        b3, c3 = bank_f32 * 3.0, (cur_f32 * 3.0).permute(1, 2, 0)
+        g32 = ops.global_match(b3, c3, bank_lab, wl.n_ids, normalize=True, compute="f32")
+        gb = ops.global_match(b3, c3, bank_lab, wl.n_ids, normalize=True, compute="bf16")
+        out["plain_bf16_err_scale_0.3"] = float((g32 - gb).abs().max().item())
+        del b3, c3, g32, gb
     return out
 
 
@@ -561,6 +568,16 @@ def also_leg(cfg, compute, device, lib, args):
     del wl, r
     torch.cuda.empty_cache()
     leg["exact_mode"] = exact_leg(cfg, device, lib, args)
+    # the leg LEADS with the tolerance-safe figure.  north_star's bar is 1e-3; plain bf16 meets it at SURVEY 8d's
+    # embedding scale 0.1 and not at 0.3 (`err_0.3`): `value` is the bf16r rate (the fp32 result bit for bit), the plain-bf16 rate and
+    # its two errors stand beside it.  (`ms_per_step`, `kernel_ms`, `roofline`, `local_stage` describe the plain-bf16 run: the bf16
+    # MFMA kernel is what those configs' rooflines are about.)
+    un = ((leg.get("parity") or {}).get("unrounded_fp32_inputs") or {}).get(compute) or {}
+    leg["value_plain_bf16"] = leg["value"]
+    leg["value"] = leg["exact_mode"]["value"]
+    leg["value_mode"] = "bf16r on f32-stored embeddings: bf16 filter + exact fp32 re-rank = the fp32 kernel's result bit for bit"
+    leg["err_0.1"] = un.get("err_vs_fp32_oracle_normalised_max")
+    leg["err_0.3"] = (leg.get("parity") or {}).get("plain_bf16_err_scale_0.3")
     return leg
 
 
@@ -681,12 +698,22 @@ def e2e_block(device, args):
     f32 = out["modes"]["f32"]
     out["bank"], out["bank_rows"] = f32["bank"], f32["bank_rows"]
     out["value"] = f32["eager_frames_per_s"]
+    # r6: `value` is a round with the clip's window-distance volumes stored (model.prepare_local_volumes, once per clip: every round
+    # but a sequence's first finds them, like the head's memoised layer-1 term); `value_first_round` charges that one-off call to
+    # one round; `value_fused_local` is the same round with the fused local kernel of r1-r5 (no volumes)
+    out["value_first_round"] = f32["first_round_frames_per_s"]
+    out["local_volumes"] = f32["local_volumes"]
     out["value_graph"] = f32["graph_frames_per_s"]
     # the round's two independent halves (forwards / backwards from the annotated frame) on two HIP streams of the one GPU
     out["value_two_streams"] = f32["two_streams_frames_per_s"]
     out["two_streams_masks_equal_eager"] = bool(all(out["modes"][m]["two_streams_masks_equal_eager"] for m in out["modes"]))
     out["masks_equal_eager_graph_two_streams"] = bool(all(out["modes"][m]["two_streams_masks_equal_eager"]
                                                           and out["modes"][m]["graph_masks_equal_eager"] for m in out["modes"]))
+    res, clip, final = pc.run_single(pc.parse_args(base + ["--bank", "roi", "--no-local-volumes"]), device, pointwise="f32")
+    out["value_fused_local"] = res["eager_frames_per_s"]
+    out["fused_local_masks_equal"] = bool(res["mask_digest"] == f32["mask_digest"])
+    del clip
+    torch.cuda.empty_cache()
     # the other banks, fp32 head, eager loop: the strokes alone (r1-r4's workload), the 5-frame memory, every pixel labelled
     for name, extra in (("scribble", ["--bank", "scribble"]), ("roi_T5", ["--bank", "roi", "--bank-frames", "5"]),
                         ("full_T5", ["--bank", "full", "--bank-frames", "5"])):
@@ -823,10 +850,14 @@ def compact_line(full):
         legs = []
         for a in full["also"]:
             un = ((a.get("parity") or {}).get("unrounded_fp32_inputs") or {}).get(a.get("dtype")) or {}
-            legs.append({"cfg": a.get("cfg"), "dtype": a.get("dtype"), "value": a.get("value"), "ms_per_step": a.get("ms_per_step"),
+            # (r5 lines: `value` was the plain-bf16 rate and `exact_value` the bf16r one; r6 leads with the tolerance-safe mode)
+            plain = a.get("value_plain_bf16", a.get("value"))
+            exact = (a.get("exact_mode") or {}).get("value")
+            legs.append({"cfg": a.get("cfg"), "dtype": a.get("dtype"), "value": exact if exact is not None else plain,
+                         "value_mode": "bf16r" if exact is not None else a.get("dtype"), "value_plain_bf16": plain,
+                         "err_0.1": a.get("err_0.1", un.get("err_vs_fp32_oracle_normalised_max")), "err_0.3": a.get("err_0.3"),
+                         "ms_per_step_plain_bf16": a.get("ms_per_step"),
                          "frac": (a.get("roofline") or {}).get("frac"), "kernel_ms": a.get("kernel_ms"),
-                         "err_max": un.get("err_vs_fp32_oracle_normalised_max"),
-                         "exact_value": (a.get("exact_mode") or {}).get("value"),
                          "local_window_ms": (a.get("local_stage") or {}).get("window_kernel_ms")})
         out["also"] = legs
     rb = full.get("robustness")
@@ -836,7 +867,7 @@ def compact_line(full):
                              "bf16_err_0.1": s.get("bf16_max_err_scale_0.1"), "bf16_err_0.3": s.get("bf16_max_err_scale_0.3")}
     e = full.get("e2e")
     if e:
-        ek = ("value", "value_graph", "value_two_streams", "value_scribble_bank", "value_bank_frames_5",
+        ek = ("value", "value_first_round", "value_fused_local", "value_graph", "value_two_streams", "value_scribble_bank", "value_bank_frames_5",
               "value_full_bank_frames_5", "value_session_8_rounds", "value_bf16r_match", "bf16r_match_masks_equal_f32", "bank", "bank_rows",
               "masks_equal_eager_graph_two_streams")
         ce = {k: e[k] for k in ek if k in e}

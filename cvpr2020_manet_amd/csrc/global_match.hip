@@ -97,6 +97,11 @@ constexpr int REFINE_DENSE_LANES = MANET_REFINE_DENSE_LANES;  // (64: off; smoot
 constexpr int REFINE_RZ = MANET_REFINE_RZ;  // workgroups of the re-rank launch per bucket: each takes every 4th entry (the longest bucket is the launch's time)
 constexpr int ONE_ROUND_OK = 1 << 29;   // block_map flag (fp32 pipe kernel): the device may swap the host's splits for ONE round of long ones
 constexpr int RESCUE_LISTED = 1 << 30;  // block_map flag of the rescue launch: deal the workgroups to the LISTED tiles
+// block_map word: bits 0-7 tuning, bits 8-20 small_S (<= 4096: 13 bits) -- or, in the rescue launch, bits 8-28 its split count --
+// bit 29 ONE_ROUND_OK, bit 30 RESCUE_LISTED.  (the rescue field was masked with 22 bits and reached bit 29.)
+constexpr int BLOCK_MAP_SMALL_S_MASK = 0x1fff, BLOCK_MAP_RESCUE_MASK = 0x1fffff;
+static_assert(((BLOCK_MAP_RESCUE_MASK << 8) & (ONE_ROUND_OK | RESCUE_LISTED)) == 0 && ((BLOCK_MAP_SMALL_S_MASK << 8) & (ONE_ROUND_OK | RESCUE_LISTED)) == 0 &&
+              4096 <= BLOCK_MAP_SMALL_S_MASK, "block_map fields overlap");
 
 // Packed operand image of one row block: `units` 16-byte units per row, stored [unit][row][16 B].
 //   f32    unit u = 2g+h holds k = 8g + 2j + h, j = 0..3 (4 floats)      -> v_mfma_f32_32x32x2_f32
@@ -446,7 +451,11 @@ __device__ __forceinline__ uint4 image_unit_bf16(const float *row, int u, int hi
             const int j = k0 + e - C;  // 0..2: bank norm / query ones, 3..5: bank ones / query norm
             if (j >= 0 && j < BF16_SPECIAL) {
                 const bool norm_slot = IS_QUERY ? (j >= 3) : (j < 3);
-                e8[e] = lo ? 0u : (norm_slot ? piece[j % 3] : 0x3f80u);
+                // (a select chain, not piece[j % 3]: a run-time index keeps the three words in a private-memory stack object --
+                // 36 bytes of scratch in frame_prepare_kernel<unsigned short, 32> through r5, tests/test_kernel_resources.py)
+                const int j3 = j % 3;
+                const unsigned pj = j3 == 0 ? piece[0] : (j3 == 1 ? piece[1] : piece[2]);
+                e8[e] = lo ? 0u : (norm_slot ? pj : 0x3f80u);
             }
         }
     }
@@ -580,7 +589,9 @@ struct FramePrep {
 #else
 #define MANET_FP_ABL(bit_) false
 #endif
-template <typename SRC, int XC>
+// VEC2 (r6): the two staging forms are separate instantiations -- as a run-time branch (r3-r5) both lived in every kernel and the
+// 2-byte instantiation ran out of scalar registers (22 SGPR spills and a 36-byte private segment; tests/test_kernel_resources.py)
+template <typename SRC, int XC, bool VEC2>
 __global__ __launch_bounds__(256) void frame_prepare_kernel(const FramePrep A)
 {
     constexpr int PIX = 2 * XC;
@@ -651,7 +662,7 @@ __global__ __launch_bounds__(256) void frame_prepare_kernel(const FramePrep A)
     const bool bf16_exact = (A.compute == MANET_COMPUTE_BF16) && (A.rcopy || sizeof(SRC) == 2 || (A.scale && A.emb_out_bf16));
     // The launch is LATENCY-bound, not bandwidth-bound (1.6 workgroups per CU, 27 MB per frame; ablations in DESIGN 3.3): every
     // load of the workgroup is issued before the first one is waited for -- one memory round trip per workgroup.
-    if (A.vec2) {  // two horizontally adjacent pixels per lane (8-byte / 4-byte loads): half the load instructions
+    if constexpr (VEC2) {  // two horizontally adjacent pixels per lane (8-byte / 4-byte loads): half the load instructions
         constexpr int NP2 = PIX / 2, NKQ = 256 / NP2;
         const int pp = tid % NP2, kq = tid / NP2;
         const int p = 2 * pp, y = y0 + p / XC, x = x0 + p % XC;  // (XC is even: both pixels in one row; w is even)
@@ -902,7 +913,7 @@ constexpr int FILTER_TAIL_CUTS = MANET_FILTER_TAIL_CUTS;  // (1: bm == 3's map)
 __device__ __forceinline__ bool split_of_block(int b, int nQT, int S, int T, int block_map, int &qt, int &s, int &t0,
                                                int &t1)
 {
-    const int bm = block_map & 0xff, small_S = (block_map >> 8) & 0x1fff;
+    const int bm = block_map & 0xff, small_S = (block_map >> 8) & BLOCK_MAP_SMALL_S_MASK;
     bool one_round = T < S && small_S > 0;
     if (!one_round && (block_map & ONE_ROUND_OK) && small_S > 0 && small_S < S) {
         // r5.  The host sizes S from the bank's UPPER-bound tile count (it cannot know how many rows are labelled without a
@@ -1281,7 +1292,7 @@ __global__ __launch_bounds__(256, 2) void global_match_f32_pipe_kernel(const cha
         // splits per tile: whole rounds of the chip's 512 workgroup slots (a workgroup's fixed cost -- its 106 KB query
         // operand, the pipeline fill, the closing atomics -- is worth ~6 tiles of matrix work: few long workgroups beat many
         // short ones; 4 tiles of 102 at cfg2 size: 390 us with 404 splits of 5 tiles, 3.2 rounds)
-        int Sd = (block_map >> 8) & 0x3fffff;  // (experiments: MANET_TUNE_RESCUE_SPLITS)
+        int Sd = (block_map >> 8) & BLOCK_MAP_RESCUE_MASK;  // (experiments: MANET_TUNE_RESCUE_SPLITS)
         if (Sd > 0) {
             const int most_grid = (int)gridDim.x / nr;
             Sd = Sd > most_grid ? most_grid : Sd;
@@ -2879,7 +2890,7 @@ void launch_rescue_f32_pipe(const char *qpack, const char *bpack, const int *met
     // matched: MANET_EPI_REFINE_EXACT) the fp32 kernel's own block map
     hipLaunchKernelGGL((global_match_f32_pipe_kernel<KS, true>), dim3((unsigned)(nQT * S)), dim3(256), lds, st, qpack, bpack, meta,
                        n_ids, nQT, S, N_pad, keys,
-                       listed ? (RESCUE_LISTED | ((manet_tune_get(MANET_TUNE_RESCUE_SPLITS, 0) & 0x3fffff) << 8)) : block_map_arg(nQT, 512, S),
+                       listed ? (RESCUE_LISTED | ((manet_tune_get(MANET_TUNE_RESCUE_SPLITS, 0) & BLOCK_MAP_RESCUE_MASK) << 8)) : block_map_arg(nQT, 512, S),
                        bcnt, bucket_cap);
 }
 
@@ -3232,12 +3243,16 @@ static int frame_prepare_impl(const void *emb, int emb_dtype, int64_t s_f, int64
     hipStream_t st = (hipStream_t)stream;
     if (emb_dtype != MANET_EMB_F32 && emb_dtype != MANET_EMB_BF16)
         return manet_set_error(MANET_E_INVALID, "embedding dtype %d (MANET_EMB_F32 / MANET_EMB_BF16)", emb_dtype);
-    const void *fn = emb_dtype == MANET_EMB_F32 ? (const void *)frame_prepare_kernel<float, 32>
-                                                : (const void *)frame_prepare_kernel<unsigned short, 32>;
+    const void *fn = emb_dtype == MANET_EMB_F32
+                         ? (A.vec2 ? (const void *)frame_prepare_kernel<float, 32, true> : (const void *)frame_prepare_kernel<float, 32, false>)
+                         : (A.vec2 ? (const void *)frame_prepare_kernel<unsigned short, 32, true>
+                                   : (const void *)frame_prepare_kernel<unsigned short, 32, false>);
 #ifdef MANET_ABLATION
     if (XC == 64)
-        fn = emb_dtype == MANET_EMB_F32 ? (const void *)frame_prepare_kernel<float, 64>
-                                        : (const void *)frame_prepare_kernel<unsigned short, 64>;
+        fn = emb_dtype == MANET_EMB_F32
+                 ? (A.vec2 ? (const void *)frame_prepare_kernel<float, 64, true> : (const void *)frame_prepare_kernel<float, 64, false>)
+                 : (A.vec2 ? (const void *)frame_prepare_kernel<unsigned short, 64, true>
+                           : (const void *)frame_prepare_kernel<unsigned short, 64, false>);
 #endif
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     void *args[] = {(void *)&A};

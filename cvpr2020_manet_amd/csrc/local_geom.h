@@ -84,14 +84,18 @@ __host__ __device__ constexpr int lf_lab_cols(int d) { return 2 * (LF_SX - 1) + 
 // phase 2 volume: [dy][cell of S][dx], dx contiguous, cell stride an ODD number of float4 -- a pixel's four taps are
 // ds_read_b128 of 4 window columns each, and the 16 cells of a row of S land on 64 distinct banks
 __host__ __device__ constexpr int lf_vs(int d) { return 4 * (((2 * d + 1 + 3) / 4) | 1); }
-__host__ __device__ constexpr int lf_npix(int d) { return (2 * (lf_sy(d) - 1) + 4) * (2 * (LF_SX - 1) + 4); }  // pixels of a tile, upper bound
+// pixels of a tile, upper bound -- rounded up to a multiple of the 64 LDS banks: the (id, pixel) slot a lane's atomic min goes to
+// is id * lf_npix + pixel, a wave's lanes hold 64 CONSECUTIVE pixels, so whatever ids they carry they hit 64 distinct banks
+// (r1-r5: 884 = 52 mod 64 -- lanes with different ids collided)
+__host__ __device__ constexpr int lf_npix(int d) { return ((2 * (lf_sy(d) - 1) + 4) * (2 * (LF_SX - 1) + 4) + 63) / 64 * 64; }
 constexpr int LF_NIP = 8;  // object ids per pass of the per-pixel phase
 // LDS of the per-pixel phase alone (the kernel's LF_VOL_IN mode: the volume image arrives from memory)
 __host__ __device__ constexpr size_t lf_lds_vol_bytes(int d)
 {
     return (size_t)lf_nd(d) * lf_sy(d) * LF_SX * lf_vs(d) * 4 + (((size_t)lf_lab_rows(d) * lf_lab_cols(d) + 15) & ~(size_t)15) +
            (size_t)lf_npix(d) * (LF_NIP + 1) * 4 +                        // per-(id, pixel) minima + the "no id" row
-           (size_t)(2 * (lf_sy(d) - 1) + 4 + 2 * (LF_SX - 1) + 4) * 16;  // bilinear row / column tables
+           (size_t)(2 * (lf_sy(d) - 1) + 4 + 2 * (LF_SX - 1) + 4) * 16 +  // bilinear row / column tables
+           (size_t)lf_lab_rows(d) * 16;                                    // label-change masks: two 64-bit words per label row
 }
 __host__ __device__ constexpr size_t lf_lds_bytes(int d)
 {

@@ -603,6 +603,16 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if constexpr (MODE == LF_VOL_IN) {
+        // the whole volume image of this (tile, window-row group): one linear LDS-DMA stream from memory, issued FIRST -- it
+        // depends on nothing; the tile table and the label loads (a dependent chain of two memory round trips) run under it
+        constexpr int IMG_PIECES = lf_img_floats(D) / 256;
+#pragma unroll
+        for (int k = 0; k < (IMG_PIECES + NWV - 1) / NWV; ++k) {
+            const int pc = k * NWV + wave;
+            if (pc < IMG_PIECES) lds_dma16(vimg + (pc * 64 + lane) * 4, smem_base + (unsigned)pc * 1024u);
+        }
+    }
     LF_T(1)
     // full-resolution pixels of this tile: rows with i0(y) in [a, a+TY), columns with j0(x) in [b0, b0+TX) -- the
     // pooling pass left the ranges in `tab`
@@ -629,15 +639,7 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         if constexpr (MODE != LF_VOL_OUT) v = labels[idx];
         labr[k] = (yy == yc && xx == xc && !(abl & 8)) ? v : 0;
     }
-    if constexpr (MODE == LF_VOL_IN) {
-        // the whole volume image of this (tile, window-row group): one linear LDS-DMA stream, issued behind the label loads
-        constexpr int IMG_PIECES = lf_img_floats(D) / 256;
-#pragma unroll
-        for (int k = 0; k < (IMG_PIECES + NWV - 1) / NWV; ++k) {
-            const int pc = k * NWV + wave;
-            if (pc < IMG_PIECES) lds_dma16(vimg + (pc * 64 + lane) * 4, smem_base + (unsigned)pc * 1024u);
-        }
-    }
+
     // stage s is in LDS buffer s & 1.  The DMA of stage s + 1 into the other buffer (free: its last readers passed the
     // barrier) is issued first and runs under the arithmetic of stage s; the wave waits for its own pieces (vmcnt --
     // the DMA is hidden from the compiler's counters, this is the only wait on it) and the barrier publishes them.
@@ -701,6 +703,23 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         float l0, l1;
     };
     Tap *RT = (Tap *)(M2 + (LF_NIP + 1) * NPS), *CT = RT + (2 * TY + 4);
+    // r6: label-change masks.  CM[2 r + parity] bit k = (L[r][2 k + parity] != L[r][2 k + 2 + parity]): a (pixel, window row)
+    // item's 2d+1 labels are the entries pxx, pxx + 2, .. of one row -- all the SAME iff bits pxx / 2 .. pxx / 2 + 2d - 1 of
+    // its parity's mask are zero.  Masks are piecewise constant (objects are blobs): most items then take the minimum of
+    // their window row in registers and touch ONE (id, pixel) slot instead of reading 2d+1 label bytes and issuing 2d+1 LDS
+    // atomics (the per-pixel phase was LDS-bound on exactly those: 25 + 25 of 78 LDS instructions per item at d = 12).
+    unsigned long long *CM = (unsigned long long *)(CT + (2 * TX + 4));
+    if constexpr (P > 1) {
+        __syncthreads();  // L is complete
+        for (int rp = wave; rp < 2 * lrows; rp += NWV) {
+            const int r_ = rp >> 1, c0 = 2 * lane + (rp & 1);
+            const bool ok = c0 + 2 < lcols;
+            const unsigned char *lr = L + r_ * lcols + (ok ? c0 : 0);
+            const bool diff = ok && lr[0] != lr[2];
+            const unsigned long long m_ = __builtin_amdgcn_ballot_w64(diff);
+            if (lane == 0) CM[rp] = m_;
+        }
+    }
     if (tid < ny) {
         const Bilin cy = bilin_coeff(ya + tid, hp, h);
         RT[tid] = Tap{(cy.i0 - a) * LF_SX * VS, (cy.i1 - a) * LF_SX * VS, cy.l0, cy.l1};
@@ -732,6 +751,35 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
                 const unsigned char *lrow = L + (py + 2 * by) * lcols + pxx;
                 unsigned *mrow = M2 + pix;
                 const f32x2 cl0 = {c.l0, c.l0}, cl1 = {c.l1, c.l1}, rl0 = {r.l0, r.l0}, rl1 = {r.l1, r.l1};
+                if constexpr (P > 1) {
+                    // every item of this wave sees ONE label along its window row (wave-uniform test: no divergence): the
+                    // row's minimum in registers, one atomic.  Same candidates, same minimum: the same bits.
+                    const unsigned long long cm = CM[2 * (py + 2 * by) + (pxx & 1)];
+                    const bool mixed = ((cm >> (pxx >> 1)) & ((1ull << (P - 1)) - 1ull)) != 0ull;
+                    if (__builtin_amdgcn_ballot_w64(mixed) == 0ull && !(abl & 32)) {
+                        float m_ = INFINITY;
+#pragma unroll
+                        for (int q = 0; q < (P + 3) / 4; ++q) {
+                            const f32x4 t00 = *(const f32x4 *)(p00 + 4 * q), t01 = *(const f32x4 *)(p01 + 4 * q);
+                            const f32x4 t10 = *(const f32x4 *)(p10 + 4 * q), t11 = *(const f32x4 *)(p11 + 4 * q);
+#pragma unroll
+                            for (int i = 0; i < 4; i += 2) {
+                                if (4 * q + i >= P) continue;
+                                const f32x2 a00 = {t00[i], t00[i + 1]}, a01 = {t01[i], t01[i + 1]};
+                                const f32x2 a10 = {t10[i], t10[i + 1]}, a11 = {t11[i], t11[i + 1]};
+                                const f32x2 v2 = rl0 * (cl0 * a00 + cl1 * a01) + rl1 * (cl0 * a10 + cl1 * a11);
+                                m_ = (4 * q + i + 1 < P) ? fminf(fminf(m_, v2[0]), v2[1]) : fminf(m_, v2[0]);
+                            }
+                        }
+                        unsigned idx = (unsigned)lrow[0];
+                        if (!SINGLE) {
+                            idx -= (unsigned)o0;
+                            idx = idx < (unsigned)LF_NIP ? idx : (unsigned)LF_NIP;
+                        }
+                        atomicMin(mrow + idx * NPS, __float_as_uint(m_));
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < (P + 3) / 4; ++q) {
                     const f32x4 t00 = *(const f32x4 *)(p00 + 4 * q), t01 = *(const f32x4 *)(p01 + 4 * q);

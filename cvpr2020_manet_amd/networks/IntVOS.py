@@ -323,7 +323,8 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         split = "sw_object" in k and ops.conv1x1_split_ok(p1, self.conv2.out_channels)
         mfma = not split and "w2t_object" in k and ops.conv1x1_mfma_ok(p1, self.conv2.out_channels)
         term = None
-        if memo is not None and memo.get("k") is k and (split or mfma):
+        stamp = _memo_stamp(self, k)
+        if memo is not None and memo.get("k") is k and memo.get("stamp") == stamp and (split or mfma):
             term = memo.get("term")
         if term is None:
             s1 = ops.dwconv7x7_bn_relu(shared, w1[:cs], b1[:cs], scale=scale[:cs], shift=shift[:cs])
@@ -332,7 +333,7 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
             elif mfma:
                 term = ops.conv1x1_mfma(s1, k["w2t_shared"], k["b2_zero"])
             if memo is not None and term is not None:
-                memo["k"], memo["term"] = k, term
+                memo["k"], memo["term"], memo["stamp"] = k, term, stamp
         if split:
             # the shared half once, then the per-object half with it added in the epilogue (no broadcast-add pass)
             return ops.conv1x1_split(p1, k["sw_object"], k["b2"], relu_out=not defer_relu, add=term)
@@ -341,6 +342,17 @@ class _split_separable_conv2d(nn.Module):  # reference IntVOS.py:488-506
         y = self._pointwise(p1, k, "object", True, False)
         y += self._pointwise(s1, k, "shared", False, False)  # broadcast over the objects
         return y if defer_relu else y.relu_()
+
+
+def _memo_stamp(layer, k):
+    """what the memoised shared-half term conv2'(dw(shared)) depends on besides the frame: the folded constants `k` (bn1, bn2,
+    conv2 -- compared by identity: a change re-folds) AND the depthwise layer's own parameters, which `_folded`'s key does not
+    cover (an in-place change of conv1 alone left a stale term in use)"""
+    w1, b1 = layer.conv1.weight, layer.conv1.bias
+    try:
+        return (w1.data_ptr(), w1._version, None if b1 is None else (b1.data_ptr(), b1._version))
+    except RuntimeError:  # inference tensors: no version counter -- never equal to a stored stamp
+        return object()
 
 
 def _layer1_fused(layer, shared, global_map, local_map, labels, n_ids, size, memo=None):
@@ -352,15 +364,17 @@ def _layer1_fused(layer, shared, global_map, local_map, labels, n_ids, size, mem
     k = layer._folded(cs)
     if k.get("mode") != "f32" or "w2t_object" not in k or layer.conv1.in_channels != cs + 3 or layer.conv2.out_channels != ops.PW_COUT:
         return None
-    term = memo.get("term") if (memo is not None and memo.get("k") is k) else None
+    # (eligibility from the shapes, BEFORE any launch: the depthwise stage keeps [1, cs, h, w] -- ADVICE r5)
+    if shared.dim() != 4 or shared.dtype != torch.float32 or not ops.conv1x1_mfma_ok(shared, layer.conv2.out_channels):
+        return None
     w1, b1 = layer.conv1.weight, layer.conv1.bias
+    stamp = _memo_stamp(layer, k)
+    term = memo.get("term") if (memo is not None and memo.get("k") is k and memo.get("stamp") == stamp) else None
     if term is None:
         s1 = ops.dwconv7x7_bn_relu(shared, w1[:cs], b1[:cs], scale=k["scale1"][:cs], shift=k["shift1"][:cs])
-        if not ops.conv1x1_mfma_ok(s1, layer.conv2.out_channels):
-            return None
         term = ops.conv1x1_mfma(s1, k["w2t_shared"], k["b2_zero"])
         if memo is not None:
-            memo["k"], memo["term"] = k, term
+            memo["k"], memo["term"], memo["stamp"] = k, term, stamp
     return ops.head_layer1_object(global_map, local_map, labels, n_ids, size, w1[cs:], None if b1 is None else b1[cs:],
                                   k["scale1"][cs:], k["shift1"][cs:], k["w2t_object"], k["b2"], term, relu_out=True)
 
@@ -431,11 +445,13 @@ def _obj_ids(n_ids, device):
 
 MAX_CLIP_FRAMES = 104       # hard-coded clip length of the reference's memories (IntVOS.py:617,645)
 MAX_INTERACTIONS = 9        # IntVOS.py:641,645
-MAX_CACHED_FRAMES = 2 * MAX_CLIP_FRAMES + 8  # most prepared per-frame operands a model ever keeps (17 MB each at 480p)
+MAX_CACHED_FRAMES = 2 * MAX_CLIP_FRAMES + 8  # most prepared per-frame operands a model ever keeps: 17 MB each at 480p, plus --
+                                             # once a head has seen the frame -- its 26 MB layer-1 term (capped: head_memo_bytes_cap)
 DEFAULT_CACHED_FRAMES = 8   # ... and what it keeps unless the driver prepared a clip up front (prepare_clip /
                             # extract_feature(packed=True)): test.py:259's cur -> prev hand-over, the annotated frames of a few
                             # rounds (136 MB at 480p; r3 kept up to 216 frames of every tensor that ever came by: ADVICE r3)
 MAX_CACHED_BANKS = 2        # prepared memory banks kept per model (one per sequence name)
+DEFAULT_HEAD_MEMO_MB = 8192  # the heads' memoised layer-1 shared-half terms kept on cached frames: 26 MB per 480p frame and head
 DEFAULT_LOCAL_VOLUME_CACHE_MB = 8192  # stored local-match volumes (prepare_local_volumes): 25.8 MB per 480p frame pair at d = 12,
                                       # two directions x (F - 1) pairs per clip (5.1 GB for 100 frames); LRU beyond the cap
 _EMB_DTYPES = {"f32": torch.float32, "fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
@@ -496,6 +512,8 @@ class IntVOS(nn.Module):
                                            #              {(frame, round): weight}]: _mirror_of
         self._bank_cache = OrderedDict()   # seq_name -> (identity key, ops.PreparedBank, keyed tensors): _prepared_bank
         self._frame_cache = OrderedDict()  # identity key of a [C,h,w] embedding -> ops.PreparedFrame: _prepared_frame
+        self._memo_bytes = 0               # bytes of the heads' memoised shared-half terms on the frame entries (_head_memo)
+        self.head_memo_bytes_cap = int(getattr(cfg, "MODEL_HEAD_MEMO_MB", DEFAULT_HEAD_MEMO_MB)) << 20
         self._vol_cache = OrderedDict()    # (key of the previous frame, key of the current frame) -> [volume, keep-alive tensors]
         self._vol_cache_bytes = 0
         self.local_volume_cache_bytes = int(getattr(cfg, "MODEL_LOCAL_VOLUME_CACHE_MB", DEFAULT_LOCAL_VOLUME_CACHE_MB)) << 20
@@ -591,10 +609,20 @@ class IntVOS(nn.Module):
         frame = ops.prepare_frames(emb_chw, compute=self.compute, max_distance=d, preset=preset)
         if key is not None:
             frame.keep = emb_chw  # the key holds a storage pointer: keep the tensor alive with the entry
-            self._frame_cache[key] = frame
-            while len(self._frame_cache) > self._frame_cache_cap:
-                self._frame_cache.popitem(last=False)
+            self._store_frame(key, frame)
+            self._trim_frames()
         return frame, preset is not None
+
+    def _store_frame(self, key, frame):
+        old = self._frame_cache.get(key)
+        if old is not None:
+            self._memo_bytes -= old.__dict__.get("memo_bytes", 0)
+        self._frame_cache[key] = frame
+
+    def _trim_frames(self):
+        while len(self._frame_cache) > self._frame_cache_cap:
+            _, old = self._frame_cache.popitem(last=False)
+            self._memo_bytes -= old.__dict__.get("memo_bytes", 0)
 
     def _head_memo(self, emb_chw, head):
         """Holder of `head`.layer1's shared-half term for this frame (r5), or None.  It lives on the frame's entry of the
@@ -610,7 +638,17 @@ class IntVOS(nn.Module):
         if fr is None:
             return None
         memos = fr.__dict__.setdefault("head_memos", {})
-        return memos.setdefault(id(head), {})
+        holder = memos.get(id(head))
+        if holder is None:
+            # a term is [256, h, w] fp32 (26 MB at 480p) per frame and head: bounded by `head_memo_bytes_cap` --
+            # beyond it the frame simply recomputes its shared half (two launches) every round
+            per = 4 * ops.PW_COUT * int(emb_chw.shape[-2]) * int(emb_chw.shape[-1])
+            if self._memo_bytes + per > self.head_memo_bytes_cap:
+                return None
+            holder = memos[id(head)] = {}
+            fr.__dict__["memo_bytes"] = fr.__dict__.get("memo_bytes", 0) + per
+            self._memo_bytes += per
+        return holder
 
     def prepare_clip(self, embeddings, batch=16):
         """Optional, for drivers that hold a clip's embeddings in one tensor (test.py:143-154 `embedding_memory`):
@@ -631,9 +669,8 @@ class IntVOS(nn.Module):
             for j, fr in enumerate(ops.prepare_frames(chunk, compute=self.compute, max_distance=d)):
                 e = embeddings[i0 + j]
                 fr.keep = e
-                self._frame_cache[self._frame_key(e, d)] = fr
-        while len(self._frame_cache) > self._frame_cache_cap:
-            self._frame_cache.popitem(last=False)
+                self._store_frame(self._frame_key(e, d), fr)
+        self._trim_frames()
         return embeddings
 
     # ---- stored local-match volumes (r6): the label-independent half of IntVOS.py:345-434, once per frame pair -----------
@@ -727,6 +764,7 @@ class IntVOS(nn.Module):
         the identity keys can see."""
         self._bank_cache.clear()
         self._frame_cache.clear()
+        self._memo_bytes = 0
         self.invalidate_local_volumes()
         self._dist_mirror.clear()
         self._frame_cache_cap = DEFAULT_CACHED_FRAMES
@@ -794,9 +832,8 @@ class IntVOS(nn.Module):
                 key = self._frame_key(e, d)
                 if key is not None:
                     fr.keep = e
-                    self._frame_cache[key] = fr
-            while len(self._frame_cache) > self._frame_cache_cap:
-                self._frame_cache.popitem(last=False)
+                    self._store_frame(key, fr)
+            self._trim_frames()
             return emb
         x = self.semantic_embedding(x)
         if x.dtype != self.emb_dtype and not (torch.is_grad_enabled() and x.requires_grad):
@@ -1076,6 +1113,7 @@ class IntVOS(nn.Module):
                            and prev_frame_nn_features_n.dtype == torch.float32
                            and nn_features_n.numel() == h * w * n_ids and prev_frame_nn_features_n.numel() == h * w * n_ids)
             if (native_maps and isinstance(dynamic_seghead, DynamicSegHead) and not dynamic_seghead.training
+                    and not torch.is_grad_enabled()  # (eval() with grad mode on: the literal, differentiable head below -- ADVICE r5)
                     and dynamic_seghead.layer1.conv1.kernel_size == (7, 7) and (h * w) % 4 == 0):
                 # layer 1 straight from the two maps and the labels (r5): input assembly + per-object depthwise + its 1x1 + the
                 # (memoised) shared half + ReLU in one launch; layers 2-4 as ever

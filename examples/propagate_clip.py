@@ -576,6 +576,21 @@ def run_parallel(args, dev, rank, world):
         # the two directions of the propagation (forwards / backwards from the annotated frame) are independent chains:
         # rank 0 runs the forward one, rank 1 -- when there is one -- the backward one, then ships its masks to rank 0
         chain_ranks = (0, 1) if world > 1 and start > 0 else (0,)
+        # the chain's label-independent work, once per clip ON the chain rank: the window-distance volumes of the frame pairs of
+        # its direction, one batched call (33 us per pair at 480p, d = 12).  Not sharded over the ranks: a volume is 25.8 MB --
+        # 169 us over one 153 GB/s xGMI link, 24 us over all seven into the chain rank -- shipping it costs what computing it
+        # costs, and it is needed once per clip (every later round finds it stored); the global maps it is sharded "alongside"
+        # are 0.3 MB per frame.
+        vol_ms = 0.0
+        if rank in chain_ranks and not getattr(args, "no_local_volumes", False):
+            fwd = [(t - 1, t) for t in range(start + 1, F_)]
+            bwd = [(t + 1, t) for t in range(start - 1, -1, -1)]
+            mine_pairs = fwd + bwd if len(chain_ranks) == 1 else (fwd if rank == 0 else bwd)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.prepare_local_volumes(emb, pairs=mine_pairs)
+            torch.cuda.synchronize()
+            vol_ms = (time.perf_counter() - t0) * 1e3
 
         def maps_for_round():
             """this rank's block -> normalised + merged global maps; ONE collective ships every rank's to the chain rank(s)"""
@@ -596,9 +611,17 @@ def run_parallel(args, dev, rank, world):
             pre = maps_for_round()
             if rank not in chain_ranks:
                 return None
+            # the SEQUENTIAL part, timed on its own: what no number of ranks shortens
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
             if len(chain_ranks) == 1:
-                return clip.one_round(pre)
+                out_ = clip.one_round(pre)
+                torch.cuda.synchronize()
+                timing["chain_ms"], timing["chain_frames"] = (time.perf_counter() - t1) * 1e3, F_ - 1
+                return out_
             mine_ = clip.one_round(pre, directions=(rank,), as_dict=True)
+            torch.cuda.synchronize()
+            timing["chain_ms"], timing["chain_frames"] = (time.perf_counter() - t1) * 1e3, max(len(mine_) - 1, 1)
             if rank == 1:  # the backward chain's masks (frames start - 1 .. 0) -> rank 0, as int16
                 back = torch.cat([mine_[i][0] for i in range(start)], 0)
                 cp.send_tensor(back.to(torch.int16), dst=0)
@@ -620,6 +643,18 @@ def run_parallel(args, dev, rank, world):
         # the plain 1-rank loop on the same embeddings: the masks must be the same bits
         want, dt1 = clip.timed_round()
         same = bool(torch.equal(final, want))
+        # Amdahl bookkeeping of the flow: per propagated frame, the part that shards over the ranks (the global match:
+        # this rank's block, `global_maps_ms`) and the chain (local match on the stored volume + head + mask step, frame by
+        # frame on the chain rank).  ceiling = the speed-up over ONE rank's loop that no number of ranks exceeds: (sharded +
+        # chain) / chain, times the number of chain ranks (the two directions are independent chains).
+        coll = dict(timing.get("gather") or {})
+        n_mine = max(len(my_frames), 1)
+        sharded_us = timing.get("global_maps_ms", 0.0) * 1e3 / n_mine
+        chain_us = timing.get("chain_ms", 0.0) * 1e3 / max(timing.get("chain_frames", 1), 1)
+        coll.update({"sharded_us_per_frame": sharded_us, "chain_us_per_frame": chain_us, "chain_ranks": len(chain_ranks),
+                     "amdahl_ceiling": (sharded_us + chain_us) / max(chain_us, 1e-9) * len(chain_ranks),
+                     "measured_speedup": dt1 / dt})
+        timing["gather"] = coll
         return {"frames": F_, "world": world, "backend": dist.get_backend(), "pointwise": model.pointwise,
                 "compute": model.compute, "bank": clip.bank, "bank_frames": clip.bank_frames, "bank_rows": clip.bank_rows,
                 "parallel_ms_per_round": dt * 1e3, "parallel_frames_per_s": (F_ - 1) / dt,
@@ -627,6 +662,7 @@ def run_parallel(args, dev, rank, world):
                 "masks_bit_equal_to_single_rank": same, "mask_digest": mask_digest(final),
                 "chain_ranks": list(chain_ranks),
                 "clip_all_gather_ms": clip_gather_ms, "rank0_global_maps_ms": timing.get("global_maps_ms"),
+                "rank0_local_volumes_ms": vol_ms, "rank0_local_volume_MB": model.local_volume_bytes_cached() / 1e6,
                 "collective": timing.get("gather")}
 
 

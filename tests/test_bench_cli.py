@@ -124,6 +124,15 @@ def test_clip_parallel_propagation_masks_bit_equal_to_one_rank(world, frames):
     assert res["chain_ranks"] == [0, 1]
     assert col["world"] == world and col["dst"] is None and col["slab_bytes"] == -(-frames // world) * L * 4
     assert res["parallel_frames_per_s"] > 0 and res["single_rank_frames_per_s"] > 0
+    # the flow says what bounds it -- per propagated frame the sharded part (global match), the sequential
+    # chain (local match on the stored volume + head + mask step) and the speed-up no number of ranks exceeds
+    assert col["chain_ranks"] == 2 and col["chain_us_per_frame"] > 0 and col["sharded_us_per_frame"] > 0
+    assert col["amdahl_ceiling"] == pytest.approx(2 * (col["sharded_us_per_frame"] + col["chain_us_per_frame"])
+                                                  / col["chain_us_per_frame"], rel=1e-6)
+    assert 2.0 < col["amdahl_ceiling"] < 20.0 and col["measured_speedup"] > 0
+    # the chain rank stored the window-distance volumes of its direction's frame pairs, once per clip
+    per_pair = 240 * 107520 / 1e6
+    assert res["rank0_local_volume_MB"] == pytest.approx((frames - 1 - frames // 2) * per_pair, rel=1e-3)
 
 
 @pytest.mark.gpu
@@ -229,7 +238,13 @@ def test_compact_line_of_the_r04_capture_fits_4k():
     assert "traffic" in c["roofline"] and "traffic_source" not in c["roofline"]
     assert c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["cores"] == 256 and c["cpu_baseline"]["kind"] == "port"
     assert len(c["cpu_baseline"]["sample"]) <= 120
-    assert [a["cfg"] for a in c["also"]] == [3, 5] and all(a["frac"] > 0 and a["err_max"] > 0 for a in c["also"])
+    assert [a["cfg"] for a in c["also"]] == [3, 5] and all(a["frac"] > 0 and a["err_0.1"] > 0 for a in c["also"])
+    # r6: a leg LEADS with the tolerance-safe mode (bf16r: the fp32 result bit for bit); the plain-bf16 rate stands beside it
+    # (on this r4 capture: `value` = its exact_mode.value, `value_plain_bf16` = what r4 called `value`)
+    for a, fa in zip(c["also"], full["also"]):
+        assert a["value_mode"] == "bf16r" and a["value"] == pytest.approx(fa["exact_mode"]["value"], rel=1e-4)
+        assert a["value_plain_bf16"] == pytest.approx(fa["value"], rel=1e-4) and a["value"] < a["value_plain_bf16"]
+        assert "err_0.3" in a
     assert len(c["robustness"]["bf16r_fps"]) == 4 and c["e2e"]["value"] > 0 and c["local_stage"]["window_kernel_ms"] > 0
     # a block that outgrows the limit is dropped rather than breaking the line
     full["e2e"]["workload"] = "x" * 100
@@ -258,6 +273,9 @@ def test_default_command_last_line_is_compact_json():
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
     assert line["parity"]["global_map_max_abs_err"] < 1e-5
     assert line["e2e"]["value"] > 0 and len(line["also"]) == 2 and len(line["robustness"]["bf16r_fps"]) == 4
+    for a in line["also"]:  # the bf16 configs lead with the bit-exact mode; plain bf16 and its errors at both scales beside it
+        assert a["value_mode"] == "bf16r" and 0 < a["value"] and 0 < a["value_plain_bf16"]
+        assert 0 < a["err_0.1"] <= 1e-3 and a["err_0.3"] > 0
     fulls = [l for l in lines if l.startswith("#bench_full ")]
     assert len(fulls) == 1
     full = json.loads(fulls[0][len("#bench_full "):])

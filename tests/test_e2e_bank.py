@@ -220,3 +220,87 @@ def test_stored_local_volumes_give_the_fused_kernels_masks_and_follow_the_embedd
         assert torch.equal(clip2.one_round(), lazy1) and torch.equal(lazy1, m_want)
         model.invalidate_caches()
         assert model.local_volume_bytes_cached() == 0
+
+
+@pytest.mark.gpu
+def test_head_memo_follows_the_depthwise_parameters_and_respects_its_byte_cap():
+    """the memoised shared-half term also depends on layer 1's DEPTHWISE parameters (not part of the folded-constant key):
+    an in-place change of conv1.weight alone must drop the terms; `head_memo_bytes_cap` bounds what the frame entries may carry."""
+    from examples import propagate_clip as pc
+    from cvpr2020_manet_amd import ops
+    dev = torch.device("cuda", 0)
+    args = pc.parse_args(["--frames", "5", "--fused-mask-step", "--height", "240", "--width", "428"])
+    cfg, model = pc.build_model(dev, None, None, None)
+    with torch.no_grad():
+        emb = pc.synthetic_clip(model, dev, args.frames, args.height, args.width, args.objects, packed=True)
+        clip = pc.Clip(cfg, model, emb, args.height, args.width, args.objects)
+        clip.one_round()
+        per = 4 * 256 * clip.eh * clip.ew
+        assert model._memo_bytes == args.frames * per
+        calls = {"n": 0}
+        real = ops.dwconv7x7_bn_relu
+
+        def counting(x, *a, **k):
+            calls["n"] += int(x.shape[0] == 1 and x.shape[1] == 100)
+            return real(x, *a, **k)
+        ops.dwconv7x7_bn_relu = counting
+        try:
+            model.dynamic_seghead.layer1.conv1.weight[:50].mul_(0.5)  # the depthwise layer alone, in place
+            got = {}
+            clip.one_round(keep_logits=got)
+            assert calls["n"] == args.frames - 1  # every propagated frame's term was rebuilt
+        finally:
+            ops.dwconv7x7_bn_relu = real
+        fresh_cfg, fresh = pc.build_model(dev, None, None, None)
+        fresh.load_state_dict(model.state_dict())
+        want = {}
+        pc.Clip(fresh_cfg, fresh, emb, args.height, args.width, args.objects).one_round(keep_logits=want)
+        for k in want:
+            assert torch.equal(got[k], want[k])
+        # the cap: room for two terms only -- the other frames recompute their shared half every round, same logits
+        model.invalidate_caches()
+        model.head_memo_bytes_cap = 2 * per + 10
+        emb2 = model.prepare_clip(emb.clone() if isinstance(emb, torch.Tensor) else emb)
+        clip2 = pc.Clip(cfg, model, emb2, args.height, args.width, args.objects)
+        capped = {}
+        clip2.one_round(keep_logits=capped)
+        assert model._memo_bytes == 2 * per
+        for k in want:
+            assert torch.equal(capped[k], want[k])
+        model.invalidate_caches()
+        assert model._memo_bytes == 0
+
+
+@pytest.mark.gpu
+def test_eval_mode_with_grad_enabled_keeps_the_head_differentiable():
+    """model.eval() with grad mode ON and detached embeddings -- the matching kernels run (nothing to
+    differentiate there), but the head must take the literal, differentiable module chain: r5's fused layer-1 launch either raised
+    (conv1.weight requires grad) or, on a memo hit, silently detached layer 1."""
+    from examples import propagate_clip as pc
+    dev = torch.device("cuda", 0)
+    args = pc.parse_args(["--frames", "3", "--fused-mask-step", "--height", "240", "--width", "428"])
+    cfg, model = pc.build_model(dev, None, None, None)
+    with torch.no_grad():
+        emb = pc.synthetic_clip(model, dev, args.frames, args.height, args.width, args.objects, packed=True)
+        clip = pc.Clip(cfg, model, emb, args.height, args.width, args.objects)
+        want = {}
+        clip.one_round(keep_logits=want)  # (fills the memos: the hit path is the one that detached silently)
+    prev_label = torch.zeros(1, 1, args.height, args.width, dtype=torch.int64, device=dev)
+    ii = clip.start + 1
+    assert torch.is_grad_enabled() and not model.training
+    tmp, _, _ = model.prop_seghead(clip.bank_emb, emb[clip.start:clip.start + 1], emb[ii:ii + 1], clip.bank_label, prev_label,
+                                   seq_names=[pc.SEQ], gt_ids=clip.gt, k_nearest_neighbors=1, global_map_tmp_dic={},
+                                   local_map_dics=({}, {}), interaction_num=1, start_annotated_frame=clip.start, frame_num=[ii],
+                                   dynamic_seghead=model.dynamic_seghead)
+    logits = tmp[pc.SEQ]
+    assert logits.requires_grad
+    logits.square().mean().backward()
+    for layer in (model.dynamic_seghead.layer1, model.dynamic_seghead.layer4):
+        for p_ in (layer.conv1.weight, layer.conv2.weight):
+            assert p_.grad is not None and torch.isfinite(p_.grad).all() and p_.grad.abs().sum() > 0
+    with torch.no_grad():
+        fast, _, _ = model.prop_seghead(clip.bank_emb, emb[clip.start:clip.start + 1], emb[ii:ii + 1], clip.bank_label, prev_label,
+                                        seq_names=[pc.SEQ], gt_ids=clip.gt, k_nearest_neighbors=1, global_map_tmp_dic={},
+                                        local_map_dics=({}, {}), interaction_num=1, start_annotated_frame=clip.start,
+                                        frame_num=[ii], dynamic_seghead=model.dynamic_seghead)
+    torch.testing.assert_close(logits.detach(), fast[pc.SEQ], rtol=2e-4, atol=2e-4)

@@ -21,6 +21,8 @@ ap.add_argument("--d", type=int, default=12)
 ap.add_argument("--ids", type=int, default=3)
 ap.add_argument("--pairs", type=int, default=60)
 ap.add_argument("--C", type=int, default=100)
+ap.add_argument("--labels", default="blobs", choices=["blobs", "random"],
+                help="previous-frame labels: a rectangle per object over background (a mask), or i.i.d. per pixel (worst case)")
 a = ap.parse_args()
 dev = torch.device("cuda")
 torch.manual_seed(0)
@@ -28,7 +30,16 @@ h, w = a.height // 4, (a.width + 3) // 4
 F = a.pairs // 2 + 1
 embs = torch.relu(torch.randn(F, a.C, h, w, device=dev)) * 0.1
 frames = ops.prepare_frames(embs, compute="f32", max_distance=a.d)
-labs = [torch.randint(0, a.ids, (h, w), dtype=torch.int32, device=dev) for _ in range(F)]
+if a.labels == "random":
+    labs = [torch.randint(0, a.ids, (h, w), dtype=torch.int32, device=dev) for _ in range(F)]
+else:
+    labs = []
+    for t in range(F):
+        lab = torch.zeros((h, w), dtype=torch.int32, device=dev)
+        for o in range(1, a.ids):
+            y0, x0 = (11 * o + 2 * t) % max(h - 40, 1), (37 * o + 3 * t) % max(w - 60, 1)
+            lab[y0:y0 + 36, x0:x0 + 52] = o
+        labs.append(lab)
 pairs = [(t - 1, t) for t in range(1, F)] + [(t + 1, t) for t in range(F - 1)]
 pairs = pairs[:a.pairs]
 n = len(pairs)
@@ -75,7 +86,7 @@ for _ in range(3):
     fused()
 torch.cuda.synchronize()
 tf, t1, t1s, t2 = timed(fused) / n, timed(phase1) / n, timed(phase1_single) / n, timed(phase2) / n
-print("%dx%d grid, C=%d, d=%d, %d ids, %d frame pairs, volume %.1f MB per pair" % (h, w, a.C, a.d, a.ids, n, vols.shape[1] * 4 / 1e6))
+print("%dx%d grid, C=%d, d=%d, %d ids (%s labels), %d frame pairs, volume %.1f MB per pair" % (h, w, a.C, a.d, a.ids, a.labels, n, vols.shape[1] * 4 / 1e6))
 print("  fused kernel (+ fill for d >= 11)        %7.1f us per pair" % tf)
 print("  phase 1, one batched call (%2d launches)   %7.1f us per pair" % ((n + 31) // 32, t1))
 print("  phase 1, one call per pair               %7.1f us per pair" % t1s)
