@@ -369,6 +369,56 @@ def roofline_blocks(wl, kern_ms, local_ms, overlap=False, prep_ms=None):
     return roof, local
 
 
+def stored_volume_block(wl, lib, reps=4):
+    """r6: the local stage split at its label boundary.  Phase 1 -- the window distances, which depend on the two
+    embeddings only -- for a batch of frame pairs in one launch (`manet_local_volume_frames`), torch events around the call; phase 2
+    -- label gather + masked minimum on a stored volume, what a propagated frame runs from a clip's second round on -- by the
+    library's own HIP events on the launch's stream (channel 1 brackets `manet_local_match_volume`), over ROTATING pairs: every
+    pair of a clip has its own volume, so phase 2 always streams a volume nobody touched since it was written.  Its roofline is
+    HBM: algorithmic bytes = the volume as stored + labels + result."""
+    from cvpr2020_manet_amd import _lib, ops
+    n_fr = int(wl.local_emb.shape[0])
+    if n_fr < 2 or wl.d < 0:
+        return None
+    frames = ops.prepare_frames(wl.local_emb, compute=wl.compute, max_distance=wl.d)
+    pairs = [(i, i + 1) for i in range(n_fr - 1)] + [(i + 1, i) for i in range(n_fr - 1)]
+    prevs, curs = [frames[a] for a, _ in pairs], [frames[b] for _, b in pairs]
+    vols = ops.local_volumes(prevs, curs)
+    torch.cuda.synchronize()
+    t1 = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.local_volumes(prevs, curs, out=vols)
+        e1.record()
+        torch.cuda.synchronize()
+        t1.append(e0.elapsed_time(e1) * 1e3 / len(pairs))
+    out = torch.ones((wl.H, wl.W, wl.n_ids), dtype=torch.float32, device=wl.device)
+    n = reps * len(pairs)
+    for i in range(len(pairs)):  # warm-up
+        ops.local_match_volume(vols[i], curs[i], wl.prev_labs[i % len(wl.prev_labs)], wl.n_ids, out=out)
+    torch.cuda.synchronize()
+    _lib.check(lib.manet_profile_begin(n + 1), "manet_profile_begin")
+    for r in range(reps):
+        for i in range(len(pairs)):
+            # (`out` pre-set to 1.0 outside the bracket, as inside prop_seghead: there the pre-set rides in frame_begin's launch)
+            out.fill_(1.0)
+            ops.local_match_volume(vols[i], curs[i], wl.prev_labs[(i + r) % len(wl.prev_labs)], wl.n_ids, out=out, out_is_preset=True)
+    torch.cuda.synchronize()
+    ms, lms = (ctypes.c_float * n)(), (ctypes.c_float * n)()
+    nrec, nloc = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.manet_profile_end2(ms, n, ctypes.byref(nrec), lms, n, ctypes.byref(nloc)), "manet_profile_end2")
+    p2_us = float(np.mean([lms[i] for i in range(nloc.value)])) * 1e3 if nloc.value else float("nan")
+    vol_bytes = float(vols.shape[1] * 4)
+    b2 = vol_bytes + 4.0 * wl.H * wl.W * (1 + wl.n_ids)
+    return {"pairs": len(pairs), "volume_bytes_per_pair": vol_bytes,
+            "phase1_us_per_pair_batched": float(min(t1)), "phase2_us_per_frame": p2_us,
+            "phase2": {"bound": "hbm", "algorithmic_bytes": b2, "achieved": b2 / (p2_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": b2 / (p2_us * 1e-6) / (HBM_PEAK_GBS * 1e9)},
+            "note": "phase 2 (+ the 1.0 pre-set launch for d >= 11, which rides in frame_begin inside prop_seghead) is what the "
+                    "sequential chain runs per frame once a clip's volumes are stored (IntVOS.prepare_local_volumes)"}
+
+
 def _sha(path):
     try:
         return hashlib.sha256(open(path, "rb").read()).hexdigest()[:12]
@@ -838,6 +888,10 @@ def compact_line(full):
         out["local_stage"] = {"frac": ls.get("frac"), "stage_ms": ls.get("stage_ms"), "window_kernel_ms": ls.get("window_kernel_ms"),
                               "frame_prepare_ms": ls.get("frame_prepare_ms"), "valu_frac": (ls.get("valu") or {}).get("frac"),
                               "max_distance": ls.get("max_distance")}
+        sv = ls.get("stored_volume")
+        if sv:  # r6: the stage split at its label boundary -- phase 2 is what the sequential chain runs per frame
+            out["local_stage"].update({"phase1_us_per_pair": sv.get("phase1_us_per_pair_batched"),
+                                       "phase2_us": sv.get("phase2_us_per_frame"), "phase2_hbm_frac": (sv.get("phase2") or {}).get("frac")})
     if "collective" in full:
         out["collective"] = full["collective"]
     if "value_one_shot" in full:
@@ -1064,6 +1118,8 @@ def main():
             # what the collective of the timed region saw: a real N-rank run shows world == n_gpus and backend nccl
             "collective": r["collective"] if use_dist else None,
         }
+        if world == 1 and not use_dist and local is not None:
+            local["stored_volume"] = stored_volume_block(wl, lib)
         if world == 1 and not args.one_shot and not use_dist:
             # r1's definition next to the headline: the bank re-sorted / re-packed every frame, one-shot API
             r1s = run_leg(wl, min(K, 10), 2, args, lib, one_shot=True)

@@ -89,18 +89,38 @@ __host__ __device__ constexpr int lf_vs(int d) { return 4 * (((2 * d + 1 + 3) / 
 // (r1-r5: 884 = 52 mod 64 -- lanes with different ids collided)
 __host__ __device__ constexpr int lf_npix(int d) { return ((2 * (lf_sy(d) - 1) + 4) * (2 * (LF_SX - 1) + 4) + 63) / 64 * 64; }
 constexpr int LF_NIP = 8;  // object ids per pass of the per-pixel phase
-// LDS of the per-pixel phase alone (the kernel's LF_VOL_IN mode: the volume image arrives from memory)
-__host__ __device__ constexpr size_t lf_lds_vol_bytes(int d)
+// LDS of the per-pixel phase: the volume of `rows` window rows (padded to whole 1 KiB LDS-DMA pieces), the label bytes around the tile
+// for those rows, the per-(id, pixel) minima of `m2_rows` ids + the "no id" row, the bilinear tables, the label-change masks
+__host__ __device__ constexpr int lf_lab_rows_of(int d, int rows) { return 2 * (lf_sy(d) - 1) + 4 + 2 * (rows - 1); }
+__host__ __device__ constexpr size_t lf_vpad_bytes(int d, int rows) { return ((size_t)rows * lf_sy(d) * LF_SX * lf_vs(d) * 4 + 1023) / 1024 * 1024; }
+__host__ __device__ constexpr size_t lf_lds_phase2_bytes(int d, int rows, int m2_rows)
 {
-    return (size_t)lf_nd(d) * lf_sy(d) * LF_SX * lf_vs(d) * 4 + (((size_t)lf_lab_rows(d) * lf_lab_cols(d) + 15) & ~(size_t)15) +
-           (size_t)lf_npix(d) * (LF_NIP + 1) * 4 +                        // per-(id, pixel) minima + the "no id" row
-           (size_t)(2 * (lf_sy(d) - 1) + 4 + 2 * (LF_SX - 1) + 4) * 16 +  // bilinear row / column tables
-           (size_t)lf_lab_rows(d) * 16;                                    // label-change masks: two 64-bit words per label row
+    return lf_vpad_bytes(d, rows) + (((size_t)lf_lab_rows_of(d, rows) * lf_lab_cols(d) + 15) & ~(size_t)15) +
+           (size_t)lf_npix(d) * (m2_rows + 1) * 4 + (size_t)(2 * (lf_sy(d) - 1) + 4 + 2 * (LF_SX - 1) + 4) * 16 +
+           (size_t)lf_lab_rows_of(d, rows) * 16;
+}
+// The per-pixel phase ON A STORED VOLUME (the kernel's LF_VOL_IN mode, r6) can deal the window rows of an image to lf_nsub(d) workgroups of
+// lf_ndv(d) rows each (two or more then fit a CU).  Measured at 480p, d = 12 (docs/history/r06_experiments.md): 5 rows per workgroup
+// (one wave of 240 workgroups) 21.1 us; 2 rows (720 workgroups, two per CU) 23.8; 1 row (1 200, four per CU) 26-30 -- every
+// workgroup pays the label fetch, the tables, the minima's initialisation and the closing atomics again, and those, not the volume
+// stream, are what a workgroup waits for.  Shipped: no split (lf_ndv = lf_nd).
+#ifndef MANET_LF_NDV12
+#define MANET_LF_NDV12 5  // (A/B builds: window rows per workgroup of the stored-volume kernel at d = 12)
+#endif
+#ifndef MANET_LF_NTV
+#define MANET_LF_NTV 0    // (A/B builds: threads per workgroup of the stored-volume kernel at d >= 10; 0 = the fused kernel's)
+#endif
+__host__ __device__ constexpr int lf_ndv(int d) { return d == 12 ? MANET_LF_NDV12 : lf_nd(d); }
+__host__ __device__ constexpr int lf_ntv(int d) { return (MANET_LF_NTV > 0 && d >= 10) ? MANET_LF_NTV : lf_nt(d); }
+__host__ __device__ constexpr int lf_nsub(int d) { return (lf_nd(d) + lf_ndv(d) - 1) / lf_ndv(d); }
+__host__ __device__ constexpr size_t lf_lds_vol_bytes(int d, int n_ids)
+{
+    return lf_lds_phase2_bytes(d, lf_ndv(d), n_ids <= LF_NIP ? n_ids : LF_NIP);
 }
 __host__ __device__ constexpr size_t lf_lds_bytes(int d)
 {
     size_t stage = 2 * (size_t)lf_stage_floats(d) * 4;
-    size_t vol = lf_lds_vol_bytes(d);
+    size_t vol = lf_lds_phase2_bytes(d, lf_nd(d), LF_NIP);
     return stage > vol ? stage : vol;
 }
 // padded pooled plane [HPAD][WS]: image pixel (py, px) at (d + py, d + px)

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     constexpr int abl = 0;
 #endif
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int P = 2 * D + 1, NT = lf_nt(D), ND = lf_nd(D), NDG = lf_ndg(D), SY = lf_sy(D), TY = SY - 1;
+    constexpr int P = 2 * D + 1, NT = MODE == LF_VOL_IN ? lf_ntv(D) : lf_nt(D), ND = lf_nd(D), NDG = lf_ndg(D), SY = lf_sy(D), TY = SY - 1;
     constexpr int TX = LF_SX - 1, CW = lf_cw(D), YR = lf_yr(D), CC = lf_cc(D), COLS = lf_cols(D), NG = LF_SX / COLS;
     constexpr int DXS = lf_dxs(D), PA = lf_pa(D), LF_PH = lf_ph(D);
     constexpr int yplane = YR * CW, xplane = SY * LF_SX;
@@ -448,11 +448,18 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     // of a full-height strip per tile column -- r3 PMC at 480p, d=12: the kernel's fabric fetch 33 -> 22 MB.
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int tix = (xcd & 3) * rw + idx % rw, tmp_ = idx / rw;
-    const int tiy = (xcd >> 2) * rh + tmp_ % rh, tiz = tmp_ / rh;
+    // LF_VOL_IN: an image's window rows are dealt to NSUB workgroups of NDR rows (lf_ndv): two of them fit a CU
+    constexpr int NDR = MODE == LF_VOL_IN ? lf_ndv(D) : ND, NSUB = MODE == LF_VOL_IN ? lf_nsub(D) : 1;
+    const int tiy = (xcd >> 2) * rh + tmp_ % rh, tizs = tmp_ / rh;
+    const int tiz = tizs / NSUB, sub = tizs - tiz * NSUB;
     if (tix >= ntx || tiy >= nty) return;  // (the regions' padding)
     const int a = tiy * TY, b0 = tix * TX;  // pooled origin of S
-    const int dy0 = tiz * ND;               // first window row of this workgroup
-    float *vimg = MODE == LF_FUSED ? nullptr : vol + (long)((tiz * nty + tiy) * ntx + tix) * lf_img_floats(D);
+    const int dy0 = tiz * ND + sub * NDR;   // first window row of this workgroup
+    // window rows this workgroup really owns (the last group of an image / the last image of a tile may hold fewer)
+    const int nd_here = min(min(P - dy0, ND - sub * NDR), NDR);
+    if (nd_here <= 0) return;
+    float *vimg = MODE == LF_FUSED ? nullptr
+                                   : vol + (long)((tiz * nty + tiy) * ntx + tix) * lf_img_floats(D) + (long)sub * NDR * (SY * LF_SX * lf_vs(D));
 
     // ---- phase 1: distances on S for window rows dy0 .. dy0+ND-1 ---------------------------------
     // Staging by LDS-DMA (lds_dma16: 64 lanes x 16 bytes land in 1 KiB of LDS, no VGPR hop, no ds_write): a stage is
@@ -606,7 +613,7 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     if constexpr (MODE == LF_VOL_IN) {
         // the whole volume image of this (tile, window-row group): one linear LDS-DMA stream from memory, issued FIRST -- it
         // depends on nothing; the tile table and the label loads (a dependent chain of two memory round trips) run under it
-        constexpr int IMG_PIECES = lf_img_floats(D) / 256;
+        constexpr int IMG_PIECES = (int)(lf_vpad_bytes(D, NDR) / 1024);  // (whole pieces: the tail over-reads into the next rows / image)
 #pragma unroll
         for (int k = 0; k < (IMG_PIECES + NWV - 1) / NWV; ++k) {
             const int pc = k * NWV + wave;
@@ -623,8 +630,8 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     // the previous frame's labels around the tile: rows ya + 2(dy0 - D) .., columns xa - 2D ..; outside the image = 0
     // (zero padding, IntVOS.py:400).  Loaded NOW (behind the first two stages' loads, under the first stage's arithmetic), used after phase 1: they come
     // from HBM (nobody has touched them this frame) and would otherwise cost a full miss latency between the phases
-    constexpr int KL = (lf_lab_rows(D) * lf_lab_cols(D) + NT - 1) / NT;
-    const int lrows = ny + 2 * (ND - 1), lcols = nx + 4 * D;
+    constexpr int KL = (lf_lab_rows_of(D, NDR) * lf_lab_cols(D) + NT - 1) / NT;
+    const int lrows = ny + 2 * (NDR - 1), lcols = nx + 4 * D;
     const int ly0 = ya + 2 * (dy0 - D), lx0 = xa - 2 * D;
     int labr[KL];
 #pragma unroll
@@ -654,8 +661,8 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
 
     LF_T(2)
     constexpr int VS = lf_vs(D), NPS = lf_npix(D);
-    float *V = smem;                                                 // [ND][SY * 16][VS]
-    unsigned char *L = (unsigned char *)(V + ND * SY * LF_SX * VS);  // [lab_rows][lab_cols], 255 = matches no id
+    float *V = smem;                                                 // [NDR][SY * 16][VS] (+ the tail of the last LDS-DMA piece)
+    unsigned char *L = (unsigned char *)smem + lf_vpad_bytes(D, NDR);  // [lab_rows][lab_cols]; a byte >= the pass's ids = "no id"
     if (MODE != LF_VOL_IN && active) {
         float *vp0 = V + ((dyi * SY + ry) * LF_SX + COLS * g) * VS + dx_lo;
 #pragma unroll
@@ -691,18 +698,19 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
 #pragma unroll
     for (int k = 0; k < KL; ++k) {
         const int e = tid + NT * k;
-        // one pass over the ids (n_ids <= LF_NIP): store the M2 row directly -- the id, or LF_NIP for "no id of this pass"
-        const int lmax = n_ids <= LF_NIP ? LF_NIP : 255;
+        // one pass over the ids (n_ids <= LF_NIP): store the M2 row directly -- the id, or n_ids for "no id" (the row behind the ids')
+        const int lmax = n_ids <= LF_NIP ? n_ids : 255;
         if (e < lrows * lcols) L[e] = (labr[k] >= 0 && labr[k] < (n_ids <= LF_NIP ? n_ids : MANET_MAX_IDS)) ? (unsigned char)labr[k] : (unsigned char)lmax;
     }
     // per-(id, pixel) minima [LF_NIP + 1][NPS] (row LF_NIP collects the candidates whose label is not an id of this
     // pass), then the separable bilinear tables: tap offsets into V and the two weights, per pixel row / column
-    unsigned *M2 = (unsigned *)(L + (((size_t)lf_lab_rows(D) * lf_lab_cols(D) + 15) & ~(size_t)15));
+    unsigned *M2 = (unsigned *)(L + (((size_t)lf_lab_rows_of(D, NDR) * lf_lab_cols(D) + 15) & ~(size_t)15));
+    const int m2_rows = n_ids <= LF_NIP ? n_ids : LF_NIP;  // + the "no id" row (the launcher sized the LDS for it)
     struct Tap {
         int o0, o1;
         float l0, l1;
     };
-    Tap *RT = (Tap *)(M2 + (LF_NIP + 1) * NPS), *CT = RT + (2 * TY + 4);
+    Tap *RT = (Tap *)(M2 + (m2_rows + 1) * NPS), *CT = RT + (2 * TY + 4);
     // r6: label-change masks.  CM[2 r + parity] bit k = (L[r][2 k + parity] != L[r][2 k + 2 + parity]): a (pixel, window row)
     // item's 2d+1 labels are the entries pxx, pxx + 2, .. of one row -- all the SAME iff bits pxx / 2 .. pxx / 2 + 2d - 1 of
     // its parity's mask are zero.  Masks are piecewise constant (objects are blobs): most items then take the minimum of
@@ -727,7 +735,6 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         const Bilin cx = bilin_coeff(xa + tid - 64, wp, w);
         CT[tid - 64] = Tap{(cx.i0 - b0) * VS, (cx.i1 - b0) * VS, cx.l0, cx.l1};
     }
-    const int nd_here = (P - dy0) < ND ? (P - dy0) : ND;  // window rows this workgroup really owns
     // work item = (pixel, window row): every lane busy whatever the tile's pixel count.  The item walks its window
     // row four columns at a time (four b128 taps), and every candidate goes to its (id, pixel) slot by an LDS
     // atomic min on the float bits -- all candidates lie in [0, 1], start value 1.0 = "no match" (IntVOS.py:429-432:
@@ -816,7 +823,7 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
             const int pix = e / nk, k = e - pix * nk;
             const int py = pix / nx, pxx = pix - py * nx;
             float *o = out + ((long)(ya + py) * w + (xa + pxx)) * n_ids + o0 + k;
-            if (NDG == 1) *o = __uint_as_float(M2[k * NPS + pix]);
+            if (NDG * NSUB == 1) *o = __uint_as_float(M2[k * NPS + pix]);
             else atomicMin((unsigned *)o, M2[k * NPS + pix]);  // several workgroups per tile: `out` was pre-set to 1.0
         }
         __syncthreads();
@@ -833,15 +840,16 @@ static void launch_fused_d(hipStream_t st, const float *ap, const float *bp, con
     // i0 runs over 0..hp-1 (the last value only for the last row); tiles cover all of them
     const int ntx = (G.wp + TX - 1) / TX, nty = (G.hp + TY - 1) / TY;
     const int rw = (ntx + 3) / 4, rh = (nty + 1) / 2;  // tiles per XCD region (4 x 2 regions)
-    dim3 grid((unsigned)(8 * rw * rh * lf_ndg(D)), (unsigned)(MODE == LF_VOL_OUT ? n_pairs : 1));
-    const size_t lds = MODE == LF_VOL_IN ? lf_lds_vol_bytes(D) : lf_lds_bytes(D);
-    (void)hipFuncSetAttribute((const void *)local_fused_kernel<D, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((unsigned)(8 * rw * rh * lf_ndg(D) * (MODE == LF_VOL_IN ? lf_nsub(D) : 1)), (unsigned)(MODE == LF_VOL_OUT ? n_pairs : 1));
+    const size_t lds = MODE == LF_VOL_IN ? lf_lds_vol_bytes(D, n_ids) : lf_lds_bytes(D);
+    (void)hipFuncSetAttribute((const void *)local_fused_kernel<D, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(MODE == LF_VOL_IN ? lf_lds_vol_bytes(D, LF_NIP) : lds));
     if constexpr (MODE == LF_VOL_OUT)
         hipLaunchKernelGGL((local_fused_kernel<D, MODE>), grid, dim3(lf_nt(D)), lds, st, ap, bp, G.WS, G.plane, labels, h, w, C, n_ids,
                            out, tab, manet_tune_get(MANET_TUNE_ABLATION, 0), ntx, nty, rw, rh, vol, *batch);
     else
-        hipLaunchKernelGGL((local_fused_kernel<D, MODE>), grid, dim3(lf_nt(D)), lds, st, ap, bp, G.WS, G.plane, labels, h, w, C, n_ids,
-                           out, tab, manet_tune_get(MANET_TUNE_ABLATION, 0), ntx, nty, rw, rh, vol, 0);
+        hipLaunchKernelGGL((local_fused_kernel<D, MODE>), grid, dim3(MODE == LF_VOL_IN ? lf_ntv(D) : lf_nt(D)), lds, st, ap, bp, G.WS,
+                           G.plane, labels, h, w, C, n_ids, out, tab, manet_tune_get(MANET_TUNE_ABLATION, 0), ntx, nty, rw, rh, vol, 0);
 }
 // workgroups (= volume images) of one frame pair
 static long lf_images(int h, int w, int d)
@@ -1245,7 +1253,8 @@ int manet_local_volume_bytes(int h, int w, int max_distance, size_t *bytes)
     if (!bytes) return manet_set_error(MANET_E_INVALID, "bytes == NULL");
     int rc = check_local(h, w, 1, max_distance, 1);
     if (rc) return rc;
-    *bytes = (size_t)lf_images(h, w, max_distance) * lf_img_floats(max_distance) * sizeof(float);
+    // (+ 1 KiB: the per-pixel kernel fetches a sub-group's rows in whole 1 KiB pieces and may read past the last image's end)
+    *bytes = (size_t)lf_images(h, w, max_distance) * lf_img_floats(max_distance) * sizeof(float) + 1024;
     return MANET_OK;
 }
 
@@ -1305,7 +1314,7 @@ int manet_local_match_volume(const float *volume, const void *cur_frame_ws, cons
     G.hp = F.hp; G.wp = F.wp; G.HPAD = F.HPAD; G.WS = F.WS; G.plane = F.PS;
     const int *tab = (const int *)((const char *)cur_frame_ws + F.off_tab);
     manet_profile_record(st, true, 1);
-    if (lf_ndg(max_distance) > 1 && !out_is_preset) {  // partial minima of several workgroups per tile meet by atomicMin
+    if (lf_ndg(max_distance) * lf_nsub(max_distance) > 1 && !out_is_preset) {  // partial minima of several workgroups per tile meet by atomicMin
         const long n_out = (long)h * w * n_ids;
         unsigned blocks = (unsigned)((n_out + 255) / 256);
         if (blocks > 1024) blocks = 1024;

@@ -711,11 +711,15 @@ class IntVOS(nn.Module):
         h, w = todo[0][3].shape[-2:]
         per = ops.local_volume_bytes(int(h), int(w), d)
         todo = todo[:max(0, self.local_volume_cache_bytes // per)]  # what does not fit the cap stays on the fused kernel
+        if not todo:
+            return hits
+        # ONE allocation for the call's volumes (a first-time device allocation of this size costs milliseconds: once, not per batch)
+        store = torch.empty((len(todo), per // 4), dtype=torch.float32, device=todo[0][3].device)
         for i0 in range(0, len(todo), batch):
             part = todo[i0:i0 + batch]
             prevs = [self._prepared_frame(ep)[0] for (_, _, ep, _) in part]
             curs = [self._prepared_frame(ec)[0] for (_, _, _, ec) in part]
-            vols = ops.local_volumes(prevs, curs)
+            vols = ops.local_volumes(prevs, curs, out=store[i0:i0 + len(part)])
             for j, (kp, kc, ep, ec) in enumerate(part):
                 self._vol_store((kp, kc), vols[j], ep, ec)
         return hits + len(todo)

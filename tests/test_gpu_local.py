@@ -291,5 +291,5 @@ def test_stored_volume_full_size_480p(ops):
     lab = torch.randint(0, n_ids, (h, w), dtype=torch.int32, device="cuda")
     frames = ops.prepare_frames(embs, compute="f32", max_distance=d)
     vols = ops.local_volumes([frames[0]], [frames[1]])
-    assert vols.numel() * 4 == ops.local_volume_bytes(h, w, d) == 240 * 107520
+    assert vols.numel() * 4 == ops.local_volume_bytes(h, w, d) == 240 * 107520 + 1024  # (+ the last LDS-DMA piece's slack)
     assert torch.equal(ops.local_match_volume(vols[0], frames[1], lab, n_ids), ops.local_match_frames(frames[0], frames[1], lab, n_ids))

@@ -12,6 +12,10 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
+from cvpr2020_manet_amd import _lib  # noqa: E402
+
+if os.environ.get("MANET_LIB_VARIANT"):  # experiments: a variant build of the library (make VAR=...)
+    _lib.LIB_PATH = os.path.abspath(os.environ["MANET_LIB_VARIANT"])
 from cvpr2020_manet_amd import ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
