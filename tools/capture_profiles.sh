@@ -34,3 +34,12 @@ tail -8 gpurun_out/$R/${R}_head_pointwise.log
 python tools/frame_prep_bench.py > gpurun_out/$R/${R}_frame_prepare.log 2>&1
 python tools/local_kernel_us.py >> gpurun_out/$R/${R}_frame_prepare.log 2>&1
 tail -12 gpurun_out/$R/${R}_frame_prepare.log
+# r6: the head's kernels on a WARM GPU and the local match split at its label boundary (stored volumes)
+tools/head_pmc.sh $R/head > gpurun_out/$R/${R}_head.log 2>&1
+cp gpurun_out/$R/head/pmc_summary.csv gpurun_out/$R/${R}_head_pmc_summary.csv
+cp gpurun_out/$R/head/kernel_stats.csv gpurun_out/$R/${R}_head_kernel_stats.csv
+tail -4 gpurun_out/$R/${R}_head.log
+tools/local_volume_pmc.sh $R/localvol --d 12 > gpurun_out/$R/${R}_localvol.log 2>&1
+cp gpurun_out/$R/localvol/pmc_summary.csv gpurun_out/$R/${R}_local_volume_pmc_summary.csv
+cp gpurun_out/$R/localvol/kernel_stats.csv gpurun_out/$R/${R}_local_volume_kernel_stats.csv
+head -12 gpurun_out/$R/${R}_localvol.log

@@ -9,7 +9,7 @@ mkdir -p $OUT
 F=31
 cd /tmp && export TMPDIR=/tmp
 for R in 1 3; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r$R -o p -- python3 $REPO/examples/propagate_clip.py --frames $F --rounds $R --fused-mask-step > $OUT/r$R.log 2>&1
+  timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r$R -o p -- python3 $REPO/examples/propagate_clip.py --frames $F --rounds $R --fused-mask-step > $OUT/r$R.log 2>&1
 done
 cd $REPO
 python3 - $OUT $F <<'PY'

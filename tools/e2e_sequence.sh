@@ -3,7 +3,7 @@
 # with the idle gap in front of each launch -- how the blocking host-to-device copy behind `table[i][j] = weight` was found (r5).
 mkdir -p gpurun_out/seq
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/seq/t -o p -- python3 $GRAFT_REPO_ROOT/examples/propagate_clip.py --frames 9 --rounds 2 --fused-mask-step > $GRAFT_REPO_ROOT/gpurun_out/seq/log.txt 2>&1
+timeout -k 5 900 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/seq/t -o p -- python3 $GRAFT_REPO_ROOT/examples/propagate_clip.py --frames 9 --rounds 2 --fused-mask-step > $GRAFT_REPO_ROOT/gpurun_out/seq/log.txt 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import csv, glob, re

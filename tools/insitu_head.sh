@@ -4,7 +4,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/insitu; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for cfg in "0 0" "1 0" "0 1" "1 1"; do set -- $cfg
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/m$1f$2 -o p -- python3 $REPO/tools/insitu_head.py --match $1 --fresh $2 > $OUT/m$1f$2.log 2>&1
+  timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/m$1f$2 -o p -- python3 $REPO/tools/insitu_head.py --match $1 --fresh $2 > $OUT/m$1f$2.log 2>&1
   echo "== global match in the loop: $1, fresh inputs: $2"
   python3 - $OUT/m$1f$2 <<'PY'
 import csv, glob, sys, re

@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python3 $REPO/bench.py "$@" > $OUT/log.txt 2>&1
+timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python3 $REPO/bench.py "$@" > $OUT/log.txt 2>&1
 cd $REPO
 python3 - $OUT <<'PY'
 import csv, glob, sys

@@ -25,6 +25,7 @@ ap.add_argument("--d", type=int, default=12)
 ap.add_argument("--ids", type=int, default=3)
 ap.add_argument("--pairs", type=int, default=60)
 ap.add_argument("--C", type=int, default=100)
+ap.add_argument("--reps", type=int, default=5, help="repetitions of every timed loop (1 under the profiler's counter passes)")
 ap.add_argument("--labels", default="blobs", choices=["blobs", "random"],
                 help="previous-frame labels: a rectangle per object over background (a mask), or i.i.d. per pixel (worst case)")
 a = ap.parse_args()
@@ -49,7 +50,8 @@ pairs = pairs[:a.pairs]
 n = len(pairs)
 
 
-def timed(fn, reps=5):
+def timed(fn, reps=None):
+    reps = a.reps if reps is None else reps
     best = 1e30
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

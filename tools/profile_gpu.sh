@@ -8,12 +8,12 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python3 $REPO/bench.py "$@" --no-cpu-baseline > $OUT/stats.log 2>&1
+timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python3 $REPO/bench.py "$@" --no-cpu-baseline > $OUT/stats.log 2>&1
 for grp in "mfma:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" \
            "lds:SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM" \
            "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
   name=${grp%%:*}; ctrs=${grp#*:}
-  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/pmc_$name -o p -- python3 $REPO/bench.py "$@" --steps 6 --warmup 2 --no-cpu-baseline > $OUT/pmc_$name.log 2>&1
+  timeout -k 5 900 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/pmc_$name -o p -- python3 $REPO/bench.py "$@" --steps 6 --warmup 2 --no-cpu-baseline > $OUT/pmc_$name.log 2>&1
 done
 cd $REPO
 f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
