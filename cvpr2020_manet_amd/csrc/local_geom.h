@@ -26,7 +26,7 @@ __device__ __forceinline__ Bilin bilin_coeff(int dst, int in_size, int out_size)
 }
 // smallest dst in [0, out_size] whose i0 is >= target (i0 is monotone in dst): an estimate from the inverse map,
 // settled with the forward expression itself -- a couple of evaluations instead of a scan over the tile
-__device__ __forceinline__ int bilin_first(int target, int in_size, int out_size)
+__host__ __device__ __forceinline__ int bilin_first(int target, int in_size, int out_size)
 {
     if (target <= 0) return 0;
     if (target > in_size - 1) return out_size;

@@ -404,6 +404,42 @@ struct LfBatch {
     const float *cur[LF_BATCH], *prev[LF_BATCH];
     float *vol[LF_BATCH];
 };
+// LF_VOL_IN: the tile table (first pixel row / column of every tile) computed on the HOST with the device's expression (fp32 IEEE
+// operations, no contraction: the same integers) and handed over as a kernel argument -- a workgroup's label loads then depend on no
+// memory round trip (under the volume stream the table read alone took 2.5 us, timeline in docs/history/r06_experiments.md)
+constexpr int LF_TAB_MAX = 96;
+struct LfTab {
+    int n;  // entries (nty + 1 + ntx + 1), or 0: read the frame's table from memory
+    int v[LF_TAB_MAX];
+};
+// wave-uniform counted wait (LDS-DMA pieces and asm-issued loads are invisible to the compiler's own counters)
+__device__ __forceinline__ void lf_wait_vmcnt(int n)
+{
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // (more pieces per wave than the table: wait for all)
+    }
+}
 // floats of one workgroup's volume image in memory: the LDS image padded to whole 1 KiB LDS-DMA pieces
 __host__ __device__ constexpr int lf_img_floats(int d) { return (lf_nd(d) * lf_sy(d) * LF_SX * lf_vs(d) + 255) / 256 * 256; }
 template <int D, int MODE>
@@ -413,7 +449,8 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
                                                                int n_ids, float *__restrict__ out,
                                                                const int *__restrict__ tab, int abl_arg, int ntx, int nty,
                                                                int rw, int rh, float *__restrict__ vol_arg,
-                                                               const typename std::conditional<MODE == LF_VOL_OUT, LfBatch, int>::type batch)
+                                                               const typename std::conditional<MODE == LF_VOL_OUT, LfBatch,
+                                                                   typename std::conditional<MODE == LF_VOL_IN, LfTab, int>::type>::type batch)
 {
     const float *curp = curp_arg, *prevp = prevp_arg;
     float *vol = vol_arg;
@@ -610,21 +647,33 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if constexpr (MODE == LF_VOL_IN) {
-        // the whole volume image of this (tile, window-row group): one linear LDS-DMA stream from memory, issued FIRST -- it
-        // depends on nothing; the tile table and the label loads (a dependent chain of two memory round trips) run under it
-        constexpr int IMG_PIECES = (int)(lf_vpad_bytes(D, NDR) / 1024);  // (whole pieces: the tail over-reads into the next rows / image)
-#pragma unroll
-        for (int k = 0; k < (IMG_PIECES + NWV - 1) / NWV; ++k) {
-            const int pc = k * NWV + wave;
-            if (pc < IMG_PIECES) lds_dma16(vimg + (pc * 64 + lane) * 4, smem_base + (unsigned)pc * 1024u);
-        }
-    }
+    // LF_VOL_IN: order of the memory traffic.  (1) the label loads -- issued from asm so that the compiler's own counted waits (which
+    // know nothing of the LDS-DMA pieces behind them) do not drain the volume stream when the labels are used; their addresses come
+    // from the host's tile table, i.e. from the kernel argument: no dependent memory round trip; (2) the volume image of this (tile,
+    // window-row group), all pieces; then counted waits: the labels (oldest) -> label bytes, change masks, tables, minima; the first
+    // VR1 window rows -> their items; the rest -> the other items.  The launch is one wave of workgroups: without this every
+    // workgroup waited 7 us for the whole 25.8 MB and then all of them computed (timeline in docs/history/r06_experiments.md).
+    constexpr int VR1 = (2 * NDR) / 5 > 0 ? (2 * NDR) / 5 : 1;  // window rows whose items start first
+    constexpr int IMG_PIECES = (int)(lf_vpad_bytes(D, NDR) / 1024);  // (whole 1 KiB pieces: the tail lands in the V region's padding)
+    constexpr int IMG_P1 = NDR > VR1 ? (VR1 * SY * LF_SX * lf_vs(D) * 4 + 1023) / 1024 : IMG_PIECES;
+    // this wave's pieces among the first x pieces of the image (dealt round-robin)
+    auto my_pieces = [&](int x) __attribute__((always_inline)) { return x > wave ? (x - wave + NWV - 1) / NWV : 0; };
     LF_T(1)
     // full-resolution pixels of this tile: rows with i0(y) in [a, a+TY), columns with j0(x) in [b0, b0+TX) -- the
     // pooling pass left the ranges in `tab`
-    const int ya = tab[tiy], yb = tab[tiy + 1];
-    const int xa = tab[nty + 1 + tix], xb = tab[nty + 2 + tix];
+    int ya = 0, yb = 0, xa = 0, xb = 0;
+    bool host_tab = false;
+    if constexpr (MODE == LF_VOL_IN) host_tab = batch.n > 0;
+    if constexpr (MODE == LF_VOL_IN) {
+        if (host_tab) {
+            ya = batch.v[tiy], yb = batch.v[tiy + 1];
+            xa = batch.v[nty + 1 + tix], xb = batch.v[nty + 2 + tix];
+        }
+    }
+    if (!host_tab) {
+        ya = tab[tiy], yb = tab[tiy + 1];
+        xa = tab[nty + 1 + tix], xb = tab[nty + 2 + tix];
+    }
     const int ny = yb - ya, nx = xb - xa;
     if (ny > 2 * TY + 4 || nx > 2 * TX + 4) __builtin_trap();  // cannot happen (ratio (hp-1)/(h-1) < 1/2): fail loudly, never overrun L
     // the previous frame's labels around the tile: rows ya + 2(dy0 - D) .., columns xa - 2D ..; outside the image = 0
@@ -643,8 +692,29 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         int idx = yc * w + xc;
         asm volatile("" : "+v"(idx));  // the compiler must not turn the clamp back into a branch around the load:
         int v = 0;                     // unconditional loads issue back to back, a branchy one waits vmcnt(0) each time
-        if constexpr (MODE != LF_VOL_OUT) v = labels[idx];
-        labr[k] = (yy == yc && xx == xc && !(abl & 8)) ? v : 0;
+        if constexpr (MODE == LF_FUSED) v = labels[idx];
+        if constexpr (MODE == LF_VOL_IN) {
+            const unsigned boff = 4u * (unsigned)idx;
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(boff), "s"(labels) : "memory");
+            labr[k] = v;  // (masked below, after the wait: the asm load's result must not be touched before it)
+        } else {
+            labr[k] = (yy == yc && xx == xc && !(abl & 8)) ? v : 0;
+        }
+    }
+    if constexpr (MODE == LF_VOL_IN) {
+        for (int pc = wave; pc < IMG_PIECES; pc += NWV) lds_dma16(vimg + (pc * 64 + lane) * 4, smem_base + (unsigned)pc * 1024u);
+        lf_wait_vmcnt(my_pieces(IMG_PIECES));  // the label loads are older than this wave's pieces: they have landed
+    }
+    if constexpr (MODE == LF_VOL_IN) {
+#pragma unroll
+        for (int k = 0; k < KL; ++k) {
+            asm volatile("" : "+v"(labr[k]));  // (uses stay behind the wait)
+            const int e = tid + NT * k;
+            const int r = e / lcols, c = e - r * lcols;
+            const int yy = ly0 + r, xx = lx0 + c;
+            const bool inside = yy >= 0 && yy < h && xx >= 0 && xx < w;
+            labr[k] = (inside && !(abl & 8)) ? labr[k] : 0;
+        }
     }
 
     // stage s is in LDS buffer s & 1.  The DMA of stage s + 1 into the other buffer (free: its last readers passed the
@@ -691,10 +761,6 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         for (int i = tid; i < IMG4; i += NT) ((f32x4 *)vimg)[i] = ((const f32x4 *)V)[i];
         return;
     }
-    if constexpr (MODE == LF_VOL_IN) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the image have landed ...
-        __syncthreads();                                   // ... everyone's have (the tail of the last piece overlaps L: written below)
-    }
 #pragma unroll
     for (int k = 0; k < KL; ++k) {
         const int e = tid + NT * k;
@@ -702,6 +768,7 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
         const int lmax = n_ids <= LF_NIP ? n_ids : 255;
         if (e < lrows * lcols) L[e] = (labr[k] >= 0 && labr[k] < (n_ids <= LF_NIP ? n_ids : MANET_MAX_IDS)) ? (unsigned char)labr[k] : (unsigned char)lmax;
     }
+    LF_T(7)
     // per-(id, pixel) minima [LF_NIP + 1][NPS] (row LF_NIP collects the candidates whose label is not an id of this
     // pass), then the separable bilinear tables: tap offsets into V and the two weights, per pixel row / column
     unsigned *M2 = (unsigned *)(L + (((size_t)lf_lab_rows_of(D, NDR) * lf_lab_cols(D) + 15) & ~(size_t)15));
@@ -744,12 +811,14 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
     for (int o0 = 0; o0 < n_ids; o0 += LF_NIP) {
         const int nk = (n_ids - o0) < LF_NIP ? (n_ids - o0) : LF_NIP;
         for (int e = tid; e < nk * NPS; e += NT) M2[e] = 0x3f800000u;  // the rows that are read back
+        // (LF_VOL_IN: this wave's pieces of the first VR1 window rows have landed; the barrier publishes everyone's)
+        if constexpr (MODE == LF_VOL_IN) lf_wait_vmcnt(my_pieces(IMG_PIECES) - my_pieces(IMG_P1));
         __syncthreads();
         LF_T(4)
         // n_ids <= LF_NIP (one pass): the label byte, clamped to LF_NIP, IS the row of M2
-        auto items = [&](auto single_pass) __attribute__((always_inline)) {
+        auto items = [&](auto single_pass, int item_lo, int item_hi) __attribute__((always_inline)) {
             constexpr bool SINGLE = decltype(single_pass)::value;
-            for (int item = tid; item < ((abl & 2) ? 0 : npix * nd_here); item += NT) {
+            for (int item = item_lo + tid; item < ((abl & 2) ? 0 : item_hi); item += NT) {
                 const int by = (int)(((float)item + 0.5f) * inv_npix), pix = item - by * npix;
                 const int py = (int)(((float)pix + 0.5f) * inv_nx), pxx = pix - py * nx;
                 const Tap r = RT[py], c = CT[pxx];
@@ -815,8 +884,16 @@ __global__ __launch_bounds__(lf_nt(D)) void local_fused_kernel(const float *__re
                 }
             }
         };
-        if (n_ids <= LF_NIP) items(std::true_type{});
-        else items(std::false_type{});
+        // (LF_VOL_IN: the first batch's rows, then -- once the second batch has landed -- the others)
+        const int item_mid = (MODE == LF_VOL_IN && NDR > VR1) ? npix * (nd_here < VR1 ? nd_here : VR1) : npix * nd_here;
+        if (n_ids <= LF_NIP) items(std::true_type{}, 0, item_mid);
+        else items(std::false_type{}, 0, item_mid);
+        if constexpr (MODE == LF_VOL_IN && NDR > VR1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (n_ids <= LF_NIP) items(std::true_type{}, item_mid, npix * nd_here);
+            else items(std::false_type{}, item_mid, npix * nd_here);
+        }
         __syncthreads();
         LF_T(5)
         for (int e = tid; e < npix * nk; e += NT) {
@@ -847,8 +924,18 @@ static void launch_fused_d(hipStream_t st, const float *ap, const float *bp, con
     if constexpr (MODE == LF_VOL_OUT)
         hipLaunchKernelGGL((local_fused_kernel<D, MODE>), grid, dim3(lf_nt(D)), lds, st, ap, bp, G.WS, G.plane, labels, h, w, C, n_ids,
                            out, tab, manet_tune_get(MANET_TUNE_ABLATION, 0), ntx, nty, rw, rh, vol, *batch);
-    else
-        hipLaunchKernelGGL((local_fused_kernel<D, MODE>), grid, dim3(MODE == LF_VOL_IN ? lf_ntv(D) : lf_nt(D)), lds, st, ap, bp, G.WS,
+    else if constexpr (MODE == LF_VOL_IN) {
+        LfTab T;
+        T.n = 0;
+        if (nty + 1 + ntx + 1 <= LF_TAB_MAX) {  // the device's expression on the host: the same integers (lf_pool_pad_kernel / frame prepare)
+            T.n = nty + 1 + ntx + 1;
+            for (int i = 0; i <= nty; ++i) T.v[i] = bilin_first(i * TY, G.hp, h);
+            for (int i = 0; i <= ntx; ++i) T.v[nty + 1 + i] = bilin_first(i * TX, G.wp, w);
+        }
+        hipLaunchKernelGGL((local_fused_kernel<D, MODE>), grid, dim3(lf_ntv(D)), lds, st, ap, bp, G.WS, G.plane, labels, h, w, C, n_ids,
+                           out, tab, manet_tune_get(MANET_TUNE_ABLATION, 0), ntx, nty, rw, rh, vol, T);
+    } else
+        hipLaunchKernelGGL((local_fused_kernel<D, MODE>), grid, dim3(lf_nt(D)), lds, st, ap, bp, G.WS,
                            G.plane, labels, h, w, C, n_ids, out, tab, manet_tune_get(MANET_TUNE_ABLATION, 0), ntx, nty, rw, rh, vol, 0);
 }
 // workgroups (= volume images) of one frame pair

@@ -53,3 +53,4 @@ for k, nm in enumerate(names):
     col = t[:, k]
     print("  %-50s min %6.2f  median %6.2f  max %6.2f us" % (nm, col.min(), np.median(col), col.max()))
 print("  per-phase medians:", np.round(np.median(t[:, 1:7] - t[:, 0:6], axis=0), 2))
+print("  label bytes stored (mark 7): min %6.2f  median %6.2f  max %6.2f us" % (t[:, 7].min(), np.median(t[:, 7]), t[:, 7].max()))
