@@ -50,8 +50,12 @@ FLAGS = [
     #   MODEL_EMB_DTYPE      storage of extract_feature's output in HBM: f32 | bf16 (2-byte embeddings end to end)
     #   MODEL_HEAD_POINTWISE the heads' 256-channel 1x1 layers in inference: f32 (exact fp32 MFMA) | split (split-bf16) | split3 (three-piece split: fp32-class) | framework
     #   MODEL_CACHE_FRAMES   keep prepared per-frame operands keyed on tensor identity (False: embeddings are rewritten in place)
+    #   MODEL_LOCAL_VOLUME_CACHE_MB  cap of the stored local-match volumes (IntVOS.prepare_local_volumes; LRU beyond it)
+    #   MODEL_LOCAL_VOLUME_LAZY      store a frame pair's volume at its first use (no prepare_local_volumes call needed)
+    #   MODEL_HEAD_MEMO_MB           cap of the heads' memoised layer-1 shared-half terms on the cached frames
     ("MODEL_MATCH_COMPUTE", S, "f32"), ("MODEL_EMB_DTYPE", S, "f32"), ("MODEL_HEAD_POINTWISE", S, "f32"),
-    ("MODEL_CACHE_FRAMES", B, True),
+    ("MODEL_CACHE_FRAMES", B, True), ("MODEL_LOCAL_VOLUME_CACHE_MB", I, 8192), ("MODEL_LOCAL_VOLUME_LAZY", B, False),
+    ("MODEL_HEAD_MEMO_MB", I, 8192),
     # train
     ("TRAIN_LR", F, 0.0007), ("TRAIN_LR_GAMMA", F, 0.1), ("TRAIN_MOMENTUM", F, 0.9),
     ("TRAIN_WEIGHT_DECAY", F, 0.00004), ("TRAIN_POWER", F, 0.9), ("TRAIN_BATCH_SIZE", I, 2),

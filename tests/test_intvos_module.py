@@ -370,11 +370,14 @@ def test_cfg_defaults_equal_reference():
     ref = json.load(open(os.path.join(GOLDEN, "config_defaults.json")))
     # (MODEL_MATCH_COMPUTE / MODEL_EMB_DTYPE / MODEL_HEAD_POINTWISE / MODEL_CACHE_FRAMES are this implementation's
     # extension flags, absent from the reference)
-    ext = ("MODEL_MATCH_COMPUTE", "MODEL_EMB_DTYPE", "MODEL_HEAD_POINTWISE", "MODEL_CACHE_FRAMES")
+    ext = ("MODEL_MATCH_COMPUTE", "MODEL_EMB_DTYPE", "MODEL_HEAD_POINTWISE", "MODEL_CACHE_FRAMES", "MODEL_LOCAL_VOLUME_CACHE_MB",
+           "MODEL_LOCAL_VOLUME_LAZY", "MODEL_HEAD_MEMO_MB")
     mine = {k: v for k, v in vars(make_cfg([])).items() if k != "ROOT_DIR" and k not in ext}
     assert mine == ref
     assert make_cfg([]).MODEL_MATCH_COMPUTE == "f32" and make_cfg([]).MODEL_EMB_DTYPE == "f32"
     assert make_cfg([]).MODEL_HEAD_POINTWISE == "f32" and make_cfg([]).MODEL_CACHE_FRAMES is True  # exact head by default
+    assert make_cfg([]).MODEL_LOCAL_VOLUME_CACHE_MB == 8192 and make_cfg([]).MODEL_LOCAL_VOLUME_LAZY is False
+    assert make_cfg([]).MODEL_HEAD_MEMO_MB == 8192
     assert make_cfg(["--TEST_MODE", "True", "--unknown-flag", "1"]).TEST_MODE is True
 
 
@@ -417,5 +420,8 @@ def test_constructor_switches_and_cache_hooks_on_cpu():
         m._bank_cache["s"] = ("key", None)
         m._frame_cache["k"] = object()
         m.dynamic_seghead.layer1._fold_cache = ("stale", {})
+        m._vol_cache[("prev", "cur")] = [torch.zeros(1), None, None]  # (r6: the stored local-match volumes go with them)
+        m._vol_cache_bytes, m._memo_bytes = 4, 104
         hook()
         assert not m._bank_cache and not m._frame_cache and m.dynamic_seghead.layer1._fold_cache is None
+        assert not m._vol_cache and m.local_volume_bytes_cached() == 0 and m._memo_bytes == 0
