@@ -650,6 +650,56 @@ class IntVOS(nn.Module):
             self._memo_bytes += per
         return holder
 
+    def drop_head_memos(self):
+        """forget the heads' memoised layer-1 terms (the frames' operands stay)"""
+        for fr in self._frame_cache.values():
+            fr.__dict__.pop("head_memos", None)
+            fr.__dict__.pop("memo_bytes", None)
+        self._memo_bytes = 0
+
+    def prepare_head_terms(self, embeddings, head=None, batch=8):
+        """Optional (r6), for drivers that prepared a clip (`prepare_clip` / `extract_feature(packed=True)`): the label-independent
+        part of the propagation head -- layer 1's shared-embedding half, conv2'(relu(bn1(dw7x7(embedding)))) (IntVOS.py:488-507 on
+        the 100 embedding channels of the head input, :665-670) -- for every frame of `embeddings` [F, C, h, w], `batch` frames per
+        launch, stored where `prop_seghead` looks for it (the frames' memo holders: `_head_memo`).  Without this call each frame
+        computes its term the first time a head sees it (two launches, 36 us at 480p, on the sequential chain of a sequence's first
+        round).  The same kernels on the same planes: the same bits.  Returns the number of frames whose term is stored."""
+        head = self.dynamic_seghead if head is None else head
+        if (not isinstance(head, DynamicSegHead) or head.training or self.training or not self.cache_frames
+                or torch.cuda.is_current_stream_capturing() or torch.is_grad_enabled()):
+            return 0
+        F_ = int(embeddings.shape[0])
+        if F_ == 0:
+            return 0
+        layer, cs = head.layer1, int(embeddings.shape[1])
+        k = layer._folded(cs)
+        if (k.get("mode") != "f32" or "w2t_shared" not in k or layer.conv1.in_channels != cs + 3
+                or layer.conv2.out_channels != ops.PW_COUT or layer.conv1.kernel_size != (7, 7)):
+            return 0
+        stamp = _memo_stamp(layer, k)
+        w1, b1 = layer.conv1.weight, layer.conv1.bias
+        todo, done = [], 0
+        for i in range(F_):
+            e = embeddings[i]
+            if not e.is_cuda or (e.shape[-1] * e.shape[-2]) % 4 != 0:
+                return done
+            memo = self._head_memo(e, head)  # (None: the frame is not in the cache, or the byte cap is reached)
+            if memo is None:
+                continue
+            if memo.get("k") is k and memo.get("stamp") == stamp and memo.get("term") is not None:
+                done += 1
+            else:
+                todo.append((e, memo))
+        for i0 in range(0, len(todo), batch):
+            part = todo[i0:i0 + batch]
+            x = torch.stack([e if e.dtype == torch.float32 else e.float() for e, _ in part])
+            s1 = ops.dwconv7x7_bn_relu(x, w1[:cs], None if b1 is None else b1[:cs], scale=k["scale1"][:cs], shift=k["shift1"][:cs])
+            terms = ops.conv1x1_mfma(s1, k["w2t_shared"], k["b2_zero"])  # [b, 256, h, w]
+            for j, (_, memo) in enumerate(part):
+                memo["k"], memo["term"], memo["stamp"] = k, terms[j:j + 1], stamp
+            done += len(part)
+        return done
+
     def prepare_clip(self, embeddings, batch=16):
         """Optional, for drivers that hold a clip's embeddings in one tensor (test.py:143-154 `embedding_memory`):
         prepares every frame of `embeddings` [F,C,h,w] up front, `batch` frames per launch, so the propagation loop

@@ -491,15 +491,19 @@ def run_single(args, dev, pointwise=None, want_graph=False, want_stages=False, b
         # window distances depend on the embeddings alone and every interaction round walks the clip again.  Timed on its own --
         # it is matching work, not encoder work: `eager_frames_per_s` is a round with the volumes (and the head's memoised
         # shared half) in place, i.e. any round but a sequence's first; `first_round_frames_per_s` charges this call to one round
-        vol_ms, vol_pairs = 0.0, 0
+        vol_ms, vol_pairs, term_frames = 0.0, 0, 0
         if not getattr(args, "no_local_volumes", False):
             # (untimed: code-object load of the batched launch, and the device allocation of the volumes -- the timed call then
             # finds its block in the caching allocator's free list, as every other timed region of this script / bench.py does)
             model.prepare_local_volumes(emb)
             model.invalidate_local_volumes()
+            model.prepare_head_terms(emb)
+            model.drop_head_memos()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             vol_pairs = model.prepare_local_volumes(emb)
+            # ... and the propagation head's label-independent part (layer 1's shared-embedding half), 8 frames per launch
+            term_frames = model.prepare_head_terms(emb)
             torch.cuda.synchronize()
             vol_ms = (time.perf_counter() - t0) * 1e3
         clip = Clip(cfg, model, emb, args.height, args.width, args.objects, fused_mask_step=args.fused_mask_step,
@@ -509,7 +513,8 @@ def run_single(args, dev, pointwise=None, want_graph=False, want_stages=False, b
         res = {"frames": args.frames, "grid": [clip.eh, clip.ew], "objects": args.objects, "pointwise": model.pointwise,
                "compute": model.compute, "bank": clip.bank, "bank_frames": clip.bank_frames, "bank_rows": clip.bank_rows,
                "eager_ms_per_round": dt * 1e3, "eager_frames_per_s": (args.frames - 1) / dt,
-               "local_volumes": {"pairs": vol_pairs, "ms": vol_ms, "MB": model.local_volume_bytes_cached() / 1e6},
+               "local_volumes": {"pairs": vol_pairs, "head_term_frames": term_frames, "ms": vol_ms,
+                                 "MB": model.local_volume_bytes_cached() / 1e6},
                "first_round_frames_per_s": (args.frames - 1) / (dt + vol_ms * 1e-3),
                "mask_digest": mask_digest(final)}
         if want_stages:
@@ -589,7 +594,10 @@ def run_parallel(args, dev, rank, world):
             mine_pairs = fwd + bwd if len(chain_ranks) == 1 else (fwd if rank == 0 else bwd)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+            emb_ = model.prepare_clip(emb)  # (keeps every frame's operands: the volumes and the head's terms hang on them)
+            assert emb_ is emb
             model.prepare_local_volumes(emb, pairs=mine_pairs)
+            model.prepare_head_terms(emb)   # the propagation head's label-independent part, too (8 frames per launch)
             torch.cuda.synchronize()
             vol_ms = (time.perf_counter() - t0) * 1e3
 

@@ -304,3 +304,37 @@ def test_eval_mode_with_grad_enabled_keeps_the_head_differentiable():
                                         local_map_dics=({}, {}), interaction_num=1, start_annotated_frame=clip.start,
                                         frame_num=[ii], dynamic_seghead=model.dynamic_seghead)
     torch.testing.assert_close(logits.detach(), fast[pc.SEQ], rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_batched_head_terms_equal_the_per_frame_ones():
+    """r6: model.prepare_head_terms computes layer 1's shared-embedding half for a clip's frames 8 per launch and stores it where
+    prop_seghead looks (the frames' memo holders): no shared-half launch in the loop, the same logits bit for bit"""
+    from examples import propagate_clip as pc
+    from cvpr2020_manet_amd import ops
+    dev = torch.device("cuda", 0)
+    args = pc.parse_args(["--frames", "11", "--fused-mask-step", "--height", "240", "--width", "428"])
+    cfg, model = pc.build_model(dev, None, None, None)
+    with torch.no_grad():
+        emb = pc.synthetic_clip(model, dev, args.frames, args.height, args.width, args.objects, packed=True)
+        clip = pc.Clip(cfg, model, emb, args.height, args.width, args.objects)
+        want = {}
+        clip.one_round(keep_logits=want)  # every frame computes and memoises its own term
+        model.drop_head_memos()
+        assert model._memo_bytes == 0
+        assert model.prepare_head_terms(emb) == args.frames and model.prepare_head_terms(emb) == args.frames
+        calls = {"n": 0}
+        real = ops.dwconv7x7_bn_relu
+
+        def counting(x, *a, **k):
+            calls["n"] += int(x.shape[1] == 100)
+            return real(x, *a, **k)
+        ops.dwconv7x7_bn_relu = counting
+        try:
+            got = {}
+            clip.one_round(keep_logits=got)
+        finally:
+            ops.dwconv7x7_bn_relu = real
+        assert calls["n"] == 1  # (the interaction head's own layer 1 on the annotated frame; no propagated frame computed a term)
+        for k in want:
+            assert torch.equal(got[k], want[k])
