@@ -293,3 +293,20 @@ def test_stored_volume_full_size_480p(ops):
     vols = ops.local_volumes([frames[0]], [frames[1]])
     assert vols.numel() * 4 == ops.local_volume_bytes(h, w, d) == 240 * 107520 + 1024  # (+ the last LDS-DMA piece's slack)
     assert torch.equal(ops.local_match_volume(vols[0], frames[1], lab, n_ids), ops.local_match_frames(frames[0], frames[1], lab, n_ids))
+
+
+@pytest.mark.parametrize("d,n_ids", [(4, 6), (12, 6), (12, 11)])
+def test_stored_volume_full_size_720p_grid(ops, d, n_ids):
+    """BASELINE configs[4]'s grid (180x320, C = 100) on 2-byte embeddings: two rounds of workgroups per launch at d = 12, more ids than
+    one per-pixel pass holds (11), labels outside [0, n_ids): the stored-volume path bit-equal to the fused kernel, both directions"""
+    torch.manual_seed(20200614 + 5 + d)
+    C, h, w = 100, 180, 320
+    embs = (torch.relu(torch.randn(3, C, h, w, device="cuda")) * 0.1).to(torch.bfloat16)
+    lab = torch.randint(-1, n_ids + 1, (h, w), dtype=torch.int32, device="cuda")
+    lab[40:120, 60:200] = 1  # a mask-like region too: rows whose window sees one label take the register path
+    frames = ops.prepare_frames(embs, compute="bf16", max_distance=d)
+    pairs = [(0, 1), (1, 2), (2, 1), (1, 0)]
+    vols = ops.local_volumes([frames[a] for a, _ in pairs], [frames[b] for _, b in pairs])
+    for i, (a, b) in enumerate(pairs):
+        want = ops.local_match_frames(frames[a], frames[b], lab, n_ids)
+        assert torch.equal(ops.local_match_volume(vols[i], frames[b], lab, n_ids), want)
