@@ -178,6 +178,10 @@ def test_bench_e2e_line_two_ranks_on_one_gpu():
     line = _run_json([sys.executable, os.path.join(ROOT, "bench.py"), "--e2e", "--gpus", "2", "--e2e-frames", "9"], env)
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["unit"] == "frames/s"
     assert line["collective"]["world"] == 2 and line["e2e_parallel"]["masks_bit_equal_to_single_rank"] is True
+    #  the bench line's `collective` block says what bounds the flow
+    col = line["collective"]
+    assert col["chain_us_per_frame"] > 0 and col["sharded_us_per_frame"] > 0 and col["chain_ranks"] == 2
+    assert col["amdahl_ceiling"] > 2.0 and col["measured_speedup"] > 0
     line1 = _run_json([sys.executable, os.path.join(ROOT, "bench.py"), "--e2e", "--e2e-frames", "9"], env)
     assert line1["n_gpus"] == 1 and line1["collective"] is None and line1["value"] > 0
 
