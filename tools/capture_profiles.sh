@@ -28,6 +28,8 @@ cp gpurun_out/$R/local/pmc_summary.csv gpurun_out/$R/${R}_local_pmc_summary.csv
 tools/e2e_launch_count.sh $R/e2e > gpurun_out/$R/${R}_e2e.log 2>&1
 cp gpurun_out/$R/e2e/per_frame_kernels.csv gpurun_out/$R/${R}_e2e_per_frame_kernels.csv
 tail -3 gpurun_out/$R/${R}_e2e.log
+tools/e2e_launch_count.sh $R/e2e_scribble --bank scribble > gpurun_out/$R/${R}_e2e_scribble.log 2>&1   # a session's rounds 2..8
+cp gpurun_out/$R/e2e_scribble/per_frame_kernels.csv gpurun_out/$R/${R}_e2e_per_frame_kernels_scribble_bank.csv
 python tools/pw_bench.py > gpurun_out/$R/${R}_head_pointwise.log 2>&1
 python tools/pw_rw_bench.py >> gpurun_out/$R/${R}_head_pointwise.log 2>&1
 tail -8 gpurun_out/$R/${R}_head_pointwise.log

@@ -1,15 +1,16 @@
 #!/bin/bash
 # Runs on the GPU box: kernel launches per propagated frame of examples/propagate_clip.py (eager loop), from two
 # rocprofv3 kernel traces of the SAME clip that differ only in the number of timed interaction rounds (1 vs 3): the
-# difference is 2 rounds of propagation -- no encoder, no warm-up, no one-off work.   usage: tools/e2e_launch_count.sh TAG
-TAG=$1
+# difference is 2 rounds of propagation -- no encoder, no warm-up, no one-off work.   usage: tools/e2e_launch_count.sh TAG [extra
+# propagate_clip.py arguments, e.g. --bank scribble: the strokes-only bank of a session's rounds 2..8]
+TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 F=31
 cd /tmp && export TMPDIR=/tmp
 for R in 1 3; do
-  timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r$R -o p -- python3 $REPO/examples/propagate_clip.py --frames $F --rounds $R --fused-mask-step > $OUT/r$R.log 2>&1
+  timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r$R -o p -- python3 $REPO/examples/propagate_clip.py --frames $F --rounds $R --fused-mask-step "$@" > $OUT/r$R.log 2>&1
 done
 cd $REPO
 python3 - $OUT $F <<'PY'

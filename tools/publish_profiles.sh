@@ -8,7 +8,7 @@ cp gpurun_out/$SRC/${SRC}_local_pmc_summary.csv profiles/${R}_local_pmc_summary.
 cp gpurun_out/$SRC/${SRC}_e2e_per_frame_kernels.csv profiles/${R}_e2e_per_frame_kernels.csv
 cp gpurun_out/$SRC/${SRC}_head_pointwise.log profiles/${R}_head_pointwise.log
 cp gpurun_out/$SRC/${SRC}_frame_prepare.log profiles/${R}_frame_prepare_local.log
-for f in head_pmc_summary.csv head_kernel_stats.csv local_volume_pmc_summary.csv local_volume_kernel_stats.csv; do
+for f in head_pmc_summary.csv head_kernel_stats.csv local_volume_pmc_summary.csv local_volume_kernel_stats.csv e2e_per_frame_kernels_scribble_bank.csv; do
   [ -f gpurun_out/$SRC/${SRC}_$f ] && cp gpurun_out/$SRC/${SRC}_$f profiles/${R}_$f
 done
 for c in "2 f32 global_match_f32_pipe_kernel" "3 bf16 global_match_bf16_wide_kernel<7, 0, false>" "5 bf16 global_match_bf16_wide_kernel<7, 0, false>" "3 bf16r global_match_bf16_wide_kernel<7, 0, true>" "2 bf16r global_match_bf16_wide_kernel<7, 0, true>"; do
