@@ -41,7 +41,8 @@ enum { MANET_TUNE_BLOCK_MAP = 0, MANET_TUNE_SPLITS = 1, MANET_TUNE_BF16_VARIANT 
        MANET_TUNE_ONE_ROUND = 10 /* 1: the fp32 kernel keeps the host's split count whatever the bank's real size (A/B timing) */,
        MANET_TUNE_RW_GROUPS = 11 /* resident-weights 1x1: pixel-range groups (default 256 = one per CU, two workgroups each) */,
        MANET_TUNE_RW_LDS_PAD = 12 /* ... and KiB of unused dynamic LDS added to its launch (caps its workgroups per CU; experiments) */,
-       MANET_TUNE_COUNT = 14 };
+       MANET_TUNE_DW_NARROW = 13 /* 0: the depthwise kernel tiles a narrow last column with standard 60 x 64 tiles (r2-r5; A/B timing and tests) */,
+       MANET_TUNE_COUNT = 15 };
 int manet_tune_get(int key, int dflt);
 
 static inline size_t manet_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

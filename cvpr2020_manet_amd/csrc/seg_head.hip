@@ -27,13 +27,21 @@
 namespace {
 
 constexpr int DW_K = 7, DW_R = 3;
-constexpr int DW_TY = 60, DW_TX = 64;      // 60 rows: 480p's 120 and 720p's 180 grid rows tile exactly; 33 row pairs of LDS
-// LDS columns: image columns x0-4 .. x0+67 (even start: aligned float2 loads) = 72, padded to 74: the row-pair stride
-// 148 floats = 20 (mod 64 banks) puts the four (row pair, column group) quads of a ds_read_b128 lane group on disjoint
-// banks (stride 144: 4-way conflicts on every window read)
-constexpr int DW_LW = 74;
-constexpr int DW_NP = (DW_TY + 2 * DW_R) / 2;  // 35 row pairs per image (rows y0-3 .. y0+66)
-constexpr int DW_IMG = DW_NP * DW_LW * 2;    // floats per interleaved image
+// Tile shapes.  DwStd: 60 rows (480p's 120 and 720p's 180 grid rows tile exactly; 33 row pairs of LDS) x 64 columns, 16 column groups of
+// 4 x 15 row groups of 4 = 240 of 256 threads.  LDS columns: image columns x0-4 .. x0+TX+3 (even start: aligned float2 loads) = 72,
+// padded to 74: the row-pair stride 148 floats = 20 (mod 64 banks) puts the four (row pair, column group) quads of a ds_read_b128 lane
+// group on disjoint banks (stride 144: 4-way conflicts on every window read).
+// DwNarrow (r6): 120 rows x 24 columns for the strip a plane's last tile column leaves when it holds at most 24 columns -- 480p's 214
+// columns are 3.34 tiles of 64: the fourth column's two 60 x 64 tiles did a full tile's work each for 22 of 64 columns; ONE 120 x 24 tile
+// (6 column groups x 30 row groups = 180 threads) covers the strip: 7 workgroups per plane instead of 8.
+struct DwStd {
+    static constexpr int TY = 60, TX = 64, CG = TX / 4, LW = 74, NP = (TY + 2 * DW_R) / 2, IMG = NP * LW * 2, NQ = (TX + 8) / 2;
+};
+struct DwNarrow {
+    static constexpr int TY = 120, TX = 24, CG = TX / 4, LW = 34, NP = (TY + 2 * DW_R) / 2, IMG = NP * LW * 2, NQ = (TX + 8) / 2;
+};
+static_assert(DwNarrow::IMG <= DwStd::IMG, "the narrow tile shares the standard tile's LDS array");
+constexpr int DW_TY = DwStd::TY, DW_TX = DwStd::TX, DW_IMG = DwStd::IMG;
 
 // FAST: w even (every aligned column pair is inside or outside the image as a whole, rows are 8-byte aligned)
 // r3b: a workgroup owns one (tile, channel) and walks the BATCH items (the objects of a frame): the next item's global loads
@@ -43,35 +51,19 @@ constexpr int DW_IMG = DW_NP * DW_LW * 2;    // floats per interleaved image
 // (the 4-byte-load form of odd widths needs ~148 registers: three workgroups per CU -- at four it spilled 20 of them, r4)
 // RELU_IN / RELU (r5): compile-time -- as run-time flags each staged element paid a select on top of its max (76 v_cndmask +
 // 76 v_max per item against 392 packed FMAs), each output one more.  (Worth ~1 % on a warm GPU: the kernel hides it.)
-template <bool FAST, bool RELU_IN, bool RELU, int ABL = 0>
-__global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(const float *__restrict__ in, int B, int C, int h, int w,
-                                                                   const float *__restrict__ weight,
-                                                                   const float *__restrict__ bias,
-                                                                   const float *__restrict__ scale,
-                                                                   const float *__restrict__ shift,
-                                                                   float *__restrict__ out, int per_item, int ntx, int nty)
+template <typename SH, bool FAST, bool RELU_IN, bool RELU, int ABL>
+__device__ __forceinline__ void dw_tile(float *__restrict__ tile, const float *__restrict__ in, int C, int h, int w,
+                                        const float *__restrict__ weight, const float *__restrict__ bias,
+                                        const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ out,
+                                        int c, int b_first, int b_end, int x0, int y0)
 {
     constexpr bool relu_in = RELU_IN, relu = RELU;
-    // XCD-aware block map (r5): block L runs on XCD L % 8; all tiles of a plane go to ONE XCD (plane z = 8 g + L % 8), so the halo
-    // rows / columns two neighbouring tiles share are hits in that XCD's L2 and the cache lines a tile boundary cuts (rows are
-    // 856 bytes at 480p: no tile edge is line-aligned) are completed in one L2 before they are written back.  r2-r4: a 3-D grid,
-    // tile index fastest -- the eight tiles of a plane sat on eight XCDs.
-    const int xcd_ = blockIdx.x & 7, j_ = blockIdx.x >> 3, ntile_ = ntx * nty;
-    const int tile_ = j_ % ntile_, bz = (j_ / ntile_) * 8 + xcd_;
-    const int bx = tile_ % ntx, by = tile_ / ntx;
-    if (bz >= (per_item ? B * C : C)) return;
-    // E: element (r, col) at ((r >> 1) * LW + col) * 2 + (r & 1), r = row - (y0 - 3); O: the same for r - 1
-    __shared__ __attribute__((aligned(16))) float tile[2 * DW_IMG];
-    // per_item (r4): few channels (layer 1's 3 per-object ones: 24 workgroups walking 3 items each = 3 serial round trips on a
-    // tenth of the chip) -- a workgroup per (tile, channel, batch item) instead of the batch walk
-    const int c = per_item ? bz % C : bz;
-    const int b_first = per_item ? bz / C : 0, b_end = per_item ? b_first + 1 : B;
-    const int x0 = bx * DW_TX, y0 = by * DW_TY;
+    constexpr int DW_LW = SH::LW, DW_NP = SH::NP, DW_IMG = SH::IMG, DW_TY = SH::TY;
     const long plane = (long)h * w;
     const int tid = threadIdx.x;
     // staging item = (row pair p, column pair q): rows 2p, 2p+1, 2p+2 of the tile, two columns -- one b128 store into E
     // (rows 2p, 2p+1) and one into O (rows 2p+1, 2p+2).  Branch-free: clamped addresses, values selected afterwards.
-    constexpr int NQ = 36, NITEM = DW_NP * NQ, KI = (NITEM + 255) / 256;  // 36 column pairs = image columns x0-4 .. x0+67
+    constexpr int NQ = SH::NQ, NITEM = DW_NP * NQ, KI = (NITEM + 255) / 256;  // column pairs = image columns x0-4 .. x0+TX+3
     // pass 1: every load of the thread is issued (clamped addresses, no predicate anywhere near them); pass 2 selects,
     // rectifies and stores.  Written as one loop, hipcc sinks each load into the branch of its select and waits
     // vmcnt(0) there: 15 serial L2 round trips per thread (r2 trace: this, not the 392 FMAs, was the kernel's time).
@@ -116,7 +108,7 @@ __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(co
     // B = (4t+2, 4t+3) share seven of the nine input row-pair lines they need, so each line is read once and used for both (27
     // ds_read_b128 per item instead of 56), and a store instruction's 16 lanes of a row write 256 contiguous bytes (the eight-column
     // form stored 16-byte pieces 32 bytes apart, twice)
-    const int t = tid >> 4, tg = tid & 15;  // output rows 4t .. 4t+3, columns 4 tg .. 4 tg + 3
+    const int t = tid / SH::CG, tg = tid - t * SH::CG;  // output rows 4t .. 4t+3, columns 4 tg .. 4 tg + 3
     issue_loads(b_first);
     for (int b = b_first; b < b_end; ++b) {
 #pragma unroll
@@ -213,6 +205,41 @@ __global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(co
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next item's staging overwrites the tile)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    }
+}
+
+template <bool FAST, bool RELU_IN, bool RELU, int ABL = 0>
+__global__ __launch_bounds__(256, FAST ? 4 : 3) void dwconv7x7_bn_relu_kernel(const float *__restrict__ in, int B, int C, int h, int w,
+                                                                   const float *__restrict__ weight,
+                                                                   const float *__restrict__ bias,
+                                                                   const float *__restrict__ scale,
+                                                                   const float *__restrict__ shift,
+                                                                   float *__restrict__ out, int per_item, int ntx, int nty,
+                                                                   int nstd, int ntile_)
+{
+    // XCD-aware block map (r5): block L runs on XCD L % 8; all tiles of a plane go to ONE XCD (plane z = 8 g + L % 8), so the halo
+    // rows / columns two neighbouring tiles share are hits in that XCD's L2 and the cache lines a tile boundary cuts (rows are
+    // 856 bytes at 480p: no tile edge is line-aligned) are completed in one L2 before they are written back.  r2-r4: a 3-D grid,
+    // tile index fastest -- the eight tiles of a plane sat on eight XCDs.
+    // Tiles of a plane (r6): `nstd` standard 60 x 64 tiles over the first ntx (- 1) tile columns, then -- when the last column holds at
+    // most 24 image columns -- 120 x 24 tiles for that strip (nstd < ntile_), else nstd == ntile_ == ntx * nty.
+    const int xcd_ = blockIdx.x & 7, j_ = blockIdx.x >> 3;
+    const int tile_ = j_ % ntile_, bz = (j_ / ntile_) * 8 + xcd_;
+    if (bz >= (per_item ? B * C : C)) return;
+    // E: element (r, col) at ((r >> 1) * LW + col) * 2 + (r & 1), r = row - (y0 - 3); O: the same for r - 1
+    __shared__ __attribute__((aligned(16))) float tile[2 * DW_IMG];
+    // per_item (r4): few channels (layer 1's 3 per-object ones: 24 workgroups walking 3 items each = 3 serial round trips on a
+    // tenth of the chip) -- a workgroup per (tile, channel, batch item) instead of the batch walk
+    const int c = per_item ? bz % C : bz;
+    const int b_first = per_item ? bz / C : 0, b_end = per_item ? b_first + 1 : B;
+    if (tile_ < nstd) {
+        const int ncol = nstd / nty;  // standard tile columns
+        const int bx = tile_ % ncol, by = tile_ / ncol;
+        dw_tile<DwStd, FAST, RELU_IN, RELU, ABL>(tile, in, C, h, w, weight, bias, scale, shift, out, c, b_first, b_end, bx * DwStd::TX,
+                                                 by * DwStd::TY);
+    } else {
+        dw_tile<DwNarrow, FAST, RELU_IN, RELU, ABL>(tile, in, C, h, w, weight, bias, scale, shift, out, c, b_first, b_end,
+                                                    (nstd / nty) * DwStd::TX, (tile_ - nstd) * DwNarrow::TY);
     }
 }
 
@@ -1064,15 +1091,20 @@ extern "C" int manet_dwconv7x7_bn_relu_ex(const float *in, int B, int C, int h, 
         return manet_set_error(MANET_E_INVALID, "bad arguments (B*C must be <= 65535)");
     if (C > 65535) return manet_set_error(MANET_E_INVALID, "C must be <= 65535");
     const int ntx = (w + DW_TX - 1) / DW_TX, nty = (h + DW_TY - 1) / DW_TY;
+    // the strip behind the last full tile column: 120 x 24 tiles instead of 60 x 64 ones when it holds at most 24 columns (480p: 22)
+    const int rem = w - (ntx - 1) * DW_TX;
+    const bool narrow = ntx >= 2 && rem <= DwNarrow::TX && manet_tune_get(MANET_TUNE_DW_NARROW, 1) != 0;
+    const int nstd = narrow ? (ntx - 1) * nty : ntx * nty;
+    const int ntile = narrow ? nstd + (h + DwNarrow::TY - 1) / DwNarrow::TY : nstd;
     // the batch walk pays when every CU has workgroups to overlap; below two workgroups per CU the items go into the grid
-    const int per_item = (B > 1 && (long)ntx * nty * C < 512) ? 1 : 0;
+    const int per_item = (B > 1 && (long)ntile * C < 512) ? 1 : 0;
     const long planes = per_item ? (long)B * C : C;
-    const long nblocks = 8L * ntx * nty * ((planes + 7) / 8);  // (planes in groups of eight: one per XCD)
+    const long nblocks = 8L * ntile * ((planes + 7) / 8);  // (planes in groups of eight: one per XCD)
     if (nblocks > 0x7fffffffL) return manet_set_error(MANET_E_INVALID, "too many tiles for one launch");
     dim3 grid((unsigned)nblocks);
 #define DW_LAUNCH2(F_, RI_, R_, A_)                                                                                    \
     hipLaunchKernelGGL((dwconv7x7_bn_relu_kernel<F_, RI_, R_, A_>), grid, dim3(256), 0, (hipStream_t)stream, in, B, C, h, w, weight, \
-                       bias, bn_scale, bn_shift, out, per_item, ntx, nty)
+                       bias, bn_scale, bn_shift, out, per_item, ntx, nty, nstd, ntile)
 #define DW_LAUNCH(F_, A_)                                                                                              \
     do {                                                                                                               \
         if (relu_in && relu) DW_LAUNCH2(F_, true, true, A_);                                                           \

@@ -489,3 +489,32 @@ def test_fused_layer1_refuses_what_it_cannot_take():
         ops.head_layer1_object(g, l, lab, n, (h, w), wd[:2], None, None, None, w2, b2, term)
     with pytest.raises(RuntimeError):
         ops.head_layer1_object(g.requires_grad_(), l, lab, n, (h, w), wd, None, None, None, w2, b2, term)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 256, 120, 214), (2, 5, 121, 150), (1, 3, 64, 129), (2, 4, 250, 80), (1, 2, 7, 66)])
+def test_depthwise_narrow_last_column_tiles_equal_the_standard_tiling(shape):
+    """r6: a plane's last tile column that holds at most 24 image columns (480p: 214 = 3 x 64 + 22) is covered by 120 x 24 tiles instead
+    of 60 x 64 ones (7 workgroups per plane instead of 8).  Same taps in the same order: bit-equal to the standard tiling (tuning key 13
+    = 0), on shapes with one / several narrow tiles per plane, ragged bottoms, even and odd widths, the per-item grid of few channels."""
+    import os
+    from cvpr2020_manet_amd import _lib, ops
+    torch.manual_seed(sum(shape))
+    B, C, h, w = shape
+    x = torch.randn(B, C, h, w, device="cuda")
+    wt = torch.randn(C, 1, 7, 7, device="cuda") * 0.2
+    bias = torch.randn(C, device="cuda")
+    sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda")
+    lib = _lib.load()
+    os.environ["MANET_TUNING"] = "1"
+    with torch.no_grad():
+        got = ops.dwconv7x7_bn_relu(x, wt, bias, scale=sc, shift=sh, relu_in=True)
+        _lib.check(lib.manet_tune_set(13, 0), "manet_tune_set")  # MANET_TUNE_DW_NARROW
+        try:
+            std = ops.dwconv7x7_bn_relu(x, wt, bias, scale=sc, shift=sh, relu_in=True)
+        finally:
+            _lib.check(lib.manet_tune_set(13, -2 ** 31), "manet_tune_set")
+        want = torch.relu((torch.nn.functional.conv2d(torch.relu(x), wt, bias, padding=3, groups=C)) * sc[None, :, None, None]
+                          + sh[None, :, None, None])
+    assert torch.equal(got, std)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-4)
